@@ -1,0 +1,207 @@
+/*
+ * sgx.h -- C ABI of the MI355X (gfx950) streaming-STFT spectrogram engine.
+ *
+ * This is the drop-in boundary for ONE path of JacksonCampolattaro/spectrogram-rs: PCM ->
+ * Hann + 2x zero-pad -> c2c FFT -> stereo magnitudes -> log-frequency resample -> dB -> colour
+ * -> RGBA pixel columns.  Every entry point names the reference interface it replaces
+ * (file:line relative to the reference repository).  Plain pointers and sizes only; no C++ or
+ * framework types cross this boundary.  INTEGRATION.md shows the Rust `extern "C"` binding a
+ * maintainer of the reference would add.
+ *
+ * Conventions
+ *   - All `d_*` pointers are DEVICE pointers (hipMalloc'ed, or a torch tensor's data_ptr()).
+ *     All `h_*` pointers are host pointers.  The caller owns every I/O buffer.
+ *   - Work is enqueued on the context's stream (sgx_set_stream; default: the NULL stream) and is
+ *     asynchronous; sgx_sync() waits for it.
+ *   - Every function returns SGX_OK (0) or a negative sgx_status; the text of the last error is
+ *     available from sgx_last_error().  The library never aborts the host process (the
+ *     reference unwrap()s: fft.rs:24,77).
+ *   - A context is not thread-safe: one context per thread / stream / GPU (the reference holds
+ *     its transform in a RefCell on the GTK main thread: gpu_spectrogram.rs:58).
+ *   - There is NO CPU fallback: without a HIP device sgx_create() fails with SGX_ERR_NO_DEVICE.
+ */
+#ifndef SGX_H
+#define SGX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define SGX_API __attribute__((visibility("default")))
+#else
+#define SGX_API
+#endif
+
+typedef enum sgx_status {
+    SGX_OK = 0,
+    SGX_ERR_INVALID_ARG = -1,
+    SGX_ERR_UNSUPPORTED = -2, /* e.g. a transform length this build has no kernel for */
+    SGX_ERR_HIP = -3,         /* a HIP runtime call failed; see sgx_last_error */
+    SGX_ERR_NOMEM = -4,
+    SGX_ERR_NO_DEVICE = -5
+} sgx_status;
+
+/* interpolated_frequency_sample.rs:46-48 calls cubic_interpolate (:88-105); cosine_interpolate
+ * (:78-86) is dead code there but is what README.md:19-20 and BASELINE config 3 name. */
+#define SGX_INTERP_CUBIC 0u
+#define SGX_INTERP_COSINE 1u
+
+/* colorous Gradient::eval_continuous index rule for 256-entry ramps (un-vendored crate; the
+ * rule is an input so it can be corrected without touching kernels) */
+#define SGX_LUT_FLOOR_N 0u   /* idx = clamp(floor(t * n), 0, n-1) */
+#define SGX_LUT_ROUND_NM1 1u /* idx = clamp(round(t * (n-1)), 0, n-1) */
+
+typedef struct sgx_ctx sgx_ctx;
+
+/* One plain struct replaces the reference's compile-time constants:
+ *   FastFourierTransform::new(sample_rate, period)                      fft.rs:18
+ *   AudioStreamTransform::new(stream, transform, stride)                audio_transform.rs:22-32
+ *   TEXTURE_HEIGHT = 1024, y range 32..22030 Hz                         simple_spectrogram.rs:34-35,107
+ *   MIN_DB = -70, MAX_DB = -10                                          colorscheme.rs:16-17        */
+typedef struct sgx_config {
+    uint32_t struct_size;    /* = sizeof(sgx_config); set by sgx_config_init */
+    float sample_rate;       /* Hz */
+    float period;            /* s; W = (period * sample_rate) as usize            (fft.rs:19)  */
+    float stride;            /* s; H = (stride * sample_rate) as usize  (audio_transform.rs:35) */
+    uint32_t window_samples; /* if non-zero, W directly (period ignored)                        */
+    uint32_t hop_samples;    /* if non-zero, H directly (stride ignored)                        */
+    uint32_t channels;       /* interleaved channels in the PCM stream: 1 = mono, expanded to
+                                (s, s) as audio_input_list_model.rs:67-69 does; 2 = (l, r);
+                                2k = k independent (l, r) pairs (extension, BASELINE config 4)  */
+    uint32_t rows;           /* R, pixel rows per column (default 1024)                         */
+    double f_min, f_max;     /* log axis range in Hz (default 32, 22030)                        */
+    float min_db, max_db;    /* default -70, -10                                                */
+    uint32_t interp;         /* SGX_INTERP_*                                                    */
+    uint32_t lut_index_mode; /* SGX_LUT_*                                                       */
+    int32_t device;          /* HIP device ordinal, or -1 for the current device                */
+    uint32_t flags;          /* SGX_FLAG_*                                                      */
+} sgx_config;
+
+#define SGX_FLAG_FORCE_GENERIC 1u /* use the generic power-of-two kernel even where a tuned one exists (testing) */
+
+typedef struct sgx_info {
+    uint32_t struct_size;
+    uint32_t window_samples;  /* W  = num_input_samples()            fft.rs:41 */
+    uint32_t fft_length;      /* P  = 2 W                            fft.rs:44 */
+    uint32_t num_frequencies; /* M  = num_output_frequencies() = W-1 fft.rs:33 */
+    uint32_t hop_samples;     /* H                                              */
+    uint32_t channels;
+    uint32_t pairs;           /* (l, r) pairs per hop position: 1 for mono/stereo, channels/2 otherwise */
+    uint32_t rows;            /* R */
+    uint32_t sample_rate_u32; /* SampleRate(sample_rate as u32)      simple_spectrogram.rs:138 */
+    uint32_t total_samples_per_column; /* sum over rows of magnitude_in's sample count */
+    uint32_t stft_kernel;     /* 0 = generic power-of-two, 1 = tuned 4096-point wave-per-frame */
+    uint32_t reserved;
+    uint64_t mags_bytes_per_frame; /* pairs * M * 2 * 4 */
+    uint64_t rgba_bytes_per_frame; /* pairs * R * 4     */
+} sgx_info;
+
+/* ---- lifetime ---------------------------------------------------------------------------- */
+
+SGX_API const char *sgx_version(void);
+
+/* Fill `cfg` with the reference's defaults for BASELINE config A:
+ * 48 kHz, W 2048 / H 256 (given as window_samples / hop_samples), 1 channel, 1024 rows,
+ * 32..22030 Hz, -70..-10 dB, cubic interpolation, SGX_LUT_FLOOR_N, current device. */
+SGX_API int sgx_config_init(sgx_config *cfg);
+
+/* Replaces FastFourierTransform::new (fft.rs:18-31: FFTW planning) + AudioStreamTransform::new
+ * (audio_transform.rs:22-32) + SimpleSpectrogram's axis/palette construction
+ * (simple_spectrogram.rs:88-113).  Builds the Hann table, twiddles, per-row resampling tables,
+ * dB thresholds and the default gradient (Magma, simple_spectrogram.rs:95) on the device. */
+SGX_API int sgx_create(const sgx_config *cfg, sgx_ctx **out_ctx);
+SGX_API void sgx_destroy(sgx_ctx *ctx);
+
+/* Text of the most recent error on this context (ctx == NULL: most recent sgx_create failure on
+ * the calling thread).  Never NULL. */
+SGX_API const char *sgx_last_error(const sgx_ctx *ctx);
+
+SGX_API int sgx_query(const sgx_ctx *ctx, sgx_info *out);
+
+/* Number of frames the hop loop of AudioStreamTransform::process (audio_transform.rs:34-42)
+ * yields from n_samples samples per channel: max(0, (n - W) / H + 1).  Frame t covers samples
+ * [t*H, t*H + W).  (The reference also skips H samples on its terminating short read -- a
+ * live-capture artefact that a batch engine must not reproduce.) */
+SGX_API size_t sgx_num_frames(const sgx_ctx *ctx, size_t n_samples);
+
+/* `stream` is a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = default. */
+SGX_API int sgx_set_stream(sgx_ctx *ctx, void *stream);
+SGX_API int sgx_sync(sgx_ctx *ctx);
+
+/* ---- the transform: replaces AudioTransform::process / AudioStreamTransform::process ----- */
+
+/* Batched FastFourierTransform::process (fft.rs:43-99) driven by the hop loop
+ * (audio_transform.rs:34-42).
+ *   d_pcm   [n_samples][channels] float, interleaved
+ *   d_mags  [n_out][pairs][M][2] float: (left, right) magnitudes of bins k = 1..W-1, scaled 2/W
+ * Frames [first_frame, first_frame + max_frames) that exist are produced; *n_out (may be NULL)
+ * receives how many.  Too few samples is not an error: *n_out = 0 (the reference returns None,
+ * fft.rs:72). */
+SGX_API int sgx_stft_batch(sgx_ctx *ctx, const float *d_pcm, size_t n_samples, size_t first_frame,
+                           size_t max_frames, float *d_mags, size_t *n_out);
+
+/* One call of AudioTransform::process (audio_transform.rs:10, fft.rs:43) on HOST buffers, for a
+ * per-frame shim: h_lr [n_avail][2] (l, r) pairs, h_out [M][2].  Returns 1 (Some), 0 (None:
+ * n_avail < W) or a negative sgx_status.  Synchronous. */
+SGX_API int sgx_process_one(sgx_ctx *ctx, const float *h_lr, size_t n_avail, float *h_out);
+
+/* ---- the pixel path: replaces the loop of SimpleSpectrogram::snapshot --------------------- */
+
+/* PCM -> RGBA pixel columns in one call (simple_spectrogram.rs:136-165 for every frame):
+ * InterpolatedFrequencySample::magnitude_in over the log-spaced row edges of
+ * LogCoordf64::unmap (log_scaling.rs:114-119), ColorScheme::color_for (colorscheme.rs:55-71),
+ * Pixbuf::put_pixel (simple_spectrogram.rs:153-160).
+ *   d_rgba [n_out][pairs][R][4] uint8; index [y] is the IMAGE row y = R-1-py, i.e. row 0 is the
+ *   highest frequency, exactly the column that put_pixel writes (simple_spectrogram.rs:150). */
+SGX_API int sgx_render_batch(sgx_ctx *ctx, const float *d_pcm, size_t n_samples, size_t first_frame,
+                             size_t max_frames, uint8_t *d_rgba, size_t *n_out);
+
+/* The pixel stage alone, from magnitudes already on the device (stage-wise parity):
+ *   d_mags [n_columns][M][2] -> d_rgba [n_columns][R][4]. */
+SGX_API int sgx_render_mags(sgx_ctx *ctx, const float *d_mags, size_t n_columns, uint8_t *d_rgba);
+
+/* ---- ColorScheme ---------------------------------------------------------------------------- */
+
+/* ColorScheme::new_mono(gradient, name) / new_stereo(gradient, background, name)
+ * (colorscheme.rs:24-39).  h_rgb: [n][3] table standing in for colorous' Gradient; stereo != 0
+ * selects the diverging branch of color_for (colorscheme.rs:63-66: colour from the left/right
+ * balance, alpha from the bounded dB magnitude). */
+SGX_API int sgx_set_gradient(sgx_ctx *ctx, const uint8_t *h_rgb, uint32_t n, int stereo);
+/* "viridis" | "magma" | "inferno" | "plasma" (colorscheme.rs:131-139) */
+SGX_API int sgx_set_builtin_gradient(sgx_ctx *ctx, const char *name);
+SGX_API int sgx_builtin_gradient(const char *name, uint8_t *h_rgb_out /* [256][3] */);
+
+/* ColorScheme::lookup_table(resolution) (colorscheme.rs:73-92): h_out [res][res][4] float,
+ * the palette texture of the GLSL path (gpu_spectrogram.rs:233-238). */
+SGX_API int sgx_lookup_table(sgx_ctx *ctx, uint32_t resolution, float *h_out);
+
+/* ---- introspection (tests, tooling) --------------------------------------------------------- */
+
+/* R+1 row edges in Hz as f32: LogCoordf64::unmap(p, (0, R)) for p = 0..R
+ * (log_scaling.rs:114-119; simple_spectrogram.rs:142-145). */
+SGX_API int sgx_bin_edges(const sgx_ctx *ctx, float *h_out);
+/* per-row sample counts of magnitude_in (interpolated_frequency_sample.rs:63-64): h_out [R] */
+SGX_API int sgx_row_sample_counts(const sgx_ctx *ctx, uint32_t *h_out);
+/* the Hann table (fft.rs:61): h_out [W] */
+SGX_API int sgx_window(const sgx_ctx *ctx, float *h_out);
+
+/* ---- synthetic input + verification helpers (bench / multi-GPU harness, not reference API) -- */
+
+/* Counter-based white noise, identical on CPU and GPU:
+ * x[n] = ((lowbias32((seed + hi32(n) * 0x9E3779B9) ^ lo32(n)) >> 8) * 2^-23) - 1.
+ * Writes d_out[i * channels + c] for sample index first + i and channel c (seed + c). */
+SGX_API int sgx_synth_white_noise(sgx_ctx *ctx, float *d_out, uint64_t first, size_t n_samples,
+                                  uint32_t channels, uint32_t seed);
+/* 64-bit order-independent checksum (sum of a 64-bit mix of each (index, 32-bit word)) of a device buffer of
+ * n_bytes (multiple of 4), with word indices starting at base_word: equal for any sharding of
+ * the same bytes.  Synchronous. */
+SGX_API int sgx_checksum(sgx_ctx *ctx, const void *d_buf, size_t n_bytes, uint64_t base_word, uint64_t *h_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SGX_H */

@@ -1,0 +1,596 @@
+/*
+ * spectro_oracle.c -- CPU restatement of the spectrogram-rs hot path.  TEST INFRASTRUCTURE ONLY.
+ * See spectro_oracle.h for scope, citations and the "PARITY UNPINNED" statement.
+ *
+ * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off: no FMA contraction, so every f32
+ * operation rounds exactly once, as rustc's default code generation does).
+ *
+ * Citations are file:line in /root/reference (the reference is NOT needed at build or run time).
+ */
+#define _GNU_SOURCE
+#include "spectro_oracle.h"
+
+#include <math.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------------------------ */
+/* sizes                                                                                      */
+/* ------------------------------------------------------------------------------------------ */
+
+/* Rust `f as usize`: truncation toward zero, saturating, NaN -> 0 */
+static size_t f32_as_usize(float v)
+{
+    if (!(v > 0.0f)) return 0; /* also NaN */
+    if (v >= 18446744073709551616.0f) return (size_t)-1;
+    return (size_t)v;
+}
+static size_t f64_as_usize(double v)
+{
+    if (!(v > 0.0)) return 0;
+    if (v >= 18446744073709551616.0) return (size_t)-1;
+    return (size_t)v;
+}
+
+size_t orc_window_samples(float sample_rate, float period)
+{
+    /* fft.rs:19, :41 -- (period * sample_rate) as usize */
+    volatile float prod = period * sample_rate;
+    return f32_as_usize(prod);
+}
+
+size_t orc_hop_samples(float sample_rate, float stride)
+{
+    /* audio_transform.rs:35 -- (self.stride * self.transform.sample_rate()) as usize */
+    volatile float prod = stride * sample_rate;
+    return f32_as_usize(prod);
+}
+
+size_t orc_num_frames(size_t n, size_t W, size_t H)
+{
+    /* audio_transform.rs:37-41: a frame is produced while at least W samples can be peeked,
+     * then H are skipped.  Batch form (quirk Q1 not reproduced). */
+    if (W == 0 || H == 0 || n < W) return 0;
+    return (n - W) / H + 1;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* FFT: forward, unnormalised, F[k] = sum_n z[n] e^{-2 pi i n k / P}                          */
+/* [third-party] fftw 0.8.0 -> FFTW3 fftwf_plan_dft_1d(P, FORWARD, MEASURE) (fft.rs:20-24,77). */
+/* FFTW's plan is chosen by timing, so its rounding is not reproducible; what is restated is  */
+/* the DFT it computes, with a plain mixed-radix decimation-in-time recursion in the same     */
+/* working precision (float, twiddles rounded from double) -- and in double for ORC_F64.      */
+/* ------------------------------------------------------------------------------------------ */
+
+typedef struct { float re, im; } cf;
+typedef struct { double re, im; } cd;
+
+typedef struct {
+    size_t P;
+    cf *twf; /* twf[j] = e^{-2 pi i j / P}, rounded from double */
+    cd *twd;
+} plan_t;
+
+static size_t smallest_factor(size_t n)
+{
+    if ((n & 1) == 0) return 2;
+    for (size_t p = 3; p * p <= n; p += 2)
+        if (n % p == 0) return p;
+    return n;
+}
+
+static plan_t *plan_new(size_t P)
+{
+    plan_t *pl = (plan_t *)malloc(sizeof(plan_t));
+    pl->P = P;
+    pl->twf = (cf *)malloc(sizeof(cf) * P);
+    pl->twd = (cd *)malloc(sizeof(cd) * P);
+    for (size_t j = 0; j < P; ++j) {
+        /* exact octant reduction is not needed at these sizes: cos/sin of a double angle */
+        double ang = -2.0 * M_PI * (double)j / (double)P;
+        double c = cos(ang), s = sin(ang);
+        /* make the axis values exact */
+        if (4 * j == P) { c = 0.0; s = -1.0; }
+        if (2 * j == P) { c = -1.0; s = 0.0; }
+        if (4 * j == 3 * P) { c = 0.0; s = 1.0; }
+        pl->twd[j].re = c; pl->twd[j].im = s;
+        pl->twf[j].re = (float)c; pl->twf[j].im = (float)s;
+    }
+    return pl;
+}
+
+#define PLAN_CACHE 8
+static plan_t *g_plans[PLAN_CACHE];
+static pthread_mutex_t g_plan_lock = PTHREAD_MUTEX_INITIALIZER;
+
+static const plan_t *plan_get(size_t P)
+{
+    pthread_mutex_lock(&g_plan_lock);
+    int slot = -1;
+    for (int i = 0; i < PLAN_CACHE; ++i) {
+        if (g_plans[i] && g_plans[i]->P == P) { plan_t *p = g_plans[i]; pthread_mutex_unlock(&g_plan_lock); return p; }
+        if (!g_plans[i] && slot < 0) slot = i;
+    }
+    plan_t *pl = plan_new(P);
+    if (slot < 0) slot = 0; /* leak the evicted plan deliberately: another thread may hold it */
+    g_plans[slot] = pl;
+    pthread_mutex_unlock(&g_plan_lock);
+    return pl;
+}
+
+static inline cf cf_mul(cf a, cf b)
+{
+    cf r;
+    r.re = a.re * b.re - a.im * b.im;
+    r.im = a.re * b.im + a.im * b.re;
+    return r;
+}
+static inline cd cd_mul(cd a, cd b)
+{
+    cd r;
+    r.re = a.re * b.re - a.im * b.im;
+    r.im = a.re * b.im + a.im * b.re;
+    return r;
+}
+
+/* out[0..n) = DFT_n(in[0], in[istride], ...); tw[j*ts] = w_n^j */
+static void fft_rec_f(const cf *in, size_t istride, cf *out, size_t n, const cf *tw, size_t ts)
+{
+    if (n == 1) { out[0] = in[0]; return; }
+    size_t p = smallest_factor(n), m = n / p;
+    for (size_t q = 0; q < p; ++q) fft_rec_f(in + q * istride, istride * p, out + q * m, m, tw, ts * p);
+    if (p == 2) {
+        for (size_t k = 0; k < m; ++k) {
+            cf t = cf_mul(out[m + k], tw[k * ts]);
+            cf a = out[k];
+            out[k].re = a.re + t.re; out[k].im = a.im + t.im;
+            out[k + m].re = a.re - t.re; out[k + m].im = a.im - t.im;
+        }
+        return;
+    }
+    cf ybuf[64];
+    cf *y = p <= 64 ? ybuf : (cf *)malloc(sizeof(cf) * p);
+    for (size_t k = 0; k < m; ++k) {
+        for (size_t q = 0; q < p; ++q) y[q] = q ? cf_mul(out[q * m + k], tw[(q * k) * ts]) : out[k];
+        for (size_t r = 0; r < p; ++r) {
+            cf acc = y[0];
+            for (size_t q = 1; q < p; ++q) {
+                cf t = cf_mul(y[q], tw[((q * r * m) % n) * ts]);
+                acc.re += t.re; acc.im += t.im;
+            }
+            out[k + r * m] = acc;
+        }
+    }
+    if (y != ybuf) free(y);
+}
+
+static void fft_rec_d(const cd *in, size_t istride, cd *out, size_t n, const cd *tw, size_t ts)
+{
+    if (n == 1) { out[0] = in[0]; return; }
+    size_t p = smallest_factor(n), m = n / p;
+    for (size_t q = 0; q < p; ++q) fft_rec_d(in + q * istride, istride * p, out + q * m, m, tw, ts * p);
+    if (p == 2) {
+        for (size_t k = 0; k < m; ++k) {
+            cd t = cd_mul(out[m + k], tw[k * ts]);
+            cd a = out[k];
+            out[k].re = a.re + t.re; out[k].im = a.im + t.im;
+            out[k + m].re = a.re - t.re; out[k + m].im = a.im - t.im;
+        }
+        return;
+    }
+    cd ybuf[64];
+    cd *y = p <= 64 ? ybuf : (cd *)malloc(sizeof(cd) * p);
+    for (size_t k = 0; k < m; ++k) {
+        for (size_t q = 0; q < p; ++q) y[q] = q ? cd_mul(out[q * m + k], tw[(q * k) * ts]) : out[k];
+        for (size_t r = 0; r < p; ++r) {
+            cd acc = y[0];
+            for (size_t q = 1; q < p; ++q) {
+                cd t = cd_mul(y[q], tw[((q * r * m) % n) * ts]);
+                acc.re += t.re; acc.im += t.im;
+            }
+            out[k + r * m] = acc;
+        }
+    }
+    if (y != ybuf) free(y);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* FastFourierTransform::process  (fft.rs:43-99)                                              */
+/* ------------------------------------------------------------------------------------------ */
+
+void orc_hann_window(size_t W, float *out)
+{
+    /* fft.rs:61: 0.5 * (1.0 - ((f32::TAU() * i as f32) / (W as f32)).cos())
+     * TAU_f32 = 6.2831855; product rounded to f32 BEFORE the divide (quirk Q6). */
+    const float tau = 6.28318530717958647692528676655900577f;
+    const float wf = (float)W;
+    for (size_t i = 0; i < W; ++i) {
+        volatile float prod = tau * (float)i;
+        volatile float q = prod / wf;
+        float c = cosf(q);
+        volatile float om = 1.0f - c;
+        out[i] = 0.5f * om;
+    }
+}
+
+/* work buffers for one frame */
+typedef struct {
+    cf *zf, *Ff;
+    cd *zd, *Fd;
+    float *win;
+} frame_ws;
+
+static frame_ws *ws_new(size_t W)
+{
+    frame_ws *ws = (frame_ws *)malloc(sizeof(frame_ws));
+    size_t P = 2 * W;
+    ws->zf = (cf *)malloc(sizeof(cf) * P);
+    ws->Ff = (cf *)malloc(sizeof(cf) * P);
+    ws->zd = (cd *)malloc(sizeof(cd) * P);
+    ws->Fd = (cd *)malloc(sizeof(cd) * P);
+    ws->win = (float *)malloc(sizeof(float) * (W ? W : 1));
+    orc_hann_window(W, ws->win);
+    return ws;
+}
+static void ws_free(frame_ws *ws)
+{
+    free(ws->zf); free(ws->Ff); free(ws->zd); free(ws->Fd); free(ws->win); free(ws);
+}
+
+/* l, r: pointers to the first left / right sample, with the given element strides */
+static void process_frame(const plan_t *pl, frame_ws *ws, const float *l, size_t lstride, const float *r,
+                          size_t rstride, size_t W, int precision, float *out, double *out64)
+{
+    const size_t P = 2 * W, M = W - 1;
+    /* fft.rs:48-69: pack (l, r) -> l + i r; multiply by the Hann factor (complex * real);
+     * pad with zeros to 2W; window occupies [0, W). */
+    for (size_t i = 0; i < W; ++i) {
+        float s = ws->win[i];
+        ws->zf[i].re = l[i * lstride] * s;
+        ws->zf[i].im = r[i * rstride] * s;
+    }
+    for (size_t i = W; i < P; ++i) { ws->zf[i].re = 0.0f; ws->zf[i].im = 0.0f; }
+
+    if (precision == ORC_F32) {
+        /* fft.rs:76-77 */
+        fft_rec_f(ws->zf, 1, ws->Ff, P, pl->twf, 1);
+        /* fft.rs:81-98: a = F[k], b = F[P-k], k = 1..M
+         *   left  = norm(a + conj(b)) / 2.0 ; right = norm(a - conj(b)) / 2.0   (norm = hypotf)
+         *   then * (2.0 / W as f32) */
+        const float scale = 2.0f / (float)W;
+        for (size_t j = 0; j < M; ++j) {
+            size_t k = j + 1;
+            cf a = ws->Ff[k], b = ws->Ff[P - k];
+            volatile float sre = a.re + b.re, sim = a.im - b.im; /* a + conj(b) */
+            volatile float dre = a.re - b.re, dim = a.im + b.im; /* a - conj(b) */
+            volatile float left = hypotf(sre, sim) / 2.0f;
+            volatile float right = hypotf(dre, dim) / 2.0f;
+            out[2 * j + 0] = left * scale;
+            out[2 * j + 1] = right * scale;
+        }
+    } else {
+        for (size_t i = 0; i < P; ++i) { ws->zd[i].re = ws->zf[i].re; ws->zd[i].im = ws->zf[i].im; }
+        fft_rec_d(ws->zd, 1, ws->Fd, P, pl->twd, 1);
+        const double scale = 2.0 / (double)W;
+        for (size_t j = 0; j < M; ++j) {
+            size_t k = j + 1;
+            cd a = ws->Fd[k], b = ws->Fd[P - k];
+            double left = hypot(a.re + b.re, a.im - b.im) / 2.0 * scale;
+            double right = hypot(a.re - b.re, a.im + b.im) / 2.0 * scale;
+            if (out) { out[2 * j + 0] = (float)left; out[2 * j + 1] = (float)right; }
+            if (out64) { out64[2 * j + 0] = left; out64[2 * j + 1] = right; }
+        }
+    }
+}
+
+int orc_fft_process(const float *lr, size_t n_avail, size_t W, int precision, float *out, double *out64)
+{
+    /* fft.rs:72: fewer than W samples -> None */
+    if (W < 2 || n_avail < W) return 0;
+    const plan_t *pl = plan_get(2 * W);
+    frame_ws *ws = ws_new(W);
+    process_frame(pl, ws, lr, 2, lr + 1, 2, W, precision, out, out64);
+    ws_free(ws);
+    return 1;
+}
+
+typedef struct {
+    const float *pcm; size_t n; int channels; size_t W, H, first, count; int precision; float *out;
+    size_t begin, end; const plan_t *pl;
+} stream_job;
+
+static void *stream_worker(void *arg)
+{
+    stream_job *jb = (stream_job *)arg;
+    const size_t W = jb->W, H = jb->H, M = W - 1;
+    const int C = jb->channels;
+    const int pairs = C == 1 ? 1 : C / 2;
+    frame_ws *ws = ws_new(W);
+    for (size_t i = jb->begin; i < jb->end; ++i) {
+        size_t t = jb->first + i;
+        const float *base = jb->pcm + (t * H) * (size_t)C;
+        for (int p = 0; p < pairs; ++p) {
+            float *o = jb->out + ((i * (size_t)pairs + (size_t)p) * M) * 2;
+            if (C == 1) /* audio_input_list_model.rs:67-69: mono -> (s, s) */
+                process_frame(jb->pl, ws, base, 1, base, 1, W, jb->precision, o, NULL);
+            else
+                process_frame(jb->pl, ws, base + 2 * p, (size_t)C, base + 2 * p + 1, (size_t)C, W, jb->precision, o, NULL);
+        }
+    }
+    ws_free(ws);
+    return NULL;
+}
+
+size_t orc_stream_process(const float *pcm, size_t n, int channels, size_t W, size_t H, size_t first,
+                          size_t count, int precision, int threads, float *out)
+{
+    if (channels < 1 || (channels > 1 && (channels & 1)) || W < 2 || H < 1) return 0;
+    size_t total = orc_num_frames(n, W, H);
+    if (first >= total) return 0;
+    if (count > total - first) count = total - first;
+    if (threads < 1) threads = 1;
+    if ((size_t)threads > count) threads = (int)(count ? count : 1);
+    const plan_t *pl = plan_get(2 * W);
+    stream_job *jobs = (stream_job *)calloc((size_t)threads, sizeof(stream_job));
+    pthread_t *tids = (pthread_t *)calloc((size_t)threads, sizeof(pthread_t));
+    for (int i = 0; i < threads; ++i) {
+        stream_job *jb = &jobs[i];
+        jb->pcm = pcm; jb->n = n; jb->channels = channels; jb->W = W; jb->H = H; jb->first = first; jb->count = count;
+        jb->precision = precision; jb->out = out; jb->pl = pl;
+        jb->begin = count * (size_t)i / (size_t)threads;
+        jb->end = count * (size_t)(i + 1) / (size_t)threads;
+        if (threads == 1) stream_worker(jb);
+        else pthread_create(&tids[i], NULL, stream_worker, jb);
+    }
+    if (threads > 1) for (int i = 0; i < threads; ++i) pthread_join(tids[i], NULL);
+    free(jobs); free(tids);
+    return count;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* InterpolatedFrequencySample  (interpolated_frequency_sample.rs)                            */
+/* ------------------------------------------------------------------------------------------ */
+
+float orc_period(size_t M, uint32_t sample_rate)
+{
+    /* :52-54  2.0 * self.magnitudes.len() as f32 / self.sample_rate.0 as f32 */
+    volatile float a = 2.0f * (float)M;
+    return a / (float)sample_rate;
+}
+
+float orc_index_of(float frequency, size_t M, uint32_t sample_rate)
+{
+    /* :24-31  (frequency * period).clamp(0.0, (len - 1) as f32) */
+    volatile float idx = frequency * orc_period(M, sample_rate);
+    float hi = (float)(M - 1);
+    float v = idx;
+    if (v < 0.0f) v = 0.0f; /* f32::clamp: NaN stays NaN */
+    if (v > hi) v = hi;
+    return v;
+}
+
+void orc_cubic_interpolate(const float *data, size_t M, float index, float out[2])
+{
+    /* :89-105, Paul Bourke cubic.  x0 = (floor as usize - 1).max(0) underflows in the reference
+     * when floor == 0 (quirk Q4: panic / wrap); restated with saturation. */
+    float fl = floorf(index);
+    volatile float mu = index - fl;
+    size_t x1 = f32_as_usize(fl);
+    size_t x0 = x1 > 0 ? x1 - 1 : 0;
+    size_t x2 = x1 + 1 < M - 1 ? x1 + 1 : M - 1;
+    size_t x3 = x1 + 2 < M - 1 ? x1 + 2 : M - 1;
+    /* num_traits::pow(mu, 2) = mu*mu ; pow(mu, 3) = mu * (mu*mu)  (exponentiation by squaring) */
+    volatile float mu2 = mu * mu;
+    volatile float mu3 = mu * mu2;
+    for (int c = 0; c < 2; ++c) {
+        float y0 = data[2 * x0 + c], y1 = data[2 * x1 + c], y2 = data[2 * x2 + c], y3 = data[2 * x3 + c];
+        volatile float t0 = y3 - y2;
+        volatile float t1 = t0 - y0;
+        volatile float a0 = t1 + y1;          /* y3 - y2 - y0 + y1 */
+        volatile float t2 = y0 - y1;
+        volatile float a1 = t2 - a0;          /* y0 - y1 - a0 */
+        volatile float a2 = y2 - y0;
+        float a3 = y1;
+        volatile float p0 = a0 * mu3;
+        volatile float p1 = a1 * mu2;
+        volatile float p2 = a2 * mu;
+        volatile float s0 = p0 + p1;
+        volatile float s1 = p2 + a3;
+        out[c] = s0 + s1;                     /* (a0*mu^3) + (a1*mu^2) + (a2*mu + a3) */
+    }
+}
+
+void orc_cosine_interpolate(const float *data, size_t M, float index, float out[2])
+{
+    /* :79-86.  clamp(low+1, len-1) panics in the reference when low+1 > len-1; saturated here. */
+    const float pi = 3.14159265358979323846264338327950288f;
+    size_t low = f32_as_usize(floorf(index));
+    size_t high = f32_as_usize(ceilf(index));
+    if (high < low + 1) high = low + 1;
+    if (high > M - 1) high = M - 1;
+    volatile float off = index - (float)low;
+    volatile float ang = off * pi;
+    volatile float c = cosf(ang);
+    volatile float om = 1.0f - c;
+    volatile float o2 = om / 2.0f;
+    volatile float w0 = 1.0f - o2;
+    for (int ch = 0; ch < 2; ++ch) {
+        volatile float a = data[2 * low + ch] * w0;
+        volatile float b = data[2 * high + ch] * o2;
+        out[ch] = a + b;
+    }
+}
+
+size_t orc_num_samples_in(size_t M, uint32_t sample_rate, float f0, float f1)
+{
+    /* :63-64 */
+    float i0 = orc_index_of(f0, M, sample_rate), i1 = orc_index_of(f1, M, sample_rate);
+    volatile float d = i1 - i0;
+    size_t n = f32_as_usize(floorf(d));
+    return n < 1 ? 1 : n;
+}
+
+void orc_magnitude_in(const float *data, size_t M, uint32_t sample_rate, float f0, float f1, int interp,
+                      float out[2])
+{
+    /* :60-75 */
+    size_t n = orc_num_samples_in(M, sample_rate, f0, f1);
+    /* [third-party] iter_num_tools 0.7.1 lin_space over a half-open Range:
+     * step = (end - start) / n ; x_i = start + i * step, i = 0..n-1 (end excluded) */
+    volatile float span = f1 - f0;
+    volatile float step = span / (float)n;
+    float sum[2] = {0.0f, 0.0f}; /* Complex::sum starts from zero */
+    for (size_t i = 0; i < n; ++i) {
+        volatile float off = (float)i * step;
+        volatile float f = f0 + off;
+        float idx = orc_index_of(f, M, sample_rate);
+        float v[2];
+        if (interp == ORC_INTERP_COSINE) orc_cosine_interpolate(data, M, idx, v);
+        else orc_cubic_interpolate(data, M, idx, v);
+        volatile float s0 = sum[0] + v[0], s1 = sum[1] + v[1];
+        sum[0] = s0; sum[1] = s1;
+    }
+    out[0] = sum[0] / (float)n;
+    out[1] = sum[1] / (float)n;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* LogCoordf64  (log_scaling.rs)                                                              */
+/* ------------------------------------------------------------------------------------------ */
+
+double orc_log_unmap(double f_min, double f_max, double zero_point, int p, int pmin, int pmax)
+{
+    /* log_scaling.rs:160-191: linear = ln(start)..ln(end), start/end = range - zero_point
+     * (negative ranges and the zero-start fix-up are not reachable from simple_spectrogram.rs:107).
+     * [third-party] plotters 0.3.5 RangedCoordf64::unmap:
+     *   logical_offset = (p - min) as f64 / (max - min) as f64 ; (hi - lo) * logical_offset + lo
+     * log_scaling.rs:116-118: exp(), then + zero_point. */
+    double lo = log(f_min - zero_point), hi = log(f_max - zero_point);
+    volatile double off = (double)(p - pmin) / (double)(pmax - pmin);
+    volatile double lin = (hi - lo) * off + lo;
+    return exp(lin) + zero_point;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* ColorScheme  (colorscheme.rs)                                                              */
+/* ------------------------------------------------------------------------------------------ */
+
+int orc_lut_index(double t, int n_lut, int lut_mode)
+{
+    /* [third-party] colorous 1.0.12 Gradient::eval_continuous for the 256-entry ramps
+     * (Viridis, Magma, Inferno, Plasma).  The table and this rule are inputs, not constants. */
+    double x;
+    if (lut_mode == ORC_LUT_ROUND_NM1) x = floor(t * (double)(n_lut - 1) + 0.5);
+    else x = floor(t * (double)n_lut);
+    size_t i = f64_as_usize(x); /* NaN, negatives -> 0 */
+    if (i > (size_t)(n_lut - 1)) i = (size_t)(n_lut - 1);
+    return (int)i;
+}
+
+uint8_t orc_alpha_u8(float alpha)
+{
+    /* simple_spectrogram.rs:159: (alpha * 255.0) as u8 -- saturating, NaN -> 0 */
+    volatile float v = alpha * 255.0f;
+    if (!(v > 0.0f)) return 0;
+    if (v >= 255.0f) return 255;
+    return (uint8_t)v;
+}
+
+static float bounded_db(float min_db, float max_db, float l, float r)
+{
+    /* colorscheme.rs:59-61 */
+    volatile float ll = l * l, rr = r * r;
+    volatile float power = ll + rr;              /* norm_sqr */
+    volatile float arg = power + 1e-7f;
+    volatile float db = 10.0f * log10f(arg);
+    volatile float num = db - min_db;
+    volatile float den = max_db - min_db;
+    return num / den;
+}
+
+void orc_color_for(const uint8_t *gradient, int n_lut, int lut_mode, int stereo, float min_db, float max_db,
+                   float l, float r, uint8_t rgb[3], float *alpha)
+{
+    float bounded = bounded_db(min_db, max_db, l, r);
+    int idx;
+    if (stereo) {
+        /* :63-66: t = l as f64 / l1_norm(l, r) as f64 ; alpha = magnitude_bounded */
+        volatile float l1 = fabsf(l) + fabsf(r);
+        double t = (double)l / (double)l1;
+        idx = orc_lut_index(t, n_lut, lut_mode);
+        *alpha = bounded;
+    } else {
+        /* :67-70 */
+        idx = orc_lut_index((double)bounded, n_lut, lut_mode);
+        *alpha = 1.0f;
+    }
+    rgb[0] = gradient[3 * idx + 0]; rgb[1] = gradient[3 * idx + 1]; rgb[2] = gradient[3 * idx + 2];
+}
+
+void orc_render_column(const float *mags, size_t M, uint32_t sample_rate, int R, double f_min, double f_max,
+                       int interp, const uint8_t *gradient, int n_lut, int lut_mode, int stereo, float min_db,
+                       float max_db, uint8_t *rgba)
+{
+    /* simple_spectrogram.rs:141-161 */
+    for (int py = 0; py < R; ++py) {
+        float f0 = (float)orc_log_unmap(f_min, f_max, 0.0, py, 0, R);     /* :142, :145 */
+        float f1 = (float)orc_log_unmap(f_min, f_max, 0.0, py + 1, 0, R); /* :143, :145 */
+        float m[2];
+        orc_magnitude_in(mags, M, sample_rate, f0, f1, interp, m);         /* :147 */
+        uint8_t rgb[3]; float alpha;
+        orc_color_for(gradient, n_lut, lut_mode, stereo, min_db, max_db, m[0], m[1], rgb, &alpha); /* :152 */
+        int y = R - py - 1;                                                 /* :150 */
+        rgba[4 * y + 0] = rgb[0]; rgba[4 * y + 1] = rgb[1]; rgba[4 * y + 2] = rgb[2];
+        rgba[4 * y + 3] = orc_alpha_u8(alpha);                              /* :159 */
+    }
+}
+
+void orc_lookup_table(const uint8_t *gradient, int n_lut, int lut_mode, int stereo, int res, float *table)
+{
+    /* colorscheme.rs:73-92 */
+    for (int i = 0; i < res; ++i)
+        for (int j = 0; j < res; ++j) {
+            volatile float magnitude = (float)i / (float)(res - 1);
+            volatile float jf = (float)j / (float)(res - 1);
+            volatile float pan = 1.0f - jf;
+            float *o = table + 4 * ((size_t)i * (size_t)res + (size_t)j);
+            int idx = orc_lut_index(stereo ? (double)pan : (double)magnitude, n_lut, lut_mode);
+            o[0] = (float)gradient[3 * idx + 0] / 256.0f;
+            o[1] = (float)gradient[3 * idx + 1] / 256.0f;
+            o[2] = (float)gradient[3 * idx + 2] / 256.0f;
+            o[3] = stereo ? magnitude : 1.0f;
+        }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* synthetic inputs -- not reference code                                         */
+/* ------------------------------------------------------------------------------------------ */
+
+uint32_t orc_lowbias32(uint32_t x)
+{
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+
+void orc_white_noise(uint32_t seed, uint64_t first, size_t n, float *out)
+{
+    for (size_t i = 0; i < n; ++i) {
+        uint64_t idx = first + i;
+        /* the high word only matters past 2^32 samples (config 5) */
+        uint32_t s = seed + (uint32_t)(idx >> 32) * 0x9E3779B9U;
+        uint32_t h = orc_lowbias32(s ^ (uint32_t)idx);
+        out[i] = (float)(h >> 8) * 1.1920928955078125e-07f - 1.0f; /* 2^-23 */
+    }
+}
+
+void orc_sine_sweep(size_t first, size_t n, float *out)
+{
+    /* x[n] = 0.5 sin(2 pi (f0 t + (f1-f0) t^2 / (2T))), t = n/48000, f0 = 20, f1 = 20000, T = 1 */
+    const double f0 = 20.0, f1 = 20000.0, T = 1.0, fs = 48000.0;
+    for (size_t i = 0; i < n; ++i) {
+        double t = (double)(first + i) / fs;
+        double ph = 2.0 * M_PI * (f0 * t + (f1 - f0) * t * t / (2.0 * T));
+        out[i] = (float)(0.5 * sin(ph));
+    }
+}

@@ -1,0 +1,432 @@
+// sgx_api.hip -- the C ABI declared in include/sgx.h: context lifetime, table upload, dispatch.
+// Host code only (kernels live in sgx_kernels.hip and stft4096.hip).
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "sgx_gradients.inc"
+#include "sgx_internal.hpp"
+
+namespace {
+
+thread_local std::string g_create_error;
+
+const char *kVersion = "sgx 0.1 (hip gfx950)";
+
+int fail(sgx_ctx *c, int code, const std::string &msg)
+{
+    if (c) c->err = msg;
+    else g_create_error = msg;
+    return code;
+}
+
+int fail_hip(sgx_ctx *c, hipError_t e, const char *what)
+{
+    char buf[512];
+    std::snprintf(buf, sizeof(buf), "%s: %s (%s)", what, hipGetErrorString(e), hipGetErrorName(e));
+    return fail(c, SGX_ERR_HIP, buf);
+}
+
+#define SGX_HIP(ctx, call)                                          \
+    do {                                                            \
+        hipError_t e__ = (call);                                    \
+        if (e__ != hipSuccess) return fail_hip((ctx), e__, #call);  \
+    } while (0)
+
+// Rust `f as usize` for f32: truncate, saturate, NaN -> 0
+uint32_t f32_as_u32(float v)
+{
+    if (!(v > 0.0f)) return 0;
+    if (v >= 4294967296.0f) return 0xffffffffu;
+    return (uint32_t)v;
+}
+
+template <typename T>
+hipError_t upload(T **dst, const T *src, size_t n)
+{
+    if (*dst) { (void)hipFree(*dst); *dst = nullptr; }
+    if (n == 0) return hipSuccess;
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(dst), n * sizeof(T));
+    if (e != hipSuccess) return e;
+    return hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice);
+}
+
+const unsigned char *builtin_gradient(const char *name)
+{
+    if (!name) return nullptr;
+    if (!std::strcmp(name, "viridis")) return SGX_GRADIENT_VIRIDIS;
+    if (!std::strcmp(name, "magma")) return SGX_GRADIENT_MAGMA;
+    if (!std::strcmp(name, "inferno")) return SGX_GRADIENT_INFERNO;
+    if (!std::strcmp(name, "plasma")) return SGX_GRADIENT_PLASMA;
+    return nullptr;
+}
+
+int upload_palette(sgx_ctx *c)
+{
+    sgx::build_palette_thresholds(c->cfg.min_db, c->cfg.max_db, c->cfg.lut_index_mode, c->pal);
+    std::vector<uchar4> rgba(c->pal.n);
+    for (uint32_t i = 0; i < c->pal.n; ++i)
+        rgba[i] = make_uchar4(c->pal.rgb[3 * i], c->pal.rgb[3 * i + 1], c->pal.rgb[3 * i + 2], 255);
+    SGX_HIP(c, hipSetDevice(c->device));
+    // ordering against kernels that may still read the old tables
+    SGX_HIP(c, hipStreamSynchronize(c->stream));
+    SGX_HIP(c, upload(&c->d_lut_rgba, rgba.data(), rgba.size()));
+    SGX_HIP(c, upload(&c->d_lut_thr, c->pal.lut_thr.data(), c->pal.lut_thr.size()));
+    SGX_HIP(c, upload(&c->d_alpha_thr, c->pal.alpha_thr.data(), c->pal.alpha_thr.size()));
+    return SGX_OK;
+}
+
+int ensure_workspace(sgx_ctx *c, size_t frames)
+{
+    if (frames <= c->ws_frames) return SGX_OK;
+    if (c->d_ws_mags) { (void)hipFree(c->d_ws_mags); c->d_ws_mags = nullptr; c->ws_frames = 0; }
+    const size_t bytes = frames * (size_t)c->pairs * c->M * 2 * sizeof(float);
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&c->d_ws_mags), bytes);
+    if (e != hipSuccess) return fail_hip(c, e, "hipMalloc(render workspace)");
+    c->ws_frames = frames;
+    return SGX_OK;
+}
+
+hipError_t run_stft(const sgx_ctx *c, const float *d_pcm, uint32_t channels, uint32_t pairs, size_t first, size_t n,
+                    float *d_mags)
+{
+    if (c->stft_kernel == 1) return sgx::launch_stft_fast4096(c, d_pcm, channels, pairs, first, n, d_mags);
+    return sgx::launch_stft_generic(c, d_pcm, channels, pairs, first, n, d_mags);
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *sgx_version(void) { return kVersion; }
+
+int sgx_config_init(sgx_config *cfg)
+{
+    if (!cfg) return SGX_ERR_INVALID_ARG;
+    std::memset(cfg, 0, sizeof(*cfg));
+    cfg->struct_size = sizeof(sgx_config);
+    cfg->sample_rate = 48000.0f;
+    cfg->period = 0.0f;
+    cfg->stride = 0.0f;
+    cfg->window_samples = 2048;  // fourier/mod.rs:7
+    cfg->hop_samples = 256;      // BASELINE config A
+    cfg->channels = 1;
+    cfg->rows = 1024;            // simple_spectrogram.rs:34-35
+    cfg->f_min = 32.0;           // simple_spectrogram.rs:107
+    cfg->f_max = 22030.0;
+    cfg->min_db = -70.0f;        // colorscheme.rs:16-17
+    cfg->max_db = -10.0f;
+    cfg->interp = SGX_INTERP_CUBIC;
+    cfg->lut_index_mode = SGX_LUT_FLOOR_N;
+    cfg->device = -1;
+    cfg->flags = 0;
+    return SGX_OK;
+}
+
+int sgx_create(const sgx_config *cfg, sgx_ctx **out_ctx)
+{
+    if (out_ctx) *out_ctx = nullptr;
+    if (!cfg || !out_ctx) return fail(nullptr, SGX_ERR_INVALID_ARG, "sgx_create: null argument");
+    if (cfg->struct_size != sizeof(sgx_config))
+        return fail(nullptr, SGX_ERR_INVALID_ARG, "sgx_create: struct_size mismatch (call sgx_config_init first)");
+
+    int n_dev = 0;
+    hipError_t e = hipGetDeviceCount(&n_dev);
+    if (e != hipSuccess || n_dev <= 0)
+        return fail(nullptr, SGX_ERR_NO_DEVICE,
+                    std::string("sgx_create: no HIP device (this library has no CPU fallback): ") +
+                        (e != hipSuccess ? hipGetErrorString(e) : "device count is 0"));
+
+    sgx_ctx *c = new (std::nothrow) sgx_ctx();
+    if (!c) return fail(nullptr, SGX_ERR_NOMEM, "sgx_create: out of host memory");
+    c->cfg = *cfg;
+
+    // fft.rs:19 / audio_transform.rs:35: f32 product, truncating cast
+    c->W = cfg->window_samples ? cfg->window_samples : f32_as_u32(cfg->period * cfg->sample_rate);
+    c->H = cfg->hop_samples ? cfg->hop_samples : f32_as_u32(cfg->stride * cfg->sample_rate);
+    c->P = 2 * c->W;
+    c->M = c->W - 1;
+    c->C = cfg->channels;
+    c->pairs = c->C <= 2 ? 1 : c->C / 2;
+    c->R = cfg->rows;
+    c->sr_u32 = f32_as_u32(cfg->sample_rate);  // SampleRate(sample_rate as u32), simple_spectrogram.rs:138
+
+    auto bail = [&](int code, const std::string &msg) {
+        sgx_destroy(c);
+        return fail(nullptr, code, msg);
+    };
+    if (c->W < 4) return bail(SGX_ERR_INVALID_ARG, "sgx_create: window must be at least 4 samples");
+    if (c->H < 1) return bail(SGX_ERR_INVALID_ARG, "sgx_create: hop must be at least 1 sample");
+    if (c->C < 1 || (c->C > 2 && (c->C & 1))) return bail(SGX_ERR_INVALID_ARG, "sgx_create: channels must be 1, 2 or an even number");
+    if (c->R < 1 || c->R > 65536) return bail(SGX_ERR_INVALID_ARG, "sgx_create: rows out of range");
+    if (!(cfg->f_min > 0.0) || !(cfg->f_max > cfg->f_min)) return bail(SGX_ERR_INVALID_ARG, "sgx_create: need 0 < f_min < f_max");
+    if (!(cfg->max_db > cfg->min_db)) return bail(SGX_ERR_INVALID_ARG, "sgx_create: need min_db < max_db");
+    if (cfg->interp > SGX_INTERP_COSINE) return bail(SGX_ERR_INVALID_ARG, "sgx_create: unknown interpolation");
+    if (cfg->lut_index_mode > SGX_LUT_ROUND_NM1) return bail(SGX_ERR_INVALID_ARG, "sgx_create: unknown lut_index_mode");
+    if (c->sr_u32 == 0) return bail(SGX_ERR_INVALID_ARG, "sgx_create: sample_rate must be at least 1 Hz");
+    if ((c->P & (c->P - 1)) != 0 || c->P > 16384)
+        return bail(SGX_ERR_UNSUPPORTED,
+                    "sgx_create: transform length 2W = " + std::to_string(c->P) +
+                        " is not supported by this build (power of two, at most 16384)");
+    c->logP = 0;
+    while ((1u << c->logP) < c->P) ++c->logP;
+
+    c->device = cfg->device;
+    if (c->device < 0) {
+        e = hipGetDevice(&c->device);
+        if (e != hipSuccess) return bail(SGX_ERR_HIP, std::string("hipGetDevice: ") + hipGetErrorString(e));
+    }
+    if (c->device >= n_dev) return bail(SGX_ERR_INVALID_ARG, "sgx_create: device ordinal out of range");
+    e = hipSetDevice(c->device);
+    if (e != hipSuccess) return bail(SGX_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+
+    sgx::build_tables(c->W, c->R, c->sr_u32, cfg->f_min, cfg->f_max, cfg->interp, c->tab);
+    if ((e = upload(&c->d_window, c->tab.window.data(), c->tab.window.size())) != hipSuccess ||
+        (e = upload(&c->d_twiddle, c->tab.twiddle.data(), c->tab.twiddle.size())) != hipSuccess ||
+        (e = upload(&c->d_rows, c->tab.rows.data(), c->tab.rows.size())) != hipSuccess ||
+        (e = upload(&c->d_samples, c->tab.samples.data(), c->tab.samples.size())) != hipSuccess ||
+        (e = hipMalloc(reinterpret_cast<void **>(&c->d_one_in), (size_t)c->W * 2 * sizeof(float))) != hipSuccess ||
+        (e = hipMalloc(reinterpret_cast<void **>(&c->d_one_out), (size_t)c->M * 2 * sizeof(float))) != hipSuccess ||
+        (e = hipMalloc(reinterpret_cast<void **>(&c->d_cksum), sizeof(unsigned long long))) != hipSuccess)
+        return bail(SGX_ERR_HIP, std::string("sgx_create: table upload: ") + hipGetErrorString(e));
+
+    // default palette: ColorScheme::new_mono(colorous::MAGMA, "magma"), simple_spectrogram.rs:95
+    c->pal.rgb.assign(SGX_GRADIENT_MAGMA, SGX_GRADIENT_MAGMA + 256 * 3);
+    c->pal.n = 256;
+    c->pal.stereo = 0;
+    int rc = upload_palette(c);
+    if (rc != SGX_OK) { std::string m = c->err; return bail(rc, m); }
+
+    c->stft_kernel = 0;
+    if (!(cfg->flags & SGX_FLAG_FORCE_GENERIC) && sgx::fast4096_supported(c)) {
+        e = sgx::fast4096_init(c);
+        if (e != hipSuccess) return bail(SGX_ERR_HIP, std::string("sgx_create: tuned kernel tables: ") + hipGetErrorString(e));
+        c->stft_kernel = 1;
+    }
+    *out_ctx = c;
+    return SGX_OK;
+}
+
+void sgx_destroy(sgx_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    sgx::fast4096_destroy(c);
+    void *ptrs[] = {c->d_window, c->d_twiddle, c->d_rows, c->d_samples, c->d_lut_thr, c->d_alpha_thr,
+                    c->d_lut_rgba, c->d_ws_mags, c->d_one_in, c->d_one_out, c->d_cksum};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    delete c;
+}
+
+const char *sgx_last_error(const sgx_ctx *c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+int sgx_query(const sgx_ctx *c, sgx_info *out)
+{
+    if (!c || !out) return SGX_ERR_INVALID_ARG;
+    std::memset(out, 0, sizeof(*out));
+    out->struct_size = sizeof(sgx_info);
+    out->window_samples = c->W;
+    out->fft_length = c->P;
+    out->num_frequencies = c->M;
+    out->hop_samples = c->H;
+    out->channels = c->C;
+    out->pairs = c->pairs;
+    out->rows = c->R;
+    out->sample_rate_u32 = c->sr_u32;
+    out->total_samples_per_column = (uint32_t)c->tab.samples.size();
+    out->stft_kernel = (uint32_t)c->stft_kernel;
+    out->mags_bytes_per_frame = (uint64_t)c->pairs * c->M * 2 * sizeof(float);
+    out->rgba_bytes_per_frame = (uint64_t)c->pairs * c->R * 4;
+    return SGX_OK;
+}
+
+size_t sgx_num_frames(const sgx_ctx *c, size_t n_samples)
+{
+    if (!c || n_samples < c->W) return 0;
+    return (n_samples - c->W) / c->H + 1;
+}
+
+int sgx_set_stream(sgx_ctx *c, void *stream)
+{
+    if (!c) return SGX_ERR_INVALID_ARG;
+    c->stream = reinterpret_cast<hipStream_t>(stream);
+    return SGX_OK;
+}
+
+int sgx_sync(sgx_ctx *c)
+{
+    if (!c) return SGX_ERR_INVALID_ARG;
+    SGX_HIP(c, hipSetDevice(c->device));
+    SGX_HIP(c, hipStreamSynchronize(c->stream));
+    return SGX_OK;
+}
+
+int sgx_stft_batch(sgx_ctx *c, const float *d_pcm, size_t n_samples, size_t first_frame, size_t max_frames,
+                   float *d_mags, size_t *n_out)
+{
+    if (n_out) *n_out = 0;
+    if (!c) return SGX_ERR_INVALID_ARG;
+    const size_t total = sgx_num_frames(c, n_samples);
+    if (first_frame >= total || max_frames == 0) return SGX_OK;  // None: not an error (fft.rs:72)
+    size_t n = total - first_frame;
+    if (n > max_frames) n = max_frames;
+    if (!d_pcm || !d_mags) return fail(c, SGX_ERR_INVALID_ARG, "sgx_stft_batch: null buffer");
+    SGX_HIP(c, hipSetDevice(c->device));
+    hipError_t e = run_stft(c, d_pcm, c->C, c->pairs, first_frame, n, d_mags);
+    if (e != hipSuccess) return fail_hip(c, e, "sgx_stft_batch: kernel launch");
+    if (n_out) *n_out = n;
+    return SGX_OK;
+}
+
+int sgx_process_one(sgx_ctx *c, const float *h_lr, size_t n_avail, float *h_out)
+{
+    if (!c) return SGX_ERR_INVALID_ARG;
+    if (n_avail < c->W) return 0;  // None (fft.rs:72)
+    if (!h_lr || !h_out) return fail(c, SGX_ERR_INVALID_ARG, "sgx_process_one: null buffer");
+    SGX_HIP(c, hipSetDevice(c->device));
+    SGX_HIP(c, hipMemcpyAsync(c->d_one_in, h_lr, (size_t)c->W * 2 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    hipError_t e = run_stft(c, c->d_one_in, 2, 1, 0, 1, c->d_one_out);
+    if (e != hipSuccess) return fail_hip(c, e, "sgx_process_one: kernel launch");
+    SGX_HIP(c, hipMemcpyAsync(h_out, c->d_one_out, (size_t)c->M * 2 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    SGX_HIP(c, hipStreamSynchronize(c->stream));
+    return 1;
+}
+
+int sgx_render_mags(sgx_ctx *c, const float *d_mags, size_t n_columns, uint8_t *d_rgba)
+{
+    if (!c) return SGX_ERR_INVALID_ARG;
+    if (n_columns == 0) return SGX_OK;
+    if (!d_mags || !d_rgba) return fail(c, SGX_ERR_INVALID_ARG, "sgx_render_mags: null buffer");
+    SGX_HIP(c, hipSetDevice(c->device));
+    hipError_t e = sgx::launch_render(c, d_mags, n_columns, d_rgba);
+    if (e != hipSuccess) return fail_hip(c, e, "sgx_render_mags: kernel launch");
+    return SGX_OK;
+}
+
+int sgx_render_batch(sgx_ctx *c, const float *d_pcm, size_t n_samples, size_t first_frame, size_t max_frames,
+                     uint8_t *d_rgba, size_t *n_out)
+{
+    if (n_out) *n_out = 0;
+    if (!c) return SGX_ERR_INVALID_ARG;
+    const size_t total = sgx_num_frames(c, n_samples);
+    if (first_frame >= total || max_frames == 0) return SGX_OK;
+    size_t n = total - first_frame;
+    if (n > max_frames) n = max_frames;
+    if (!d_pcm || !d_rgba) return fail(c, SGX_ERR_INVALID_ARG, "sgx_render_batch: null buffer");
+    SGX_HIP(c, hipSetDevice(c->device));
+    // magnitudes stay in a bounded, reused workspace (L2 / Infinity-Cache sized chunks)
+    const size_t bytes_per_frame = (size_t)c->pairs * c->M * 2 * sizeof(float);
+    size_t chunk = (size_t)(192u << 20) / bytes_per_frame;
+    if (chunk < 1) chunk = 1;
+    if (chunk > n) chunk = n;
+    int rc = ensure_workspace(c, chunk);
+    if (rc != SGX_OK) return rc;
+    for (size_t done = 0; done < n; done += chunk) {
+        const size_t m = n - done < chunk ? n - done : chunk;
+        hipError_t e = run_stft(c, d_pcm, c->C, c->pairs, first_frame + done, m, c->d_ws_mags);
+        if (e != hipSuccess) return fail_hip(c, e, "sgx_render_batch: stft launch");
+        e = sgx::launch_render(c, c->d_ws_mags, m * c->pairs, d_rgba + done * (size_t)c->pairs * c->R * 4);
+        if (e != hipSuccess) return fail_hip(c, e, "sgx_render_batch: render launch");
+    }
+    if (n_out) *n_out = n;
+    return SGX_OK;
+}
+
+int sgx_set_gradient(sgx_ctx *c, const uint8_t *h_rgb, uint32_t n, int stereo)
+{
+    if (!c) return SGX_ERR_INVALID_ARG;
+    if (!h_rgb || n < 2 || n > 65536) return fail(c, SGX_ERR_INVALID_ARG, "sgx_set_gradient: need 2..65536 entries");
+    c->pal.rgb.assign(h_rgb, h_rgb + (size_t)n * 3);
+    c->pal.n = n;
+    c->pal.stereo = stereo ? 1 : 0;
+    return upload_palette(c);
+}
+
+int sgx_builtin_gradient(const char *name, uint8_t *h_rgb_out)
+{
+    const unsigned char *g = builtin_gradient(name);
+    if (!g || !h_rgb_out) return SGX_ERR_INVALID_ARG;
+    std::memcpy(h_rgb_out, g, 256 * 3);
+    return SGX_OK;
+}
+
+int sgx_set_builtin_gradient(sgx_ctx *c, const char *name)
+{
+    if (!c) return SGX_ERR_INVALID_ARG;
+    const unsigned char *g = builtin_gradient(name);
+    if (!g) return fail(c, SGX_ERR_INVALID_ARG, std::string("sgx_set_builtin_gradient: unknown gradient '") + (name ? name : "(null)") + "'");
+    return sgx_set_gradient(c, g, 256, 0);
+}
+
+int sgx_lookup_table(sgx_ctx *c, uint32_t res, float *h_out)
+{
+    if (!c) return SGX_ERR_INVALID_ARG;
+    if (!h_out || res < 2) return fail(c, SGX_ERR_INVALID_ARG, "sgx_lookup_table: resolution must be at least 2");
+    // colorscheme.rs:73-92
+    for (uint32_t i = 0; i < res; ++i)
+        for (uint32_t j = 0; j < res; ++j) {
+            const float magnitude = (float)i / (float)(res - 1);
+            const float pan = 1.0f - ((float)j / (float)(res - 1));
+            const int idx = sgx::lut_index_host(c->pal.stereo ? (double)pan : (double)magnitude, c->pal.n, c->cfg.lut_index_mode);
+            float *o = h_out + 4 * ((size_t)i * res + j);
+            o[0] = (float)c->pal.rgb[3 * idx + 0] / 256.0f;
+            o[1] = (float)c->pal.rgb[3 * idx + 1] / 256.0f;
+            o[2] = (float)c->pal.rgb[3 * idx + 2] / 256.0f;
+            o[3] = c->pal.stereo ? magnitude : 1.0f;
+        }
+    return SGX_OK;
+}
+
+int sgx_bin_edges(const sgx_ctx *c, float *h_out)
+{
+    if (!c || !h_out) return SGX_ERR_INVALID_ARG;
+    std::memcpy(h_out, c->tab.edges.data(), c->tab.edges.size() * sizeof(float));
+    return SGX_OK;
+}
+
+int sgx_row_sample_counts(const sgx_ctx *c, uint32_t *h_out)
+{
+    if (!c || !h_out) return SGX_ERR_INVALID_ARG;
+    for (uint32_t i = 0; i < c->R; ++i) h_out[i] = c->tab.rows[i].count;
+    return SGX_OK;
+}
+
+int sgx_window(const sgx_ctx *c, float *h_out)
+{
+    if (!c || !h_out) return SGX_ERR_INVALID_ARG;
+    std::memcpy(h_out, c->tab.window.data(), c->tab.window.size() * sizeof(float));
+    return SGX_OK;
+}
+
+int sgx_synth_white_noise(sgx_ctx *c, float *d_out, uint64_t first, size_t n_samples, uint32_t channels, uint32_t seed)
+{
+    if (!c) return SGX_ERR_INVALID_ARG;
+    if (n_samples == 0) return SGX_OK;
+    if (!d_out || channels < 1) return fail(c, SGX_ERR_INVALID_ARG, "sgx_synth_white_noise: bad argument");
+    SGX_HIP(c, hipSetDevice(c->device));
+    hipError_t e = sgx::launch_white_noise(c, d_out, first, n_samples, channels, seed);
+    if (e != hipSuccess) return fail_hip(c, e, "sgx_synth_white_noise: kernel launch");
+    return SGX_OK;
+}
+
+int sgx_checksum(sgx_ctx *c, const void *d_buf, size_t n_bytes, uint64_t base_word, uint64_t *h_out)
+{
+    if (!c || !h_out) return SGX_ERR_INVALID_ARG;
+    if (n_bytes % 4) return fail(c, SGX_ERR_INVALID_ARG, "sgx_checksum: size must be a multiple of 4");
+    SGX_HIP(c, hipSetDevice(c->device));
+    SGX_HIP(c, hipMemsetAsync(c->d_cksum, 0, sizeof(unsigned long long), c->stream));
+    if (n_bytes) {
+        if (!d_buf) return fail(c, SGX_ERR_INVALID_ARG, "sgx_checksum: null buffer");
+        hipError_t e = sgx::launch_checksum(c, static_cast<const uint32_t *>(d_buf), n_bytes / 4, base_word, c->d_cksum);
+        if (e != hipSuccess) return fail_hip(c, e, "sgx_checksum: kernel launch");
+    }
+    unsigned long long v = 0;
+    SGX_HIP(c, hipMemcpyAsync(&v, c->d_cksum, sizeof(v), hipMemcpyDeviceToHost, c->stream));
+    SGX_HIP(c, hipStreamSynchronize(c->stream));
+    *h_out = v;
+    return SGX_OK;
+}
+
+}  // extern "C"

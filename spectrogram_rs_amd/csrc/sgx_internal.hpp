@@ -1,0 +1,104 @@
+// sgx_internal.hpp -- context layout and kernel launchers shared by the C-ABI translation units.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/sgx.h"
+
+namespace sgx {
+
+// One row of the pixel column (py = 0 is the LOWEST frequency; it is written at image row R-1-py).
+struct RowEntry {
+    uint32_t first;  // index of the row's first entry in the sample table
+    uint32_t count;  // n = max(1, floor(i1 - i0))           interpolated_frequency_sample.rs:63-64
+    float count_f;   // n as f32, the divisor of the mean     :72
+    uint32_t pad;
+};
+
+// One sample of magnitude_in's lin_space.  Everything that depends only on the configuration is
+// evaluated once on the host with the reference's f32 operation order; the kernel is left with
+// gathers and exactly-rounded adds / multiplies.
+//   cubic  (:89-105): i0 = x1 (floor(index)), w = {mu, mu^2, mu^3}
+//   cosine (:79-86) : i0 = low, i1 = high,    w = {1 - o', o'}
+struct SampleEntry {
+    int32_t i0;
+    union { int32_t i1; float w0; };
+    float w1;
+    float w2;
+};
+static_assert(sizeof(SampleEntry) == 16, "SampleEntry must be 16 bytes");
+
+struct Tables {
+    std::vector<float> window;      // [W]      fft.rs:61
+    std::vector<float2> twiddle;    // [P/2]    e^{-2 pi i j / P}
+    std::vector<float> edges;       // [R+1]    log_scaling.rs:114-119
+    std::vector<RowEntry> rows;     // [R]
+    std::vector<SampleEntry> samples;
+};
+
+struct Palette {
+    std::vector<uint8_t> rgb;       // [n][3]
+    uint32_t n = 0;
+    int stereo = 0;
+    std::vector<float> lut_thr;     // [n-1]   smallest power whose LUT index is >= i+1 (mono)
+    std::vector<float> alpha_thr;   // [255]   smallest power whose alpha byte is >= i+1 (stereo)
+};
+
+void build_tables(uint32_t W, uint32_t R, uint32_t sample_rate_u32, double f_min, double f_max, uint32_t interp,
+                  Tables &out);
+void build_palette_thresholds(float min_db, float max_db, uint32_t lut_mode, Palette &pal);
+int lut_index_host(double t, uint32_t n, uint32_t mode);
+uint8_t alpha_u8_host(float alpha);
+float bounded_db_host(float min_db, float max_db, float power);
+
+}  // namespace sgx
+
+struct sgx_ctx {
+    sgx_config cfg{};
+    uint32_t W = 0, P = 0, M = 0, H = 0, C = 0, pairs = 0, R = 0, sr_u32 = 0, logP = 0;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int stft_kernel = 0;  // 0 generic, 1 tuned 4096
+
+    sgx::Tables tab;
+    sgx::Palette pal;
+
+    // device tables
+    float *d_window = nullptr;
+    float2 *d_twiddle = nullptr;
+    sgx::RowEntry *d_rows = nullptr;
+    sgx::SampleEntry *d_samples = nullptr;
+    float *d_lut_thr = nullptr;    // [n-1]
+    float *d_alpha_thr = nullptr;  // [255]
+    uchar4 *d_lut_rgba = nullptr;  // [n]
+    void *d_fast = nullptr;        // tables of the tuned kernel (opaque here)
+
+    // workspaces (grown on demand, kept)
+    float *d_ws_mags = nullptr;
+    size_t ws_frames = 0;
+    float *d_one_in = nullptr, *d_one_out = nullptr;
+    unsigned long long *d_cksum = nullptr;
+
+    std::string err;
+};
+
+namespace sgx {
+
+// kernel launchers (each returns hipSuccess or the launch error)
+hipError_t launch_stft_generic(const sgx_ctx *c, const float *d_pcm, uint32_t channels, uint32_t pairs, size_t first_frame,
+                               size_t n_frames, float *d_mags);
+bool fast4096_supported(const sgx_ctx *c);
+hipError_t fast4096_init(sgx_ctx *c);
+void fast4096_destroy(sgx_ctx *c);
+hipError_t launch_stft_fast4096(const sgx_ctx *c, const float *d_pcm, uint32_t channels, uint32_t pairs, size_t first_frame,
+                                size_t n_frames, float *d_mags);
+hipError_t launch_render(const sgx_ctx *c, const float *d_mags, size_t n_columns, uint8_t *d_rgba);
+hipError_t launch_white_noise(const sgx_ctx *c, float *d_out, uint64_t first, size_t n, uint32_t channels, uint32_t seed);
+hipError_t launch_checksum(const sgx_ctx *c, const uint32_t *d_words, size_t n_words, uint64_t base_word,
+                           unsigned long long *d_acc);
+
+}  // namespace sgx

@@ -1,0 +1,336 @@
+// sgx_kernels.hip -- gfx950 kernels that are not the tuned 4096-point STFT:
+//   * stft_generic_kernel : any power-of-two transform length up to 16384 (one workgroup per
+//                           frame and channel pair, the whole padded frame resident in LDS)
+//   * render_kernel       : magnitude_in + color_for + put_pixel for one pixel column
+//   * white-noise generator and checksum (harness helpers)
+//
+// Compiled with -ffp-contract=off: the pixel path must round every f32 operation exactly once
+// so that its bytes equal the CPU restatement's; FFT code asks for FMAs explicitly.
+#include "sgx_internal.hpp"
+
+namespace sgx {
+
+// ------------------------------------------------------------------------------------------------
+// generic power-of-two STFT
+// ------------------------------------------------------------------------------------------------
+
+struct StftGenericParams {
+    const float *pcm;      // [n][C]
+    const float *window;   // [W]
+    const float2 *twiddle; // [P/2]
+    float *mags;           // [F][pairs][M][2]
+    unsigned long long first_frame;
+    uint32_t W, logP, H, C, pairs;
+    float half_scale;      // applied as (hypot * 0.5f) * scale
+    float scale;
+};
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b)
+{
+    // (a.x + i a.y)(b.x + i b.y) with two FMAs
+    return make_float2(fmaf(a.x, b.x, -(a.y * b.y)), fmaf(a.x, b.y, a.y * b.x));
+}
+
+// Replaces FastFourierTransform::process (fft.rs:43-99) for one (frame, pair).
+// Data flow: PCM -> (l + i r) * hann -> LDS; the zero padding is never materialised: with
+// z[n] = 0 for n >= W the first decimation-in-frequency stage degenerates to
+//   s[n] = z[n], s[n + W] = z[n] * w_P^n,
+// after which log2(P) - 1 in-place radix-2 DIF stages leave F in bit-reversed order.
+__global__ void __launch_bounds__(256) stft_generic_kernel(StftGenericParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2 *s = reinterpret_cast<float2 *>(smem_raw);
+    const uint32_t W = p.W, P = 2 * W, M = W - 1;
+    const uint32_t tid = threadIdx.x, nt = blockDim.x;
+    const unsigned long long frame_local = blockIdx.x;
+    const uint32_t pair = blockIdx.y;
+    const unsigned long long t = p.first_frame + frame_local;
+    const uint32_t cl = p.C == 1 ? 0 : 2 * pair, cr = p.C == 1 ? 0 : 2 * pair + 1;
+    const float *src = p.pcm + (size_t)(t * p.H) * p.C;
+
+    for (uint32_t n = tid; n < W; n += nt) {
+        const float w = p.window[n];
+        const float l = src[(size_t)n * p.C + cl];
+        const float r = src[(size_t)n * p.C + cr];
+        const float2 z = make_float2(l * w, r * w);  // complex * real, fft.rs:59-63
+        s[n] = z;
+        s[n + W] = cmul(z, p.twiddle[n]);
+    }
+    __syncthreads();
+
+    for (uint32_t h = W >> 1, lh = p.logP - 2; h >= 1; h >>= 1, --lh) {
+        const uint32_t tw_stride = W / h;  // w_{2h}^j = w_P^{j * P / (2h)}
+        for (uint32_t b = tid; b < W; b += nt) {
+            const uint32_t grp = b >> lh, j = b & (h - 1);
+            const uint32_t i0 = (grp << (lh + 1)) + j, i1 = i0 + h;
+            const float2 u = s[i0], v = s[i1];
+            s[i0] = make_float2(u.x + v.x, u.y + v.y);
+            const float2 d = make_float2(u.x - v.x, u.y - v.y);
+            s[i1] = (j == 0) ? d : cmul(d, p.twiddle[j * tw_stride]);
+        }
+        __syncthreads();
+        if (h == 1) break;
+    }
+
+    // fft.rs:81-98: a = F[k], b = F[P - k]; left = |a + conj b| / 2, right = |a - conj b| / 2; * 2/W
+    float *out = p.mags + ((size_t)(frame_local * p.pairs + pair) * M) * 2;
+    const uint32_t sh = 32 - p.logP;
+    for (uint32_t j = tid; j < M; j += nt) {
+        const uint32_t k = j + 1;
+        const float2 a = s[__brev(k) >> sh];
+        const float2 b = s[__brev(P - k) >> sh];
+        const float sre = a.x + b.x, sim = a.y - b.y;
+        const float dre = a.x - b.x, dim = a.y + b.y;
+        const float left = sqrtf(fmaf(sre, sre, sim * sim)) * 0.5f * p.scale;
+        const float right = sqrtf(fmaf(dre, dre, dim * dim)) * 0.5f * p.scale;
+        reinterpret_cast<float2 *>(out)[j] = make_float2(left, right);
+    }
+}
+
+hipError_t launch_stft_generic(const sgx_ctx *c, const float *d_pcm, uint32_t channels, uint32_t pairs, size_t first_frame,
+                               size_t n_frames, float *d_mags)
+{
+    if (n_frames == 0) return hipSuccess;
+    StftGenericParams p;
+    p.pcm = d_pcm;
+    p.window = c->d_window;
+    p.twiddle = c->d_twiddle;
+    p.mags = d_mags;
+    p.first_frame = first_frame;
+    p.W = c->W;
+    p.logP = c->logP;
+    p.H = c->H;
+    p.C = channels;
+    p.pairs = pairs;
+    p.half_scale = 0.5f;
+    p.scale = 2.0f / (float)c->W;
+    const size_t lds = (size_t)c->P * sizeof(float2);
+    static thread_local size_t attr_set_for = 0;
+    if (lds > 64 * 1024 && attr_set_for < lds) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(stft_generic_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set_for = lds;
+    }
+    // gridDim.x is limited to 2^31-1; frames are chunked far below that by the caller
+    const size_t max_chunk = 1u << 30;
+    size_t done = 0;
+    while (done < n_frames) {
+        size_t chunk = n_frames - done < max_chunk ? n_frames - done : max_chunk;
+        StftGenericParams q = p;
+        q.first_frame = first_frame + done;
+        q.mags = d_mags + done * (size_t)pairs * c->M * 2;
+        hipLaunchKernelGGL(stft_generic_kernel, dim3((unsigned)chunk, pairs), dim3(256), lds, c->stream, q);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        done += chunk;
+    }
+    return hipSuccess;
+}
+
+// ------------------------------------------------------------------------------------------------
+// pixel column: magnitude_in -> color_for -> put_pixel
+// ------------------------------------------------------------------------------------------------
+
+struct RenderParams {
+    const float *mags;          // [n_columns][M][2]
+    const RowEntry *rows;       // [R]
+    const SampleEntry *samples;
+    const float *lut_thr;       // [n_lut - 1]
+    const float *alpha_thr;     // [255]
+    const uchar4 *lut_rgba;     // [n_lut]
+    uint8_t *rgba;              // [n_columns][R][4]
+    uint32_t M, R, n_lut, interp, stereo, lut_mode;
+};
+
+// number of thresholds <= v in a sorted table (NaN thresholds sort last and never match)
+__device__ __forceinline__ uint32_t count_reached(const float *thr, uint32_t n, float v)
+{
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (v >= thr[mid]) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
+}
+
+// Replaces the body of `for py in 0..buffer.height()` (simple_spectrogram.rs:141-161).
+__global__ void __launch_bounds__(256) render_kernel(RenderParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2 *m = reinterpret_cast<float2 *>(smem_raw);                 // [M]
+    float *thr = reinterpret_cast<float *>(m + p.M + 1);              // [n_lut - 1]
+    float *athr = thr + p.n_lut;                                      // [255]
+    const uint32_t tid = threadIdx.x, nt = blockDim.x;
+    const size_t col = blockIdx.x;
+    const float2 *src = reinterpret_cast<const float2 *>(p.mags) + col * p.M;
+    for (uint32_t i = tid; i < p.M; i += nt) m[i] = src[i];
+    for (uint32_t i = tid; i + 1 < p.n_lut; i += nt) thr[i] = p.lut_thr[i];
+    for (uint32_t i = tid; i < 255; i += nt) athr[i] = p.alpha_thr[i];
+    __syncthreads();
+
+    const int32_t last = (int32_t)p.M - 1;
+    uchar4 *dst = reinterpret_cast<uchar4 *>(p.rgba) + col * p.R;
+    for (uint32_t py = tid; py < p.R; py += nt) {
+        const RowEntry row = p.rows[py];
+        float sl = 0.0f, sr = 0.0f;  // Complex::sum starts at zero (interpolated_frequency_sample.rs:70-72)
+        for (uint32_t i = 0; i < row.count; ++i) {
+            const SampleEntry se = p.samples[row.first + i];
+            float vl, vr;
+            if (p.interp == SGX_INTERP_COSINE) {
+                // :79-86  data[low] * (1 - o') + data[high] * o'
+                const float2 a = m[se.i0], b = m[se.i1];
+                vl = a.x * se.w1 + b.x * se.w2;
+                vr = a.y * se.w1 + b.y * se.w2;
+            } else {
+                // :89-105
+                const int32_t x1 = se.i0;
+                const int32_t x0 = x1 > 0 ? x1 - 1 : 0;
+                const int32_t x2 = x1 + 1 < last ? x1 + 1 : last;
+                const int32_t x3 = x1 + 2 < last ? x1 + 2 : last;
+                const float2 y0 = m[x0], y1 = m[x1], y2 = m[x2], y3 = m[x3];
+                const float mu = se.w0, mu2 = se.w1, mu3 = se.w2;
+                {
+                    const float a0 = ((y3.x - y2.x) - y0.x) + y1.x;
+                    const float a1 = (y0.x - y1.x) - a0;
+                    const float a2 = y2.x - y0.x;
+                    vl = ((a0 * mu3) + (a1 * mu2)) + ((a2 * mu) + y1.x);
+                }
+                {
+                    const float a0 = ((y3.y - y2.y) - y0.y) + y1.y;
+                    const float a1 = (y0.y - y1.y) - a0;
+                    const float a2 = y2.y - y0.y;
+                    vr = ((a0 * mu3) + (a1 * mu2)) + ((a2 * mu) + y1.y);
+                }
+            }
+            sl = sl + vl;
+            sr = sr + vr;
+        }
+        const float l = sl / row.count_f, r = sr / row.count_f;  // :72
+
+        // colorscheme.rs:59: norm_sqr = l*l + r*r, then the dB ramp as a threshold count
+        const float power = (l * l) + (r * r);
+        uchar4 px;
+        if (p.stereo) {
+            // :63-66
+            const float l1 = fabsf(l) + fabsf(r);
+            const double t = (double)l / (double)l1;
+            double x = (p.lut_mode == SGX_LUT_ROUND_NM1) ? floor(t * (double)(p.n_lut - 1) + 0.5) : floor(t * (double)p.n_lut);
+            uint32_t idx = 0;
+            if (x > 0.0) idx = x >= (double)p.n_lut ? p.n_lut - 1 : (uint32_t)x;
+            px = p.lut_rgba[idx];
+            px.w = (unsigned char)count_reached(athr, 255, power);  // (alpha * 255.0) as u8, simple_spectrogram.rs:159
+        } else {
+            // :67-70; alpha = 1.0 -> 255
+            px = p.lut_rgba[count_reached(thr, p.n_lut - 1, power)];
+            px.w = 255;
+        }
+        dst[p.R - 1 - py] = px;  // simple_spectrogram.rs:150
+    }
+}
+
+hipError_t launch_render(const sgx_ctx *c, const float *d_mags, size_t n_columns, uint8_t *d_rgba)
+{
+    if (n_columns == 0) return hipSuccess;
+    RenderParams p;
+    p.mags = d_mags;
+    p.rows = c->d_rows;
+    p.samples = c->d_samples;
+    p.lut_thr = c->d_lut_thr;
+    p.alpha_thr = c->d_alpha_thr;
+    p.lut_rgba = c->d_lut_rgba;
+    p.rgba = d_rgba;
+    p.M = c->M;
+    p.R = c->R;
+    p.n_lut = c->pal.n;
+    p.interp = c->cfg.interp;
+    p.stereo = (uint32_t)c->pal.stereo;
+    p.lut_mode = c->cfg.lut_index_mode;
+    const size_t lds = (size_t)(c->M + 1) * sizeof(float2) + (size_t)(c->pal.n + 255) * sizeof(float);
+    static thread_local size_t attr_set_for = 0;
+    if (lds > 64 * 1024 && attr_set_for < lds) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(render_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set_for = lds;
+    }
+    const size_t max_chunk = 1u << 30;
+    size_t done = 0;
+    while (done < n_columns) {
+        size_t chunk = n_columns - done < max_chunk ? n_columns - done : max_chunk;
+        RenderParams q = p;
+        q.mags = d_mags + done * (size_t)c->M * 2;
+        q.rgba = d_rgba + done * (size_t)c->R * 4;
+        hipLaunchKernelGGL(render_kernel, dim3((unsigned)chunk), dim3(256), lds, c->stream, q);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        done += chunk;
+    }
+    return hipSuccess;
+}
+
+// ------------------------------------------------------------------------------------------------
+// harness helpers
+// ------------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ uint32_t lowbias32(uint32_t x)
+{
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+
+__global__ void white_noise_kernel(float *out, unsigned long long first, size_t n, uint32_t channels, uint32_t seed)
+{
+    const size_t total = n * channels;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t i = e / channels;
+        const uint32_t ch = (uint32_t)(e - i * channels);
+        const unsigned long long idx = first + i;
+        const uint32_t s = (seed + ch) + (uint32_t)(idx >> 32) * 0x9E3779B9U;
+        const uint32_t h = lowbias32(s ^ (uint32_t)idx);
+        out[e] = (float)(h >> 8) * 1.1920928955078125e-07f - 1.0f;
+    }
+}
+
+hipError_t launch_white_noise(const sgx_ctx *c, float *d_out, uint64_t first, size_t n, uint32_t channels, uint32_t seed)
+{
+    if (n == 0) return hipSuccess;
+    const size_t total = n * channels;
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(white_noise_kernel, dim3((unsigned)blocks), dim3(256), 0, c->stream, d_out, (unsigned long long)first, n,
+                       channels, seed);
+    return hipGetLastError();
+}
+
+__device__ __forceinline__ unsigned long long mix64(unsigned long long z)
+{
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__global__ void checksum_kernel(const uint32_t *words, size_t n_words, unsigned long long base, unsigned long long *acc)
+{
+    unsigned long long local = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (size_t)gridDim.x * blockDim.x)
+        local += mix64(((base + i) << 32) ^ (unsigned long long)words[i] ^ ((base + i) >> 32));
+    // wave reduction, then one atomic per wave
+    for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(acc, local);
+}
+
+hipError_t launch_checksum(const sgx_ctx *c, const uint32_t *d_words, size_t n_words, uint64_t base_word,
+                           unsigned long long *d_acc)
+{
+    if (n_words == 0) return hipSuccess;
+    size_t blocks = (n_words + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(checksum_kernel, dim3((unsigned)blocks), dim3(256), 0, c->stream, d_words, n_words,
+                       (unsigned long long)base_word, d_acc);
+    return hipGetLastError();
+}
+
+}  // namespace sgx

@@ -1,0 +1,209 @@
+// sgx_tables.cpp -- host-side, once-per-context evaluation of everything on the pixel path that
+// depends only on the configuration (not on the audio): Hann table, twiddles, the log-frequency
+// row edges, magnitude_in's sample positions and interpolation weights, and the power
+// thresholds that replace log10 on the device.
+//
+// The arithmetic follows the reference's f32/f64 operation order (citations inline; file:line
+// in the reference repository).  This file must be compiled without FMA contraction
+// (-ffp-contract=off): every float operation below rounds exactly once, as rustc emits it.
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+#include "sgx_internal.hpp"
+
+namespace sgx {
+
+namespace {
+
+// Rust `x as usize` / `as i32` for floats: truncate toward zero, saturate, NaN -> 0.
+inline int64_t f32_as_index(float v)
+{
+    if (!(v > 0.0f)) return 0;
+    if (v >= 2147483648.0f) return 2147483647;
+    return (int64_t)v;
+}
+
+// interpolated_frequency_sample.rs:52-54: 2.0 * len as f32 / sample_rate as f32
+inline float period_of(uint32_t M, uint32_t sr) { return (2.0f * (float)M) / (float)sr; }
+
+// :24-31: (frequency * period).clamp(0.0, (len - 1) as f32)
+inline float index_of(float f, float period, uint32_t M)
+{
+    float idx = f * period;
+    const float hi = (float)(M - 1);
+    if (idx < 0.0f) idx = 0.0f;
+    if (idx > hi) idx = hi;
+    return idx;
+}
+
+}  // namespace
+
+void build_tables(uint32_t W, uint32_t R, uint32_t sr, double f_min, double f_max, uint32_t interp, Tables &out)
+{
+    const uint32_t P = 2 * W, M = W - 1;
+
+    // fft.rs:61 -- 0.5 * (1.0 - ((TAU * i as f32) / (W as f32)).cos()), all f32, product first.
+    out.window.resize(W);
+    {
+        const float tau = 6.28318530717958647692528676655900577f;
+        const float wf = (float)W;
+        for (uint32_t i = 0; i < W; ++i) {
+            float prod = tau * (float)i;
+            float q = prod / wf;
+            float c = cosf(q);
+            float om = 1.0f - c;
+            out.window[i] = 0.5f * om;
+        }
+    }
+
+    // Forward twiddles e^{-2 pi i j / P}, j < P/2, rounded from double (FFTW computes its
+    // twiddles in extended precision too; fft.rs:20-24 Sign::Forward).
+    out.twiddle.resize(P / 2);
+    for (uint32_t j = 0; j < P / 2; ++j) {
+        double ang = -2.0 * M_PI * (double)j / (double)P;
+        double c = cos(ang), s = sin(ang);
+        if (4 * j == P) { c = 0.0; s = -1.0; }
+        out.twiddle[j] = make_float2((float)c, (float)s);
+    }
+
+    // log_scaling.rs:160-191 (linear = ln(start)..ln(end), zero_point 0) and :114-119 (unmap),
+    // through plotters' RangedCoordf64::unmap: (hi - lo) * ((p - 0) / (R - 0)) + lo; exp; the
+    // cast to f32 is simple_spectrogram.rs:145.
+    out.edges.resize(R + 1);
+    {
+        const double lo = log(f_min), hi = log(f_max);
+        for (uint32_t p = 0; p <= R; ++p) {
+            double off = (double)p / (double)R;
+            double lin = (hi - lo) * off + lo;
+            out.edges[p] = (float)exp(lin);
+        }
+    }
+
+    // interpolated_frequency_sample.rs:60-75 for every row, :79-105 for the weights.
+    out.rows.resize(R);
+    out.samples.clear();
+    const float period = period_of(M, sr);
+    const float pi = 3.14159265358979323846264338327950288f;
+    for (uint32_t py = 0; py < R; ++py) {
+        const float f0 = out.edges[py], f1 = out.edges[py + 1];
+        const float i0 = index_of(f0, period, M), i1 = index_of(f1, period, M);
+        float d = i1 - i0;
+        int64_t n = f32_as_index(floorf(d));
+        if (n < 1) n = 1;
+        RowEntry re;
+        re.first = (uint32_t)out.samples.size();
+        re.count = (uint32_t)n;
+        re.count_f = (float)n;
+        re.pad = 0;
+        out.rows[py] = re;
+        // iter_num_tools lin_space over the half-open range: step = (end - start) / n,
+        // x_i = start + i * step
+        const float span = f1 - f0;
+        const float step = span / (float)n;
+        for (int64_t i = 0; i < n; ++i) {
+            float off = (float)i * step;
+            float f = f0 + off;
+            float idx = index_of(f, period, M);
+            SampleEntry se;
+            std::memset(&se, 0, sizeof(se));
+            float fl = floorf(idx);
+            if (interp == SGX_INTERP_COSINE) {
+                int64_t low = f32_as_index(fl);
+                int64_t high = f32_as_index(ceilf(idx));
+                if (high < low + 1) high = low + 1;
+                if (high > (int64_t)M - 1) high = (int64_t)M - 1;
+                float o = idx - (float)low;
+                float ang = o * pi;
+                float c = cosf(ang);
+                float om = 1.0f - c;
+                float o2 = om / 2.0f;
+                se.i0 = (int32_t)low;
+                se.i1 = (int32_t)high;
+                se.w1 = 1.0f - o2;
+                se.w2 = o2;
+            } else {
+                float mu = idx - fl;
+                float mu2 = mu * mu;   // num_traits::pow(mu, 2)
+                float mu3 = mu * mu2;  // num_traits::pow(mu, 3) = mu * (mu * mu)
+                se.i0 = (int32_t)f32_as_index(fl);
+                se.w0 = mu;
+                se.w1 = mu2;
+                se.w2 = mu3;
+            }
+            out.samples.push_back(se);
+        }
+    }
+}
+
+int lut_index_host(double t, uint32_t n, uint32_t mode)
+{
+    double x = (mode == SGX_LUT_ROUND_NM1) ? floor(t * (double)(n - 1) + 0.5) : floor(t * (double)n);
+    if (!(x > 0.0)) return 0;  // NaN, negatives: Rust's saturating `as usize`
+    if (x >= (double)n) return (int)n - 1;
+    return (int)x;
+}
+
+uint8_t alpha_u8_host(float alpha)
+{
+    // simple_spectrogram.rs:159: (alpha * 255.0) as u8
+    float v = alpha * 255.0f;
+    if (!(v > 0.0f)) return 0;
+    if (v >= 255.0f) return 255;
+    return (uint8_t)v;
+}
+
+float bounded_db_host(float min_db, float max_db, float power)
+{
+    // colorscheme.rs:60-61
+    float arg = power + 1e-7f;
+    float db = 10.0f * log10f(arg);
+    float num = db - min_db;
+    float den = max_db - min_db;
+    return num / den;
+}
+
+namespace {
+
+// Smallest non-negative float p (by bit pattern, +inf included) with level(p) >= want; +inf's
+// successor (a NaN pattern) is returned as +inf when no finite or infinite p reaches it.
+template <typename F>
+float first_power_reaching(int want, F level)
+{
+    uint32_t lo = 0, hi = 0x7f800000u;  // [+0, +inf]
+    auto at = [&](uint32_t bits) {
+        float p;
+        std::memcpy(&p, &bits, 4);
+        return level(p);
+    };
+    if (at(hi) < want) return std::numeric_limits<float>::quiet_NaN();  // unreachable level: never matches
+    while (lo < hi) {
+        uint32_t mid = lo + (hi - lo) / 2;
+        if (at(mid) >= want) hi = mid;
+        else lo = mid + 1;
+    }
+    float p;
+    std::memcpy(&p, &lo, 4);
+    return p;
+}
+
+}  // namespace
+
+void build_palette_thresholds(float min_db, float max_db, uint32_t lut_mode, Palette &pal)
+{
+    // color_for (colorscheme.rs:55-71) is a monotone step function of the power l^2 + r^2.  The
+    // device counts how many of these thresholds the power has reached instead of evaluating
+    // log10f, so the byte it writes is the one the host's libm would have chosen.
+    const uint32_t n = pal.n;
+    pal.lut_thr.assign(n > 0 ? n - 1 : 0, 0.0f);
+    for (uint32_t i = 1; i < n; ++i)
+        pal.lut_thr[i - 1] = first_power_reaching((int)i, [&](float p) {
+            return lut_index_host((double)bounded_db_host(min_db, max_db, p), n, lut_mode);
+        });
+    pal.alpha_thr.assign(255, 0.0f);
+    for (int a = 1; a <= 255; ++a)
+        pal.alpha_thr[a - 1] =
+            first_power_reaching(a, [&](float p) { return (int)alpha_u8_host(bounded_db_host(min_db, max_db, p)); });
+}
+
+}  // namespace sgx

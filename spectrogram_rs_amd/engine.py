@@ -1,0 +1,212 @@
+"""SpectrogramEngine -- thin object wrapper over one sgx_ctx (include/sgx.h).
+
+Device buffers are torch tensors (plumbing: allocation, streams); the arithmetic is entirely in
+libsgx.so's HIP kernels.  All batch calls take and return tensors on the engine's GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+
+from . import _lib
+from ._lib import SgxError, sgx_config, sgx_info
+
+
+class SpectrogramEngine:
+    def __init__(self, sample_rate: float = 48000.0, *, period: float = 0.0, stride: float = 0.0,
+                 window_samples: int = 0, hop_samples: int = 0, channels: int = 1, rows: int = 1024,
+                 f_min: float = 32.0, f_max: float = 22030.0, min_db: float = -70.0, max_db: float = -10.0,
+                 interp: int = _lib.INTERP_CUBIC, lut_index_mode: int = _lib.LUT_FLOOR_N,
+                 device: Optional[int] = None, force_generic: bool = False, gradient: Optional[str] = None):
+        import torch
+
+        self._lib = _lib.load()
+        self._ctx = C.c_void_p()
+        cfg = sgx_config()
+        self._lib.sgx_config_init(C.byref(cfg))
+        cfg.sample_rate = sample_rate
+        cfg.period, cfg.stride = period, stride
+        if period == 0.0 and window_samples == 0:
+            window_samples = 2048
+        if stride == 0.0 and hop_samples == 0:
+            hop_samples = 256
+        cfg.window_samples, cfg.hop_samples = window_samples, hop_samples
+        cfg.channels, cfg.rows = channels, rows
+        cfg.f_min, cfg.f_max = f_min, f_max
+        cfg.min_db, cfg.max_db = min_db, max_db
+        cfg.interp, cfg.lut_index_mode = interp, lut_index_mode
+        cfg.device = -1 if device is None else int(device)
+        cfg.flags = _lib.FLAG_FORCE_GENERIC if force_generic else 0
+        if device is not None and torch.cuda.is_available():
+            torch.cuda.set_device(int(device))
+        rc = self._lib.sgx_create(C.byref(cfg), C.byref(self._ctx))
+        if rc != 0:
+            msg = self._lib.sgx_last_error(None).decode()
+            self._ctx = C.c_void_p()
+            raise SgxError(rc, msg)
+        info = sgx_info()
+        self._check(self._lib.sgx_query(self._ctx, C.byref(info)))
+        self.info = info
+        self.W, self.P, self.M, self.H = info.window_samples, info.fft_length, info.num_frequencies, info.hop_samples
+        self.channels, self.pairs, self.R = info.channels, info.pairs, info.rows
+        self.sample_rate = float(sample_rate)
+        self.sample_rate_u32 = info.sample_rate_u32
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else int(device))
+        self.use_current_stream()
+        if gradient is not None:
+            self.set_builtin_gradient(gradient)
+
+    # ---- plumbing --------------------------------------------------------------------------
+    def _check(self, rc: int) -> int:
+        if rc < 0:
+            raise SgxError(rc, self._lib.sgx_last_error(self._ctx).decode())
+        return rc
+
+    def close(self):
+        if getattr(self, "_ctx", None) is not None and self._ctx.value:
+            self._lib.sgx_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def use_current_stream(self):
+        """Enqueue on torch's current stream for this device."""
+        import torch
+
+        s = torch.cuda.current_stream(self.device)
+        self._check(self._lib.sgx_set_stream(self._ctx, C.c_void_p(s.cuda_stream)))
+
+    def set_stream(self, cuda_stream: int):
+        self._check(self._lib.sgx_set_stream(self._ctx, C.c_void_p(cuda_stream)))
+
+    def sync(self):
+        self._check(self._lib.sgx_sync(self._ctx))
+
+    def _dev_f32(self, t):
+        import torch
+
+        assert isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous(), \
+            "expected a contiguous float32 CUDA tensor"
+        return C.c_void_p(t.data_ptr())
+
+    # ---- sizes -----------------------------------------------------------------------------
+    def num_frames(self, n_samples: int) -> int:
+        return int(self._lib.sgx_num_frames(self._ctx, n_samples))
+
+    # ---- transform -------------------------------------------------------------------------
+    def stft_batch(self, pcm, first_frame: int = 0, max_frames: Optional[int] = None, out=None):
+        """pcm: CUDA float32 tensor of n_samples*channels interleaved samples.
+        Returns [frames][pairs][M][2] float32 (left, right) magnitudes."""
+        import torch
+
+        n_samples = pcm.numel() // self.channels
+        total = self.num_frames(n_samples)
+        n = max(total - first_frame, 0)
+        if max_frames is not None:
+            n = min(n, max_frames)
+        if out is None:
+            out = torch.empty((n, self.pairs, self.M, 2), dtype=torch.float32, device=pcm.device)
+        else:
+            assert out.numel() >= n * self.pairs * self.M * 2 and out.dtype == torch.float32 and out.is_contiguous()
+        got = C.c_size_t(0)
+        if n:
+            self._check(self._lib.sgx_stft_batch(self._ctx, self._dev_f32(pcm), n_samples, first_frame, n,
+                                                 C.c_void_p(out.data_ptr()), C.byref(got)))
+            assert got.value == n
+        return out
+
+    def process_one(self, lr: np.ndarray) -> Optional[np.ndarray]:
+        """AudioTransform::process on host (l, r) pairs: [n][2] -> [M][2] or None."""
+        lr = np.ascontiguousarray(lr, np.float32).reshape(-1, 2)
+        out = np.empty((self.M, 2), np.float32)
+        rc = self._check(self._lib.sgx_process_one(self._ctx, lr.ctypes.data_as(C.c_void_p), lr.shape[0],
+                                                   out.ctypes.data_as(C.c_void_p)))
+        return out if rc == 1 else None
+
+    # ---- pixel path ------------------------------------------------------------------------
+    def render_batch(self, pcm, first_frame: int = 0, max_frames: Optional[int] = None, out=None):
+        """PCM -> [frames][pairs][R][4] uint8 RGBA columns (image-row order: row 0 = top)."""
+        import torch
+
+        n_samples = pcm.numel() // self.channels
+        total = self.num_frames(n_samples)
+        n = max(total - first_frame, 0)
+        if max_frames is not None:
+            n = min(n, max_frames)
+        if out is None:
+            out = torch.empty((n, self.pairs, self.R, 4), dtype=torch.uint8, device=pcm.device)
+        got = C.c_size_t(0)
+        if n:
+            self._check(self._lib.sgx_render_batch(self._ctx, self._dev_f32(pcm), n_samples, first_frame, n,
+                                                   C.c_void_p(out.data_ptr()), C.byref(got)))
+            assert got.value == n
+        return out
+
+    def render_mags(self, mags, out=None):
+        """[columns][M][2] float32 magnitudes -> [columns][R][4] uint8."""
+        import torch
+
+        n = mags.numel() // (self.M * 2)
+        if out is None:
+            out = torch.empty((n, self.R, 4), dtype=torch.uint8, device=mags.device)
+        if n:
+            self._check(self._lib.sgx_render_mags(self._ctx, self._dev_f32(mags), n, C.c_void_p(out.data_ptr())))
+        return out
+
+    # ---- colour scheme ---------------------------------------------------------------------
+    def set_gradient(self, rgb: np.ndarray, stereo: bool = False):
+        rgb = np.ascontiguousarray(rgb, np.uint8).reshape(-1, 3)
+        self._check(self._lib.sgx_set_gradient(self._ctx, rgb.ctypes.data_as(C.c_void_p), rgb.shape[0], int(stereo)))
+
+    def set_builtin_gradient(self, name: str):
+        self._check(self._lib.sgx_set_builtin_gradient(self._ctx, name.encode()))
+
+    def lookup_table(self, resolution: int = 32) -> np.ndarray:
+        out = np.empty((resolution, resolution, 4), np.float32)
+        self._check(self._lib.sgx_lookup_table(self._ctx, resolution, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    # ---- introspection ---------------------------------------------------------------------
+    def bin_edges(self) -> np.ndarray:
+        out = np.empty(self.R + 1, np.float32)
+        self._check(self._lib.sgx_bin_edges(self._ctx, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def row_sample_counts(self) -> np.ndarray:
+        out = np.empty(self.R, np.uint32)
+        self._check(self._lib.sgx_row_sample_counts(self._ctx, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def window(self) -> np.ndarray:
+        out = np.empty(self.W, np.float32)
+        self._check(self._lib.sgx_window(self._ctx, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    # ---- harness helpers -------------------------------------------------------------------
+    def white_noise(self, n_samples: int, first: int = 0, seed: int = 0x5EED0001, channels: Optional[int] = None):
+        import torch
+
+        ch = self.channels if channels is None else channels
+        out = torch.empty(n_samples * ch, dtype=torch.float32, device=self.device)
+        self._check(self._lib.sgx_synth_white_noise(self._ctx, C.c_void_p(out.data_ptr()), first, n_samples, ch, seed))
+        return out
+
+    def checksum(self, t, base_word: int = 0) -> int:
+        nbytes = t.numel() * t.element_size()
+        v = C.c_uint64(0)
+        self._check(self._lib.sgx_checksum(self._ctx, C.c_void_p(t.data_ptr()), nbytes, base_word, C.byref(v)))
+        return int(v.value)
+
+
+def builtin_gradient(name: str) -> np.ndarray:
+    lib = _lib.load()
+    out = np.empty((256, 3), np.uint8)
+    if lib.sgx_builtin_gradient(name.encode(), out.ctypes.data_as(C.c_void_p)) != 0:
+        raise KeyError(name)
+    return out

@@ -1,0 +1,77 @@
+"""Host-side mirror of the pixel loop of src/widgets/simple_spectrogram.rs.
+
+SimpleSpectrogram keeps a TEXTURE_WIDTH x TEXTURE_HEIGHT RGBA image that is used as a ring of
+pixel columns (simple_spectrogram.rs:34-35,89-94,164).  `snapshot()` here does what the first half
+of the reference's `snapshot` does (:120-165): drain the ring through the transform, turn every
+frame into one pixel column and advance `offset`.  Drawing the two sub-pixbufs (:181-209) is GTK
+and out of scope; `scrolled()` returns the same image they would compose.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+
+from .colorscheme import ColorScheme
+from .engine import SpectrogramEngine
+from .fourier import RingBuffer
+
+TEXTURE_WIDTH = 1024   # simple_spectrogram.rs:34
+TEXTURE_HEIGHT = 1024  # simple_spectrogram.rs:35
+
+
+class SimpleSpectrogram:
+    def __init__(self, sample_stream: RingBuffer, *, sample_rate: int = 48000, period: float = 0.05,
+                 window_samples: int = 0, device: Optional[int] = None, interp: int = 0,
+                 width: int = TEXTURE_WIDTH, height: int = TEXTURE_HEIGHT):
+        import torch
+
+        self.input_stream = sample_stream
+        self.width, self.height = width, height
+        self.palette = ColorScheme.new_mono("magma", "magma")  # :95
+        self.offset = 0
+        self._period, self._window_samples, self._device, self._interp = period, window_samples, device, interp
+        self.stride = 2.0 / width  # :102
+        self.engine: Optional[SpectrogramEngine] = None
+        self.set_sample_rate(sample_rate)
+        self.buffer = torch.zeros((height, width, 4), dtype=torch.uint8, device=self.engine.device)
+
+    def set_sample_rate(self, sample_rate: int) -> None:
+        """:214-219 -- replaces the transform wholesale"""
+        sr = np.float32(sample_rate)
+        hop = int(np.float32(self.stride) * sr)
+        if self.engine is not None:
+            self.engine.close()
+        kw = dict(window_samples=self._window_samples) if self._window_samples else dict(period=self._period)
+        self.engine = SpectrogramEngine(float(sr), hop_samples=max(hop, 1), channels=2, rows=self.height,
+                                        interp=self._interp, device=self._device, **kw)
+        self.palette.apply(self.engine)
+
+    def set_palette(self, palette: ColorScheme) -> None:
+        self.palette = palette
+        palette.apply(self.engine)
+
+    def snapshot(self) -> int:
+        """Drain the ring; returns the number of pixel columns written."""
+        import torch
+
+        eng = self.engine
+        n = len(self.input_stream)
+        frames = eng.num_frames(n)
+        if frames:
+            lr = self.input_stream.iter()[:(frames - 1) * eng.H + eng.W]
+            pcm = torch.from_numpy(np.ascontiguousarray(lr)).to(eng.device).reshape(-1)
+            cols = eng.render_batch(pcm)[:, 0]                      # [frames][R][4], image-row order
+            px = (self.offset + torch.arange(frames, device=eng.device)) % self.width
+            keep = slice(max(frames - self.width, 0), frames)       # later columns overwrite earlier ones
+            self.buffer[:, px[keep], :] = cols[keep].permute(1, 0, 2)
+            self.offset = (self.offset + frames) % self.width       # :164
+        self.input_stream.skip((frames + 1) * eng.H)                # audio_transform.rs:37-41
+        return frames
+
+    def scrolled(self):
+        """The image the two append_scaled_texture calls compose (:181-209): columns
+        [offset, width) followed by [0, offset)."""
+        import torch
+
+        return torch.cat([self.buffer[:, self.offset:], self.buffer[:, :self.offset]], dim=1)

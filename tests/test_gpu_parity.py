@@ -1,0 +1,266 @@
+"""Parity tests proper: the HIP path, called through the C ABI, against the CPU oracle on the same
+seeded inputs, against the committed golden fixtures, and -- at sizes the oracle cannot reach --
+through size-independent properties.  Run with -m gpu on an MI355X."""
+import numpy as np
+import pytest
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+W, H, SR, R = 2048, 256, 48000, 1024
+M = W - 1
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the GPU"
+    return torch
+
+
+def engine(**kw):
+    from spectrogram_rs_amd import SpectrogramEngine
+    return SpectrogramEngine(48000.0, **kw)
+
+
+def to_dev(torch, a):
+    return torch.from_numpy(np.ascontiguousarray(a, np.float32)).cuda().reshape(-1)
+
+
+# ---- the transform -----------------------------------------------------------------------------
+
+@pytest.mark.parametrize("force_generic", [False, True])
+@pytest.mark.parametrize("channels", [1, 2])
+def test_stft_batch_matches_oracle(torch_cuda, mags_err, force_generic, channels):
+    torch = torch_cuda
+    eng = engine(window_samples=W, hop_samples=H, channels=channels, force_generic=force_generic)
+    n = W + H * 130 + 77
+    pcm = oracle.white_noise(n * channels, seed=11 + channels)
+    got = eng.stft_batch(to_dev(torch, pcm)).cpu().numpy()
+    ref32 = oracle.stream_process(pcm, channels, W, H, threads=8)
+    ref64 = np.stack([oracle.np_truth_frame(
+        (np.stack([pcm[t * H:t * H + W]] * 2, 1) if channels == 1 else pcm.reshape(-1, 2)[t * H:t * H + W]), W)
+        for t in range(0, 131, 13)])
+    assert got.shape == ref32.shape == (131, 1, M, 2)
+    assert mags_err(got[::13, 0], ref64) <= 1.0          # against float64 truth
+    assert mags_err(got, ref32) <= 2.0                   # two float32 FFTs, each within tolerance of the truth
+    if channels == 1:
+        assert np.array_equal(got[..., 0], got[..., 1])  # mono -> (s, s): L == R bit for bit
+
+
+def test_golden_frames_through_the_abi(torch_cuda, gold, mags_err):
+    torch = torch_cuda
+    eng = engine(window_samples=W, hop_samples=H, channels=1)
+    for name in ("config1_sweep.npz", "noise_frames.npz"):
+        g = gold(name)
+        for s, exp in zip(g["input"], g["expected_f64"]):
+            got = eng.stft_batch(to_dev(torch, s)).cpu().numpy()
+            assert got.shape == (1, 1, M, 2)
+            assert mags_err(got[0, 0], exp) <= 1.0
+
+
+@pytest.mark.parametrize("Wt,Ht,ch", [(8192, 512, 8), (1024, 93, 2), (64, 16, 1), (4, 1, 2), (2048, 58, 2)])
+def test_other_sizes_and_channel_pairs(torch_cuda, mags_err, Wt, Ht, ch):
+    # config 4 (16384-point, 8 interleaved channels = 4 pairs) and assorted power-of-two windows
+    torch = torch_cuda
+    eng = engine(window_samples=Wt, hop_samples=Ht, channels=ch)
+    n = Wt + Ht * 9 + 3
+    pcm = oracle.white_noise(n * ch, seed=5)
+    got = eng.stft_batch(to_dev(torch, pcm)).cpu().numpy()
+    ref = oracle.stream_process(pcm, ch, Wt, Ht, threads=8)
+    assert got.shape == ref.shape == (10, max(ch // 2, 1), Wt - 1, 2)
+    assert mags_err(got, ref) <= 2.0
+
+
+def test_short_ragged_and_empty_inputs(torch_cuda):
+    torch = torch_cuda
+    eng = engine(window_samples=W, hop_samples=H, channels=2)
+    assert eng.num_frames(0) == 0 and eng.num_frames(W - 1) == 0 and eng.num_frames(W) == 1
+    short = torch.zeros(2 * (W - 1), device="cuda")
+    assert eng.stft_batch(short).shape == (0, 1, M, 2)           # None -> no frames, no error
+    assert eng.render_batch(short).shape == (0, 1, R, 4)
+    assert eng.process_one(np.zeros((W - 1, 2), np.float32)) is None
+    ragged = to_dev(torch, oracle.white_noise(2 * (W + H + 100)))  # 100 trailing samples unused
+    assert eng.stft_batch(ragged).shape[0] == 2
+    # first_frame / max_frames window
+    pcm = oracle.white_noise(2 * (W + 7 * H), seed=2)
+    full = eng.stft_batch(to_dev(torch, pcm)).cpu().numpy()
+    part = eng.stft_batch(to_dev(torch, pcm), first_frame=3, max_frames=2).cpu().numpy()
+    assert np.array_equal(part, full[3:5])
+    assert eng.stft_batch(to_dev(torch, pcm), first_frame=99).shape[0] == 0
+
+
+def test_process_one_mirrors_process(torch_cuda, mags_err):
+    from spectrogram_rs_amd import FastFourierTransform
+    fft = FastFourierTransform(48000.0, 2048 / 48000.0 + 1e-7)
+    assert fft.num_input_samples() == W and fft.num_output_frequencies() == M and fft.sample_rate() == 48000.0
+    lr = oracle.white_noise(2 * W, seed=9).reshape(-1, 2)
+    out = fft.process(lr)
+    assert out.shape == (M, 2) and mags_err(out, oracle.np_truth_frame(lr, W)) <= 1.0
+    assert fft.process(lr[:-1]) is None                       # fft.rs:72
+    assert fft.process(iter([tuple(x) for x in lr])) is not None  # any iterable of (l, r)
+
+
+def test_unsupported_length_is_reported_not_approximated(torch_cuda):
+    from spectrogram_rs_amd import SgxError
+    with pytest.raises(SgxError) as ei:
+        engine(period=0.05)  # W = 2400, P = 4800: not a power of two
+    assert ei.value.code == -2 and "4800" in str(ei.value)
+
+
+def test_stream_wrapper_on_gpu(torch_cuda, mags_err):
+    from spectrogram_rs_amd import AudioStreamTransform, FastFourierTransform, RingBuffer
+    rb = RingBuffer(1 << 16)
+    lr = oracle.white_noise(2 * (W + 5 * 93 + 40), seed=4).reshape(-1, 2)
+    rb.push_iter(lr)
+    st = AudioStreamTransform(rb, FastFourierTransform(48000.0, 2048 / 48000.0 + 1e-7), 2.0 / 1024)
+    frames = list(st.process())
+    assert st.stride_samples() == 93 and len(frames) == 6
+    ref = oracle.stream_process(lr, 2, W, 93)
+    assert mags_err(np.stack(frames), ref[:, 0]) <= 2.0
+    assert len(rb) == len(lr) - 7 * 93
+
+
+# ---- properties at sizes the oracle does not reach -----------------------------------------------
+
+def test_full_size_properties(torch_cuda, mags_err):
+    torch = torch_cuda
+    F = 200_000
+    eng = engine(window_samples=W, hop_samples=H, channels=1)
+    n = (F - 1) * H + W
+    pcm = eng.white_noise(n)
+    assert np.array_equal(pcm[:4096].cpu().numpy(), oracle.white_noise(4096))      # generator parity
+    assert np.array_equal(pcm[n - 512:].cpu().numpy(), oracle.white_noise(512, first=n - 512))
+    mags = eng.stft_batch(pcm)
+    assert mags.shape == (F, 1, M, 2) and bool(torch.isfinite(mags).all())
+    # sampled frames against the oracle (t = i*977 mod F)
+    ts = [(i * 977) % F for i in range(64)]
+    host = pcm.cpu().numpy()
+    ref = np.stack([oracle.fft_process(np.stack([host[t * H:t * H + W]] * 2, 1), W) for t in ts])
+    got = mags[ts, 0].cpu().numpy()
+    assert mags_err(got, ref) <= 2.0
+    # homogeneity: halving the input (exact in f32) halves every magnitude bit for bit
+    half = eng.stft_batch(pcm * 0.5)
+    assert bool(torch.equal(half * 2.0, mags))
+    # Parseval per frame: sum_k (m_k W/2)^2 over k=1..W-1 vs the windowed energy (DC/Nyquist excluded: loose bound)
+    win = torch.from_numpy(eng.window()).cuda()
+    idx = torch.arange(W, device="cuda")[None, :] + (torch.tensor(ts, device="cuda") * H)[:, None]
+    e_time = ((pcm[idx] * win) ** 2).sum(1) * W  # = (1/2) sum over all P bins |F|^2 = P/2 * energy
+    e_freq = ((mags[ts, 0, :, 0].double() * (W / 2.0)) ** 2).sum(1)
+    rel = ((e_freq - e_time.double()).abs() / e_time.double()).max().item()
+    assert rel < 2e-2
+    # determinism and shard-independence: any split of the frame range gives the same bytes
+    a = eng.checksum(mags)
+    again = eng.stft_batch(pcm)
+    assert eng.checksum(again) == a
+    lo = eng.stft_batch(pcm, first_frame=0, max_frames=F // 2)
+    hi = eng.stft_batch(pcm, first_frame=F // 2)
+    words_lo = lo.numel()
+    assert (eng.checksum(lo) + eng.checksum(hi, base_word=words_lo)) % (1 << 64) == a
+
+
+# ---- the pixel path --------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("interp", [0, 1])
+@pytest.mark.parametrize("grad", ["viridis", "magma"])
+def test_render_stage_is_bit_exact_given_identical_magnitudes(torch_cuda, gradients, interp, grad):
+    torch = torch_cuda
+    eng = engine(window_samples=W, hop_samples=H, channels=1, interp=interp, gradient=grad)
+    assert np.array_equal(eng.bin_edges(), oracle.bin_edges(R))
+    pcm = oracle.white_noise(W + 15 * H, seed=21)
+    mags = oracle.stream_process(pcm, 1, W, H)[:, 0]
+    # widen the dynamic range so every LUT level and both clamps are exercised
+    mags = (mags * np.logspace(-4, 1.5, mags.shape[0], dtype=np.float32)[:, None, None]).astype(np.float32)
+    mags[3] = 0.0
+    got = eng.render_mags(to_dev(torch, mags)).cpu().numpy()
+    ref = oracle.render_columns(mags, SR, gradients[grad], interp=interp)
+    assert got.shape == ref.shape == (16, R, 4)
+    assert np.array_equal(got, ref)
+    assert len(np.unique(ref[..., :3].reshape(-1, 3), axis=0)) > 200
+
+
+def test_render_golden_columns(torch_cuda, gold):
+    torch = torch_cuda
+    g = gold("rgba_columns.npz")
+    for name, interp in (("cubic", 0), ("cosine", 1)):
+        eng = engine(window_samples=W, hop_samples=H, interp=interp, gradient="viridis")
+        got = eng.render_mags(to_dev(torch, g["mags"])).cpu().numpy()
+        assert np.array_equal(got, g["viridis_" + name])
+
+
+def test_render_stereo_scheme_bit_exact(torch_cuda, gradients):
+    torch = torch_cuda
+    eng = engine(window_samples=W, hop_samples=H, channels=2)
+    eng.set_gradient(gradients["plasma"], stereo=True)
+    st = oracle.white_noise(2 * (W + 7 * H), seed=8).reshape(-1, 2) * np.array([1.0, 0.3], np.float32)
+    mags = oracle.stream_process(st, 2, W, H)[:, 0]
+    mags = (mags * np.logspace(-3, 1, 8, dtype=np.float32)[:, None, None]).astype(np.float32)
+    mags[2] = 0.0  # l = r = 0 -> t = NaN -> index 0, alpha from silence
+    got = eng.render_mags(to_dev(torch, mags)).cpu().numpy()
+    ref = oracle.render_columns(mags, SR, gradients["plasma"], stereo=True)
+    assert np.array_equal(got, ref)
+    assert got[..., 3].min() == 0 and got[..., 3].max() == 255
+
+
+def test_threshold_tables_reproduce_log10_everywhere(torch_cuda, gradients):
+    # dense sweep of powers across every LUT boundary: one bin per "column", constant spectrum
+    torch = torch_cuda
+    eng = engine(window_samples=W, hop_samples=H, gradient="viridis")
+    rng = np.random.default_rng(0)
+    p = np.concatenate([10 ** rng.uniform(-8, 0, 4000), [0.0, 1e-30, 1e-7, 0.1, 0.1000001, 1.0, 1e6]]).astype(np.float32)
+    m = np.sqrt(p / 2).astype(np.float32)
+    mags = np.repeat(m[:, None, None], M, 1).repeat(2, 2).astype(np.float32)
+    got = eng.render_mags(to_dev(torch, mags)).cpu().numpy()
+    ref = oracle.render_columns(mags, SR, gradients["viridis"])
+    assert np.array_equal(got, ref)
+
+
+def test_fused_pcm_to_rgba_end_to_end(torch_cuda, gradients):
+    # end to end the magnitudes differ from the oracle's by float32 rounding, so a pixel that sits
+    # on a LUT boundary may move by one step: report the rate, bound it, and bound the step.
+    torch = torch_cuda
+    for interp in (0, 1):
+        eng = engine(window_samples=W, hop_samples=H, channels=1, interp=interp, gradient="viridis")
+        pcm = oracle.white_noise(W + 63 * H, seed=33) * np.float32(0.05)
+        got = eng.render_batch(to_dev(torch, pcm)).cpu().numpy()[:, 0]
+        mags = oracle.stream_process(pcm, 1, W, H)[:, 0]
+        ref = oracle.render_columns(mags, SR, gradients["viridis"], interp=interp)
+        assert got.shape == ref.shape == (64, R, 4)
+        lut = {tuple(c): i for i, c in enumerate(gradients["viridis"])}
+        gi = np.array([lut[tuple(c)] for c in got[..., :3].reshape(-1, 3)])
+        ri = np.array([lut[tuple(c)] for c in ref[..., :3].reshape(-1, 3)])
+        mismatch = (gi != ri).mean()
+        assert mismatch < 2e-3 and np.abs(gi - ri).max() <= 1, (mismatch, np.abs(gi - ri).max())
+        # and exactly equal to the render stage applied to the engine's own magnitudes
+        own = eng.render_mags(eng.stft_batch(to_dev(torch, pcm))[:, 0].contiguous()).cpu().numpy()
+        assert np.array_equal(got, own)
+
+
+def test_lookup_table_and_widget_ring(torch_cuda, gradients):
+    torch = torch_cuda
+    from spectrogram_rs_amd import ColorScheme, RingBuffer, SimpleSpectrogram
+    eng = engine(window_samples=W, hop_samples=H)
+    cs = ColorScheme.new_mono("magma", "Magma")
+    assert np.array_equal(cs.lookup_table(32, eng), oracle.lookup_table(gradients["magma"], 32))
+    cs2 = ColorScheme.new_stereo(gradients["plasma"], (0, 0, 0), "Plasma (Stereo)")
+    assert np.array_equal(cs2.lookup_table(32, eng), oracle.lookup_table(gradients["plasma"], 32, stereo=True))
+    assert cs2.background() == (0, 0, 0) and cs.background() == tuple(gradients["magma"][0])
+    # SimpleSpectrogram: columns land at offset, offset advances modulo width, low frequencies at the bottom
+    rb = RingBuffer(1 << 20)
+    w = SimpleSpectrogram(rb, sample_rate=48000, window_samples=W, width=64, height=R)
+    w.set_palette(ColorScheme.new_mono("viridis", "Viridis"))
+    H2 = w.engine.H
+    t = np.arange(W + 9 * H2) / 48000.0
+    tone = (0.25 * np.sin(2 * np.pi * 100.0 * t)).astype(np.float32)
+    rb.push_mono(tone)
+    assert w.snapshot() == 10 and w.offset == 10
+    img = w.buffer.cpu().numpy()
+    bg = gradients["viridis"][0]
+    lit_rows = np.nonzero((img[:, 0, :3] != bg).any(axis=1))[0]
+    assert len(lit_rows) and lit_rows.min() > R // 2 and (img[:, 10:, :] == 0).all()
+    mags = oracle.stream_process(np.stack([tone, tone], 1), 2, W, H2)[:, 0]
+    ref = oracle.render_columns(mags, 48000, gradients["viridis"])
+    diff = (img[:, :10].transpose(1, 0, 2) != ref).any(axis=2).mean()
+    assert diff < 5e-3
+    assert w.scrolled().shape == (R, 64, 4)

@@ -1,0 +1,81 @@
+"""Host-side mirror of the reference interface: ring buffer, hop loop, log axis.  No GPU: the
+transform is replaced by a recording fake that implements the AudioTransform interface."""
+import math
+
+import numpy as np
+import pytest
+
+import oracle
+from spectrogram_rs_amd.fourier import AudioStreamTransform, AudioTransform, RingBuffer
+from spectrogram_rs_amd.log_scaling import LogCoordf64
+
+
+class FakeTransform(AudioTransform):
+    def __init__(self, sr, W):
+        self.sr, self.W, self.calls = sr, W, []
+
+    def sample_rate(self):
+        return self.sr
+
+    def num_input_samples(self):
+        return self.W
+
+    def process(self, samples):
+        s = np.asarray(samples).reshape(-1, 2)[:self.W]
+        if len(s) < self.W:
+            return None
+        self.calls.append(s.copy())
+        return s[:1]
+
+
+def test_ring_buffer_semantics():
+    rb = RingBuffer(8)
+    assert rb.push_iter([(i, -i) for i in range(6)]) == 6
+    assert rb.push_mono([9, 9, 9, 9]) == 2  # overflow is dropped (audio_input_list_model.rs:70)
+    assert len(rb) == 8 and rb.iter()[6].tolist() == [9, 9]
+    assert rb.skip(3) == 3 and rb.iter()[0].tolist() == [3, -3]
+    assert rb.skip(100) == 5 and len(rb) == 0
+
+
+def test_hop_loop_yields_reference_frames_and_skips_like_the_reference():
+    sr, W, stride = 1000.0, 16, 0.004  # H = 4
+    rb = RingBuffer(4096)
+    data = np.arange(2 * 45, dtype=np.float32).reshape(45, 2)
+    rb.push_iter(data)
+    tr = FakeTransform(sr, W)
+    st = AudioStreamTransform(rb, tr, stride)
+    assert st.stride_samples() == 4 == oracle.hop_samples(sr, stride)
+    frames = list(st.process())
+    n = oracle.num_frames(45, W, 4)
+    assert len(frames) == n == 8
+    for t, call in enumerate(tr.calls):
+        assert np.array_equal(call, data[t * 4:t * 4 + W])  # frame t covers [tH, tH+W)
+    # the terminating short read also skips H (audio_transform.rs:37-41, quirk Q1)
+    assert len(rb) == 45 - (n + 1) * 4
+    # nothing more to yield
+    assert list(st.process()) == [] and len(rb) == 45 - (n + 2) * 4
+    with pytest.raises(ValueError):
+        AudioStreamTransform(rb, tr, 1e-9).process().__next__()
+
+
+def test_public_fields_are_reassignable():
+    rb = RingBuffer(64)
+    st = AudioStreamTransform(rb, FakeTransform(100.0, 4), 0.02)
+    st.transform = FakeTransform(200.0, 8)  # set_sample_rate replaces the transform wholesale
+    st.stride = 0.01
+    assert st.stride_samples() == 2
+    rb.push_iter(np.zeros((12, 2), np.float32))
+    assert len(list(st.process())) == 3
+
+
+def test_log_axis_matches_oracle_and_roundtrips():
+    ax = LogCoordf64.reversible_log_scale(32.0, 22030.0).with_base(2.0).with_zero_point(0.0)  # simple_spectrogram.rs:107
+    assert ax.linear == (math.log(32.0), math.log(22030.0)) and not ax.negative
+    for p in (0, 1, 511, 1023, 1024):
+        assert ax.unmap(p, (0, 1024)) == oracle.log_unmap(32.0, 22030.0, p, 0, 1024)
+    assert ax.unmap(-1, (0, 1024)) is None and ax.unmap(1025, (0, 1024)) is None
+    assert ax.unmap(0, (0, 1024)) == pytest.approx(32.0) and ax.unmap(1024, (0, 1024)) == pytest.approx(22030.0)
+    for p in (3, 400, 1000):
+        assert ax.map(ax.unmap(p, (0, 1024)), (0, 1024)) == p
+    e = np.array([np.float32(ax.unmap(p, (0, 1024))) for p in range(1025)], np.float32)
+    assert np.array_equal(e, oracle.bin_edges(1024))
