@@ -46,7 +46,9 @@ def test_stft_batch_matches_oracle(torch_cuda, mags_err, force_generic, channels
     assert mags_err(got[::13, 0], ref64) <= 1.0          # against float64 truth
     assert mags_err(got, ref32) <= 2.0                   # two float32 FFTs, each within tolerance of the truth
     if channels == 1:
-        assert np.array_equal(got[..., 0], got[..., 1])  # mono -> (s, s): L == R bit for bit
+        # mono -> (s, s): both columns are |S^[k]| (computed by different float32 expressions in the
+        # reference too, fft.rs:87-88, so equal to rounding, not bit for bit)
+        assert mags_err(got[..., 0:1], got[..., 1:2].astype(np.float64)) <= 1.0
 
 
 def test_golden_frames_through_the_abi(torch_cuda, gold, mags_err):
@@ -69,7 +71,8 @@ def test_other_sizes_and_channel_pairs(torch_cuda, mags_err, Wt, Ht, ch):
     pcm = oracle.white_noise(n * ch, seed=5)
     got = eng.stft_batch(to_dev(torch, pcm)).cpu().numpy()
     ref = oracle.stream_process(pcm, ch, Wt, Ht, threads=8)
-    assert got.shape == ref.shape == (10, max(ch // 2, 1), Wt - 1, 2)
+    assert got.shape == ref.shape == (oracle.num_frames(n, Wt, Ht), max(ch // 2, 1), Wt - 1, 2)
+    assert got.shape[0] >= 10
     assert mags_err(got, ref) <= 2.0
 
 

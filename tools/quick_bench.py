@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Quick device-side timing of the STFT / render kernels (development aid; bench.py is the contract)."""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from spectrogram_rs_amd import SpectrogramEngine
+
+
+def timeit(fn, iters=10, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for a, b in evs:
+        a.record(); fn(); b.record()
+    torch.cuda.synchronize()
+    ts = sorted(a.elapsed_time(b) for a, b in evs)
+    return ts[len(ts) // 2], ts[0]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=200_000)
+    ap.add_argument("--generic", action="store_true")
+    ap.add_argument("--render", action="store_true")
+    args = ap.parse_args()
+    F = args.frames
+    for ch in (1, 2):
+        eng = SpectrogramEngine(48000.0, window_samples=2048, hop_samples=256, channels=ch, force_generic=args.generic,
+                                gradient="viridis")
+        n = (F - 1) * eng.H + eng.W
+        pcm = eng.white_noise(n)
+        out = torch.empty((F, 1, eng.M, 2), dtype=torch.float32, device="cuda")
+        med, best = timeit(lambda: eng.stft_batch(pcm, out=out))
+        byts = F * (eng.H * ch * 4 + eng.M * 8)
+        print(f"stft ch={ch} kernel={eng.info.stft_kernel} F={F}: median {med:.3f} ms best {best:.3f} ms -> "
+              f"{F / med / 1e3:.1f} M frames/s, {byts / med / 1e6:.1f} GB/s algorithmic", flush=True)
+        if args.render:
+            rg = torch.empty((F, 1, eng.R, 4), dtype=torch.uint8, device="cuda")
+            med, best = timeit(lambda: eng.render_batch(pcm, out=rg), iters=5)
+            print(f"render ch={ch}: median {med:.3f} ms -> {F / med / 1e3:.1f} M frames/s", flush=True)
+            med, best = timeit(lambda: eng.render_mags(out[:, 0], out=rg[:, 0]), iters=5)
+            print(f"render_mags only: median {med:.3f} ms -> {F / med / 1e3:.1f} M columns/s", flush=True)
+
+
+if __name__ == "__main__":
+    main()
