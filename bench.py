@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""bench.py -- STFT frames/s (4096-point, hop 256) on N MI355X, with roofline and CPU baseline.
+
+Contract (one JSON line on rank 0):
+  python bench.py --gpus N --steps K --warmup W
+  N > 1 is launched by the driver as
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path over one batch of synthetic PCM that is already resident in
+HBM: BASELINE config 2 -- 1e6 frames of mono white noise (256 001 792 samples), W 2048 / P 4096 /
+H 256, output [1e6][2047][2] float32 magnitudes.  With N GPUs every rank transforms its own
+1e6-frame shard of one long stream (contiguous frame ranges, sample offset rank * 1e6 * H; no
+data-path collective: the path shards by frame) => weak scaling; value = N * 1e6 * K / t.
+
+Extra objects on the same line:
+  roofline     -- dominant kernel (the STFT kernel): algorithmic bytes per launch / measured
+                  launch duration (HIP events on the launch stream) against the 8 TB/s HBM peak
+  cpu_baseline -- the CPU oracle (oracle/, a port of the reference's algorithm; the reference itself
+                  is Rust + FFTW and cannot be built in this image) timed on this host's cores, on a
+                  bounded sample of the same stream (rank 0, N = 1 only)
+  pixel_path   -- BASELINE config 3 (N = 1) / config 5 shape (N > 1): PCM -> RGBA columns, and for
+                  N > 1 the RCCL gather of pixel columns to rank 0 (reported, not the headline value)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+W, H, M, R = 2048, 256, 2047, 1024
+ALGO_BYTES_STFT = H * 1 * 4 + M * 2 * 4  # 17 400 B / frame: each input sample once, each output byte once
+ALGO_BYTES_PIXEL = H * 1 * 4 + R * 4     # 5 120 B / frame
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=1_000_000, help="frames per GPU per step (config 2: 1e6)")
+    ap.add_argument("--pixel-frames", type=int, default=262_144, help="frames per GPU for the pixel-path leg (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=65_536, help="frames of the bounded CPU-baseline sample (0 = skip)")
+    ap.add_argument("--generic", action="store_true", help="force the generic power-of-two kernel")
+    return ap.parse_args()
+
+
+def load_traffic():
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/hbm_traffic.json), or None."""
+    path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f)
+    except Exception:
+        return None
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU fallback"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from spectrogram_rs_amd import SpectrogramEngine
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    F = args.frames
+    eng = SpectrogramEngine(48000.0, window_samples=W, hop_samples=H, channels=1, device=local_rank,
+                            force_generic=args.generic, interp=1, gradient="viridis")
+    n_samples = (F - 1) * H + W
+    # rank g owns frames [g*F, (g+1)*F) of one stream: samples from g*F*H, with the W-H halo
+    pcm = eng.white_noise(n_samples, first=rank * F * H)
+    mags = torch.empty((F, 1, M, 2), dtype=torch.float32, device=eng.device)
+
+    for _ in range(args.warmup):
+        eng.stft_batch(pcm, out=mags)
+    torch.cuda.synchronize()
+    barrier()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for a, b in evs:
+        a.record()
+        eng.stft_batch(pcm, out=mags)
+        b.record()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = sum(a.elapsed_time(b) for a, b in evs) / max(len(evs), 1)
+    t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=eng.device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed, kernel_ms = float(t[0]), float(t[1])
+    checksum = eng.checksum(mags[:4096])
+
+    # ---- pixel path leg (config 3 / config 5 shape), not the headline value -----------------------
+    pixel = None
+    if args.pixel_frames > 0:
+        Fp = min(args.pixel_frames, F)
+        chunk = min(65_536, Fp)
+        rgba = torch.empty((Fp, 1, R, 4), dtype=torch.uint8, device=eng.device)
+        gather_bufs = None
+        if world > 1 and rank == 0:
+            gather_bufs = [torch.empty((chunk, 1, R, 4), dtype=torch.uint8, device=eng.device) for _ in range(world)]
+
+        def pixel_pass():
+            acc = 0
+            for c0 in range(0, Fp, chunk):
+                c1 = min(c0 + chunk, Fp)
+                eng.render_batch(pcm, first_frame=c0, max_frames=c1 - c0, out=rgba[c0:c1])
+                if world > 1:
+                    # the one exchange step of the path: pixel columns to rank 0 (RCCL over xGMI);
+                    # rank 0 consumes each gathered chunk (checksum) instead of materialising 4 KB * 1e8
+                    part = rgba[c0:c0 + chunk]
+                    if part.shape[0] < chunk:
+                        part = torch.nn.functional.pad(part, (0, 0, 0, 0, 0, 0, 0, chunk - part.shape[0]))
+                    dist.gather(part, gather_bufs if rank == 0 else None, dst=0)
+                    if rank == 0:
+                        acc += int(gather_bufs[-1][0, 0, 0, 0])
+            return acc
+
+        pixel_pass()
+        torch.cuda.synchronize()
+        barrier()
+        tp0 = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            pixel_pass()
+        torch.cuda.synchronize()
+        barrier()
+        tp = torch.tensor([time.perf_counter() - tp0], dtype=torch.float64, device=eng.device)
+        if world > 1:
+            dist.all_reduce(tp, op=dist.ReduceOp.MAX)
+        fps = world * Fp * reps / float(tp[0])
+        pixel = {
+            "workload": ("config 3: " if world == 1 else "config 5 shape: ") + f"{Fp} frames/GPU -> 1024 log rows (cosine), Viridis RGBA"
+                        + ("" if world == 1 else f", RCCL gather of {chunk}-column chunks to rank 0"),
+            "frames_per_s": fps,
+            "algorithmic_GBps": fps * ALGO_BYTES_PIXEL / 1e9,
+            "gathered": world > 1,
+        }
+
+    # ---- CPU baseline: the oracle on this host's cores (rank 0, N = 1 only) ------------------------
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu_frames > 0:
+        import numpy as np
+
+        import oracle
+
+        cores = min(os.cpu_count() or 1, 16)
+        Fc = args.cpu_frames
+        host = oracle.white_noise((Fc - 1) * H + W)
+        oracle.stream_process(host[:W + 64 * H], 1, W, H, threads=cores)  # plan + page-in
+        c0 = time.perf_counter()
+        ref = oracle.stream_process(host, 1, W, H, threads=cores)
+        cdt = time.perf_counter() - c0
+        got = mags[:64, 0].cpu().numpy() if rank == 0 else None
+        peak = np.abs(ref[:64, 0]).max(axis=(1, 2), keepdims=True)
+        ok = bool((np.abs(got - ref[:64, 0]) <= 2e-5 * np.maximum(np.abs(ref[:64, 0]), 0.05 * peak)).all())
+        cpu = {
+            "value": Fc / cdt, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"first {Fc} frames of the same white-noise stream, float32 oracle (oracle/spectro_oracle.c), {cores} threads",
+            "parity_on_sample": ok,
+        }
+
+    if rank == 0:
+        total_frames = world * F * args.steps
+        value = total_frames / elapsed
+        achieved = F * ALGO_BYTES_STFT / (kernel_ms * 1e-3) / 1e9
+        traffic = load_traffic()
+        line = {
+            "metric": "STFT frames/sec (4096-pt, hop 256)",
+            "value": value,
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"configs[1]: batched 4096-pt Hann STFT, hop 256, {F} frames/GPU of counter-based white-noise mono PCM resident in HBM",
+                "window": W, "fft_length": 2 * W, "hop": H, "channels": 1, "frames_per_gpu": F,
+                "kernel": "stft4096 wave-per-transform" if eng.info.stft_kernel == 1 else "generic pow2",
+                "sharding": "contiguous frame ranges per rank, no data-path collective" if world > 1 else "single GPU",
+            },
+            "achieved_GBps_algorithmic": value * ALGO_BYTES_STFT / 1e9,
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": (traffic or {}).get("stft_bytes_per_launch"),
+                "kernel": "stft4096_kernel<mono>" if eng.info.stft_kernel == 1 else "stft_generic_kernel",
+                "launch_ms": kernel_ms, "bytes_per_frame": ALGO_BYTES_STFT, "frames_per_launch": F,
+            },
+            "cpu_baseline": cpu,
+            "pixel_path": pixel,
+            "checksum_first_4096_frames": checksum,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -21,6 +21,7 @@ SGX_ERR_NO_DEVICE = -5
 INTERP_CUBIC, INTERP_COSINE = 0, 1
 LUT_FLOOR_N, LUT_ROUND_NM1 = 0, 1
 FLAG_FORCE_GENERIC = 1
+FLAG_WAVE_KERNEL = 2
 
 
 class SgxError(RuntimeError):

@@ -91,6 +91,7 @@ int ensure_workspace(sgx_ctx *c, size_t frames)
 hipError_t run_stft(const sgx_ctx *c, const float *d_pcm, uint32_t channels, uint32_t pairs, size_t first, size_t n,
                     float *d_mags)
 {
+    if (c->stft_kernel == 2) return sgx::launch_stft_wg4096(c, c->d_fast_wg, d_pcm, channels, pairs, first, n, d_mags);
     if (c->stft_kernel == 1) return sgx::launch_stft_fast4096(c, d_pcm, channels, pairs, first, n, d_mags);
     return sgx::launch_stft_generic(c, d_pcm, channels, pairs, first, n, d_mags);
 }
@@ -202,7 +203,9 @@ int sgx_create(const sgx_config *cfg, sgx_ctx **out_ctx)
     if (!(cfg->flags & SGX_FLAG_FORCE_GENERIC) && sgx::fast4096_supported(c)) {
         e = sgx::fast4096_init(c);
         if (e != hipSuccess) return bail(SGX_ERR_HIP, std::string("sgx_create: tuned kernel tables: ") + hipGetErrorString(e));
-        c->stft_kernel = 1;
+        e = sgx::wg4096_init(c, &c->d_fast_wg);
+        if (e != hipSuccess) return bail(SGX_ERR_HIP, std::string("sgx_create: tuned kernel tables: ") + hipGetErrorString(e));
+        c->stft_kernel = (cfg->flags & SGX_FLAG_WAVE_KERNEL) ? 1 : 2;
     }
     *out_ctx = c;
     return SGX_OK;
@@ -213,6 +216,8 @@ void sgx_destroy(sgx_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     sgx::fast4096_destroy(c);
+    sgx::wg4096_destroy(c->d_fast_wg);
+    c->d_fast_wg = nullptr;
     void *ptrs[] = {c->d_window, c->d_twiddle, c->d_rows, c->d_samples, c->d_lut_thr, c->d_alpha_thr,
                     c->d_lut_rgba, c->d_ws_mags, c->d_one_in, c->d_one_out, c->d_cksum};
     for (void *p : ptrs)

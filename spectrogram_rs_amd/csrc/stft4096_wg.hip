@@ -1,0 +1,299 @@
+// stft4096_wg.hip -- tuned STFT for W = 2048 (P = 4096): one 256-thread workgroup per transform,
+// 16 points per thread, three radix-16 passes.
+//
+// Why this shape (measured on MI355X, tools/microbench.hip): a single wave per SIMD issues one
+// VALU instruction every ~7 cycles, four waves per SIMD one every ~2.  64 points per lane (the
+// wave-per-transform kernel in stft4096.hip) needs > 128 VGPRs and so caps at 2 waves per SIMD;
+// 16 points per thread fits 4 waves per SIMD and keeps 16 waves per CU in flight to cover LDS,
+// barrier and memory latency.
+//
+// Replaces FastFourierTransform::process (fft.rs:43-99) + the hop loop (audio_transform.rs:34-42).
+//
+//   sample index  n = t + 256 a           (t = thread, a < 8 non-zero rows: padding never touched)
+//   pass 1  thread t        : 16-point DFT over a (8 non-zero inputs = two 8-point FFTs), -> q1
+//                             twiddle w_4096^{t q1}            (15 per-thread constants in VGPRs)
+//   pass 2  thread (q1, t0) : t = t0 + 16 t1; 16-point FFT over t1 -> q2; twiddle w_256^{t0 q2} (LDS)
+//   pass 3  thread q1+16 q2 : 16-point FFT over t0 -> q3;  bin k = q1 + 16 q2 + 256 q3
+//   split   F[k] and F[P-k] -> |L^[k]|, |R^[k]| (fft.rs:81-89): the partner of thread u is thread
+//           (256 - u) % 256, exchanged through LDS (upper 8 registers only; k = 1..2047 is kept)
+//
+// Mono streams (a mono sample is duplicated into (s, s): audio_input_list_model.rs:67-69) pack
+// TWO consecutive frames into one transform: frame 2j in the real part, frame 2j+1 in the
+// imaginary part; the same split that separates left from right separates the two frames.
+#include "sgx_internal.hpp"
+
+namespace sgx {
+
+namespace wg {
+
+typedef float f2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float cl_fma(float a, float c, float u) { return fmaf(a, c, u); }
+__device__ __forceinline__ f2v cl_fma(f2v a, float c, f2v u) { return __builtin_elementwise_fma(a, f2v{c, c}, u); }
+
+#include "fft_codelets.inc"
+
+constexpr int kW = 2048, kP = 4096, kM = 2047;
+constexpr int kS1 = 272;            // row stride (complex) of the pass-1 -> pass-2 image [q1][t]
+constexpr int kS2 = 257;            // row stride (complex) of the pass-2 -> pass-3 image [t0][q1 + 16 q2]
+constexpr int kBufComplex = 16 * kS1;  // 4352 complex = 34 816 B (also holds 16*257 and 9*256)
+constexpr size_t kLdsBytes = (size_t)(kBufComplex + 256) * sizeof(float2);
+
+struct Params {
+    const float *pcm;
+    const float2 *tw1;   // [16][256]  w_4096^{t q1}
+    const float2 *tw2;   // [16][16]   w_256^{t0 q2} at [q2][t0]
+    const float *window; // [2048]
+    float *mags;
+    unsigned long long first_frame, n_frames, n_jobs, jobs_per_block;
+    uint32_t H, C, pair_l, pair_r, pairs, pair;
+};
+
+__device__ __forceinline__ void lds_barrier()
+{
+    // LDS-only workgroup barrier: outstanding global stores are NOT waited for
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+__device__ __forceinline__ float2 cmulf(float2 a, float2 b)
+{
+    return make_float2(fmaf(a.x, b.x, -(a.y * b.y)), fmaf(a.x, b.y, a.y * b.x));
+}
+
+template <bool MONO, bool HOP256>
+__global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2 *buf = reinterpret_cast<float2 *>(smem_raw);
+    float2 *tw2 = buf + kBufComplex;
+
+    const int tid = threadIdx.x;
+    tw2[tid] = p.tw2[tid];
+
+    // per-thread constants, kept in registers for the life of the (persistent) workgroup
+    float win[8];
+#pragma unroll
+    for (int a = 0; a < 8; ++a) win[a] = p.window[tid + 256 * a];
+    float2 tw1[16];
+#pragma unroll
+    for (int q = 1; q < 16; ++q) tw1[q] = p.tw1[q * 256 + tid];
+
+    const int q1_2 = tid >> 4, t0_2 = tid & 15;                 // pass-2 role
+    const int pbase = tid == 0 ? 256 : 256 - tid;               // partner slot (thread 0 is its own partner, one row up)
+    const float inv_w = 1.0f / (float)kW;                       // (hypot / 2) * (2 / W)
+    __syncthreads();
+
+    const unsigned long long job_begin = (unsigned long long)blockIdx.x * p.jobs_per_block;
+    unsigned long long job_end = job_begin + p.jobs_per_block;
+    if (job_end > p.n_jobs) job_end = p.n_jobs;
+
+    for (unsigned long long job = job_begin; job < job_end; ++job) {
+        // ---- load + Hann (fft.rs:53-63)
+        float er[8], ei[8];
+        unsigned long long f0;
+        bool have_second = true;
+        if (MONO) {
+            f0 = 2 * job;
+            have_second = f0 + 1 < p.n_frames;
+            const float *s0 = p.pcm + (p.first_frame + f0) * p.H;
+            if (HOP256) {
+                // H = 256 = one row: frame f0+1 row a is frame f0 row a+1
+                float s[9];
+#pragma unroll
+                for (int a = 0; a < 8; ++a) s[a] = s0[tid + 256 * a];
+                s[8] = have_second ? s0[tid + 256 * 8] : 0.0f;
+#pragma unroll
+                for (int a = 0; a < 8; ++a) { er[a] = s[a] * win[a]; ei[a] = have_second ? s[a + 1] * win[a] : 0.0f; }
+            } else {
+                const float *s1 = s0 + (have_second ? p.H : 0);
+#pragma unroll
+                for (int a = 0; a < 8; ++a) {
+                    er[a] = s0[tid + 256 * a] * win[a];
+                    ei[a] = have_second ? s1[tid + 256 * a] * win[a] : 0.0f;
+                }
+            }
+        } else {
+            f0 = job;
+            const float *s0 = p.pcm + (p.first_frame + f0) * p.H * p.C;
+#pragma unroll
+            for (int a = 0; a < 8; ++a) {
+                const size_t e = (size_t)(tid + 256 * a) * p.C;
+                er[a] = s0[e + p.pair_l] * win[a];
+                ei[a] = s0[e + p.pair_r] * win[a];
+            }
+        }
+
+        // ---- pass 1: 16-point DFT over a, inputs a >= 8 are the zero padding:
+        //      even q1 = FFT8(z), odd q1 = FFT8(z * w_16^a)
+        float orr[8], oi[8];
+#pragma unroll
+        for (int a = 0; a < 8; ++a) { orr[a] = er[a]; oi[a] = ei[a]; }
+        pretwiddle8_w16(orr, oi);
+        fft8(er, ei);
+        fft8(orr, oi);
+
+        lds_barrier();  // the previous transform's partner reads are complete
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int pos = FFT8_OUT[j];
+            const float2 ve = make_float2(er[pos], ei[pos]);
+            const float2 vo = make_float2(orr[pos], oi[pos]);
+            buf[(2 * j) * kS1 + tid] = j == 0 ? ve : cmulf(ve, tw1[2 * j]);
+            buf[(2 * j + 1) * kS1 + tid] = cmulf(vo, tw1[2 * j + 1]);
+        }
+        lds_barrier();
+
+        // ---- pass 2: thread (q1, t0): 16-point FFT over t1, then twiddle w_256^{t0 q2}
+        float xr[16], xi[16];
+#pragma unroll
+        for (int t1 = 0; t1 < 16; ++t1) {
+            const float2 v = buf[q1_2 * kS1 + t0_2 + 16 * t1];
+            xr[t1] = v.x; xi[t1] = v.y;
+        }
+        fft16(xr, xi);
+        lds_barrier();  // everyone has read image 1
+#pragma unroll
+        for (int q2 = 0; q2 < 16; ++q2) {
+            const int pos = FFT16_OUT[q2];
+            const float2 v = make_float2(xr[pos], xi[pos]);
+            buf[t0_2 * kS2 + q1_2 + 16 * q2] = q2 == 0 ? v : cmulf(v, tw2[q2 * 16 + t0_2]);
+        }
+        lds_barrier();
+
+        // ---- pass 3: thread u = q1 + 16 q2: 16-point FFT over t0 -> bins k = u + 256 q3
+#pragma unroll
+        for (int t0 = 0; t0 < 16; ++t0) {
+            const float2 v = buf[t0 * kS2 + tid];
+            xr[t0] = v.x; xi[t0] = v.y;
+        }
+        fft16(xr, xi);
+        lds_barrier();  // everyone has read image 2
+        // partner exchange: publish q3 = 8..15 (the bins P-k of the kept half)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int pos = FFT16_OUT[8 + j];
+            buf[j * 256 + tid] = make_float2(xr[pos], xi[pos]);
+        }
+        lds_barrier();
+
+        // ---- split + magnitude + store (fft.rs:81-98)
+        float *row0 = p.mags + ((f0 * p.pairs + p.pair) * (size_t)kM) * 2;
+        float *row1 = MONO ? row0 + (size_t)p.pairs * kM * 2 : row0;
+#pragma unroll
+        for (int q3 = 0; q3 < 8; ++q3) {
+            const int pos = FFT16_OUT[q3];
+            // F[P-k]: thread 256-u holds it as q3' = 15 - q3 (row 7 - q3); thread 0 as q3' = 16 - q3
+            const float2 b = buf[(7 - q3) * 256 + pbase];
+            const float ar = xr[pos], ai = xi[pos];
+            const float pr = ar + b.x, pi = ai - b.y;   // a + conj(b) = 2 L^
+            const float qr = ar - b.x, qi = ai + b.y;   // a - conj(b) = 2i R^
+            const float left = __builtin_amdgcn_sqrtf(fmaf(pr, pr, pi * pi)) * inv_w;
+            const float right = __builtin_amdgcn_sqrtf(fmaf(qr, qr, qi * qi)) * inv_w;
+            const int k = tid + 256 * q3;
+            if (k >= 1) {
+                if (MONO) {
+                    reinterpret_cast<float2 *>(row0)[k - 1] = make_float2(left, left);
+                    if (have_second) reinterpret_cast<float2 *>(row1)[k - 1] = make_float2(right, right);
+                } else {
+                    reinterpret_cast<float2 *>(row0)[k - 1] = make_float2(left, right);
+                }
+            }
+        }
+    }
+}
+
+struct WgTables {
+    float2 *d_tw1 = nullptr;
+    float2 *d_tw2 = nullptr;
+};
+
+}  // namespace wg
+
+hipError_t wg4096_init(sgx_ctx *c, void **out)
+{
+    using namespace wg;
+    auto *t = new WgTables();
+    std::vector<float2> tw1(16 * 256), tw2(256);
+    auto unit = [](int idx, int N) {
+        idx %= N;
+        const double ang = -2.0 * M_PI * (double)idx / (double)N;
+        double cs = cos(ang), sn = sin(ang);
+        if (idx == 0) { cs = 1.0; sn = 0.0; }
+        if (4 * idx == N) { cs = 0.0; sn = -1.0; }
+        if (2 * idx == N) { cs = -1.0; sn = 0.0; }
+        if (4 * idx == 3 * N) { cs = 0.0; sn = 1.0; }
+        return make_float2((float)cs, (float)sn);
+    };
+    for (int q = 0; q < 16; ++q)
+        for (int t = 0; t < 256; ++t) tw1[q * 256 + t] = unit(t * q, kP);
+    for (int q = 0; q < 16; ++q)
+        for (int t0 = 0; t0 < 16; ++t0) tw2[q * 16 + t0] = unit(t0 * q, 256);
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&t->d_tw1), tw1.size() * sizeof(float2));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&t->d_tw2), tw2.size() * sizeof(float2));
+    if (e == hipSuccess) e = hipMemcpy(t->d_tw1, tw1.data(), tw1.size() * sizeof(float2), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(t->d_tw2, tw2.data(), tw2.size() * sizeof(float2), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        if (t->d_tw1) (void)hipFree(t->d_tw1);
+        if (t->d_tw2) (void)hipFree(t->d_tw2);
+        delete t;
+        return e;
+    }
+    (void)c;
+    *out = t;
+    return hipSuccess;
+}
+
+void wg4096_destroy(void *tables)
+{
+    auto *t = static_cast<wg::WgTables *>(tables);
+    if (!t) return;
+    if (t->d_tw1) (void)hipFree(t->d_tw1);
+    if (t->d_tw2) (void)hipFree(t->d_tw2);
+    delete t;
+}
+
+hipError_t launch_stft_wg4096(const sgx_ctx *c, const void *tables, const float *d_pcm, uint32_t channels, uint32_t pairs,
+                              size_t first_frame, size_t n_frames, float *d_mags)
+{
+    using namespace wg;
+    if (n_frames == 0) return hipSuccess;
+    const auto *t = static_cast<const WgTables *>(tables);
+    int n_cu = 256;
+    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device);
+    for (uint32_t pair = 0; pair < pairs; ++pair) {
+        Params p;
+        p.pcm = d_pcm;
+        p.tw1 = t->d_tw1;
+        p.tw2 = t->d_tw2;
+        p.window = c->d_window;
+        p.mags = d_mags;
+        p.first_frame = first_frame;
+        p.n_frames = n_frames;
+        p.H = c->H;
+        p.C = channels;
+        p.pairs = pairs;
+        p.pair = pair;
+        p.pair_l = channels == 1 ? 0 : 2 * pair;
+        p.pair_r = channels == 1 ? 0 : 2 * pair + 1;
+        const bool mono = channels == 1;
+        p.n_jobs = mono ? (n_frames + 1) / 2 : n_frames;
+        // persistent workgroups, 4 per CU; each owns a contiguous run of transforms so that the
+        // overlapping audio of consecutive frames is re-read from L1/L2, not HBM
+        unsigned long long blocks = (unsigned long long)n_cu * 4;
+        unsigned long long per = (p.n_jobs + blocks - 1) / blocks;
+        if (per < 1) per = 1;
+        blocks = (p.n_jobs + per - 1) / per;
+        p.jobs_per_block = per;
+        const dim3 grid((unsigned)blocks), block(256);
+        if (mono) {
+            if (c->H == 256) hipLaunchKernelGGL((stft4096_wg_kernel<true, true>), grid, block, kLdsBytes, c->stream, p);
+            else hipLaunchKernelGGL((stft4096_wg_kernel<true, false>), grid, block, kLdsBytes, c->stream, p);
+        } else {
+            hipLaunchKernelGGL((stft4096_wg_kernel<false, false>), grid, block, kLdsBytes, c->stream, p);
+        }
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+}  // namespace sgx

@@ -187,13 +187,14 @@ def main():
              "// 2-wide float vector (two independent transforms in the halves of packed registers).\n"
              "// cl_fma(a, c, u) = a * c + u with a scalar constant c.\n"]
     total = {}
-    for name, N, radices in (("fft32", 32, [4, 4, 2]), ("fft64", 64, [4, 4, 4])):
+    for name, N, radices in (("fft8", 8, [4, 2]), ("fft16", 16, [4, 4]), ("fft32", 32, [4, 4, 2]), ("fft64", 64, [4, 4, 4])):
         src, ops, _ = gen_fft(name, N, radices)
         parts.append(src + "\n")
         total[name] = ops
-    src, ops = gen_pretwiddle("pretwiddle32_w64", 32, 64)
-    parts.append(src + "\n")
-    total["pretwiddle32_w64"] = ops
+    for name, n, N in (("pretwiddle32_w64", 32, 64), ("pretwiddle8_w16", 8, 16)):
+        src, ops = gen_pretwiddle(name, n, N)
+        parts.append(src + "\n")
+        total[name] = ops
     path = os.path.join(ROOT, "spectrogram_rs_amd", "csrc", "fft_codelets.inc")
     with open(path, "w") as f:
         f.write("\n".join(parts))
