@@ -59,7 +59,7 @@ __device__ __forceinline__ float2 cmulf(float2 a, float2 b)
     return make_float2(fmaf(a.x, b.x, -(a.y * b.y)), fmaf(a.x, b.y, a.y * b.x));
 }
 
-template <bool MONO, bool HOP256>
+template <bool MONO, bool HOP256, bool C2>
 __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -86,40 +86,54 @@ __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
     unsigned long long job_end = job_begin + p.jobs_per_block;
     if (job_end > p.n_jobs) job_end = p.n_jobs;
 
-    for (unsigned long long job = job_begin; job < job_end; ++job) {
-        // ---- load + Hann (fft.rs:53-63)
-        float er[8], ei[8];
-        unsigned long long f0;
-        bool have_second = true;
+    // Software pipeline: the samples of transform j+1 are requested while transform j is still in
+    // its FFT passes, i.e. BEFORE j's magnitude stores.  vmcnt retires in issue order, so a load
+    // issued after 16-32 stores would have to wait for all of them to reach memory first.
+    float sa[MONO ? 9 : 8], sb[8];
+    auto fetch = [&](unsigned long long job) {
         if (MONO) {
-            f0 = 2 * job;
-            have_second = f0 + 1 < p.n_frames;
-            const float *s0 = p.pcm + (p.first_frame + f0) * p.H;
+            const unsigned long long f = 2 * job;
+            const bool second = f + 1 < p.n_frames;
+            const float *s0 = p.pcm + (p.first_frame + f) * p.H;
             if (HOP256) {
-                // H = 256 = one row: frame f0+1 row a is frame f0 row a+1
-                float s[9];
+                // H = 256 = one row: frame f+1 row a is frame f row a+1
 #pragma unroll
-                for (int a = 0; a < 8; ++a) s[a] = s0[tid + 256 * a];
-                s[8] = have_second ? s0[tid + 256 * 8] : 0.0f;
-#pragma unroll
-                for (int a = 0; a < 8; ++a) { er[a] = s[a] * win[a]; ei[a] = have_second ? s[a + 1] * win[a] : 0.0f; }
+                for (int a = 0; a < 8; ++a) sa[a] = s0[tid + 256 * a];
+                sa[8] = second ? s0[tid + 256 * 8] : 0.0f;
             } else {
-                const float *s1 = s0 + (have_second ? p.H : 0);
+                const float *s1 = s0 + (second ? p.H : 0);
 #pragma unroll
-                for (int a = 0; a < 8; ++a) {
-                    er[a] = s0[tid + 256 * a] * win[a];
-                    ei[a] = have_second ? s1[tid + 256 * a] * win[a] : 0.0f;
-                }
+                for (int a = 0; a < 8; ++a) { sa[a] = s0[tid + 256 * a]; sb[a] = s1[tid + 256 * a]; }
             }
         } else {
-            f0 = job;
-            const float *s0 = p.pcm + (p.first_frame + f0) * p.H * p.C;
+            const float *s0 = p.pcm + (p.first_frame + job) * p.H * p.C;
+            if (C2) {
 #pragma unroll
-            for (int a = 0; a < 8; ++a) {
-                const size_t e = (size_t)(tid + 256 * a) * p.C;
-                er[a] = s0[e + p.pair_l] * win[a];
-                ei[a] = s0[e + p.pair_r] * win[a];
+                for (int a = 0; a < 8; ++a) {
+                    const float2 v = reinterpret_cast<const float2 *>(s0)[tid + 256 * a];
+                    sa[a] = v.x; sb[a] = v.y;
+                }
+            } else {
+#pragma unroll
+                for (int a = 0; a < 8; ++a) {
+                    const size_t e = (size_t)(tid + 256 * a) * p.C;
+                    sa[a] = s0[e + p.pair_l]; sb[a] = s0[e + p.pair_r];
+                }
             }
+        }
+    };
+    if (job_begin < job_end) fetch(job_begin);
+
+    for (unsigned long long job = job_begin; job < job_end; ++job) {
+        // ---- Hann (fft.rs:53-63) on the prefetched samples
+        float er[8], ei[8];
+        const unsigned long long f0 = MONO ? 2 * job : job;
+        const bool have_second = !MONO || f0 + 1 < p.n_frames;
+#pragma unroll
+        for (int a = 0; a < 8; ++a) {
+            er[a] = sa[a] * win[a];
+            if (MONO && HOP256) ei[a] = have_second ? sa[a + 1] * win[a] : 0.0f;
+            else ei[a] = have_second ? sb[a] * win[a] : 0.0f;
         }
 
         // ---- pass 1: 16-point DFT over a, inputs a >= 8 are the zero padding:
@@ -166,6 +180,7 @@ __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
             xr[t0] = v.x; xi[t0] = v.y;
         }
         fft16(xr, xi);
+        if (job + 1 < job_end) fetch(job + 1);  // ahead of this transform's stores (see above)
         lds_barrier();  // everyone has read image 2
         // partner exchange: publish q3 = 8..15 (the bins P-k of the kept half)
 #pragma unroll
@@ -285,10 +300,12 @@ hipError_t launch_stft_wg4096(const sgx_ctx *c, const void *tables, const float 
         p.jobs_per_block = per;
         const dim3 grid((unsigned)blocks), block(256);
         if (mono) {
-            if (c->H == 256) hipLaunchKernelGGL((stft4096_wg_kernel<true, true>), grid, block, kLdsBytes, c->stream, p);
-            else hipLaunchKernelGGL((stft4096_wg_kernel<true, false>), grid, block, kLdsBytes, c->stream, p);
+            if (c->H == 256) hipLaunchKernelGGL((stft4096_wg_kernel<true, true, false>), grid, block, kLdsBytes, c->stream, p);
+            else hipLaunchKernelGGL((stft4096_wg_kernel<true, false, false>), grid, block, kLdsBytes, c->stream, p);
+        } else if (channels == 2) {
+            hipLaunchKernelGGL((stft4096_wg_kernel<false, false, true>), grid, block, kLdsBytes, c->stream, p);
         } else {
-            hipLaunchKernelGGL((stft4096_wg_kernel<false, false>), grid, block, kLdsBytes, c->stream, p);
+            hipLaunchKernelGGL((stft4096_wg_kernel<false, false, false>), grid, block, kLdsBytes, c->stream, p);
         }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
