@@ -34,6 +34,12 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
 W, H, M, R = 2048, 256, 2047, 1024
 ALGO_BYTES_STFT = H * 1 * 4 + M * 2 * 4  # 17 400 B / frame: each input sample once, each output byte once
 ALGO_BYTES_PIXEL = H * 1 * 4 + R * 4     # 5 120 B / frame
+KERNEL_NAMES = {
+    0: ("generic power-of-two (workgroup per frame, LDS radix-2)", "sgx::stft_generic_kernel"),
+    1: ("stft4096 wave-per-transform", "sgx::stft4096_kernel<6, true>"),
+    2: ("stft4096 workgroup-per-transform (256 threads x 16 points, radix-16 x3, mono frame pairs)",
+        "sgx::wg::stft4096_wg_kernel<true, true, false>"),
+}
 
 
 def parse():
@@ -77,6 +83,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from spectrogram_rs_amd import SpectrogramEngine
+    from spectrogram_rs_amd.sharding import chunks, frame_range, gather_columns, sample_range
 
     def barrier():
         if world > 1:
@@ -85,9 +92,12 @@ def main():
     F = args.frames
     eng = SpectrogramEngine(48000.0, window_samples=W, hop_samples=H, channels=1, device=local_rank,
                             force_generic=args.generic, interp=1, gradient="viridis")
-    n_samples = (F - 1) * H + W
-    # rank g owns frames [g*F, (g+1)*F) of one stream: samples from g*F*H, with the W-H halo
-    pcm = eng.white_noise(n_samples, first=rank * F * H)
+    # weak scaling: one stream of world*F frames; rank g owns the contiguous range frame_range(g)
+    # and generates exactly its samples (with the W-H halo) -- no input exchange
+    first_frame, n_own = frame_range(rank, world, world * F)
+    assert n_own == F
+    first_sample, n_samples = sample_range(first_frame, F, W, H)
+    pcm = eng.white_noise(n_samples, first=first_sample)
     mags = torch.empty((F, 1, M, 2), dtype=torch.float32, device=eng.device)
 
     for _ in range(args.warmup):
@@ -117,25 +127,21 @@ def main():
         Fp = min(args.pixel_frames, F)
         chunk = min(65_536, Fp)
         rgba = torch.empty((Fp, 1, R, 4), dtype=torch.uint8, device=eng.device)
-        gather_bufs = None
-        if world > 1 and rank == 0:
-            gather_bufs = [torch.empty((chunk, 1, R, 4), dtype=torch.uint8, device=eng.device) for _ in range(world)]
+        counts = [Fp] * world
+        root_seen = [0]
+
+        def consume(first_col, piece):
+            # rank 0 consumes every gathered piece (here: touches it) instead of materialising the
+            # whole image -- 1e8 columns would be 410 GB, more than one GPU's HBM
+            root_seen[0] += int(piece.shape[0])
 
         def pixel_pass():
-            acc = 0
-            for c0 in range(0, Fp, chunk):
-                c1 = min(c0 + chunk, Fp)
-                eng.render_batch(pcm, first_frame=c0, max_frames=c1 - c0, out=rgba[c0:c1])
-                if world > 1:
-                    # the one exchange step of the path: pixel columns to rank 0 (RCCL over xGMI);
-                    # rank 0 consumes each gathered chunk (checksum) instead of materialising 4 KB * 1e8
-                    part = rgba[c0:c0 + chunk]
-                    if part.shape[0] < chunk:
-                        part = torch.nn.functional.pad(part, (0, 0, 0, 0, 0, 0, 0, chunk - part.shape[0]))
-                    dist.gather(part, gather_bufs if rank == 0 else None, dst=0)
-                    if rank == 0:
-                        acc += int(gather_bufs[-1][0, 0, 0, 0])
-            return acc
+            for c0, cn in chunks(Fp, chunk):
+                eng.render_batch(pcm, first_frame=c0, max_frames=cn, out=rgba[c0:c0 + cn])
+            if world > 1:
+                # the one exchange step of the path: finished pixel columns to rank 0 (RCCL over xGMI),
+                # world-1 point-to-point flows, chunked
+                gather_columns(rgba[:, 0], counts, dst=0, chunk=chunk, consume=consume)
 
         pixel_pass()
         torch.cuda.synchronize()
@@ -202,7 +208,7 @@ def main():
             "config": {
                 "workload": f"configs[1]: batched 4096-pt Hann STFT, hop 256, {F} frames/GPU of counter-based white-noise mono PCM resident in HBM",
                 "window": W, "fft_length": 2 * W, "hop": H, "channels": 1, "frames_per_gpu": F,
-                "kernel": "stft4096 wave-per-transform" if eng.info.stft_kernel == 1 else "generic pow2",
+                "kernel": KERNEL_NAMES[eng.info.stft_kernel][0],
                 "sharding": "contiguous frame ranges per rank, no data-path collective" if world > 1 else "single GPU",
             },
             "achieved_GBps_algorithmic": value * ALGO_BYTES_STFT / 1e9,
@@ -210,7 +216,7 @@ def main():
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": (traffic or {}).get("stft_bytes_per_launch"),
-                "kernel": "stft4096_kernel<mono>" if eng.info.stft_kernel == 1 else "stft_generic_kernel",
+                "kernel": KERNEL_NAMES[eng.info.stft_kernel][1],
                 "launch_ms": kernel_ms, "bytes_per_frame": ALGO_BYTES_STFT, "frames_per_launch": F,
             },
             "cpu_baseline": cpu,

@@ -1,0 +1,36 @@
+// Source of the binding shown in INTEGRATION.md (not compiled in this image: no Rust toolchain).
+// src/fourier/sgx_sys.rs
+use std::os::raw::{c_char, c_int, c_void};
+
+#[repr(C)]
+pub struct SgxConfig {
+    pub struct_size: u32,
+    pub sample_rate: f32, pub period: f32, pub stride: f32,
+    pub window_samples: u32, pub hop_samples: u32, pub channels: u32, pub rows: u32,
+    pub f_min: f64, pub f_max: f64,
+    pub min_db: f32, pub max_db: f32,
+    pub interp: u32, pub lut_index_mode: u32,
+    pub device: i32, pub flags: u32,
+}
+#[repr(C)] pub struct SgxCtx { _private: [u8; 0] }
+
+extern "C" {
+    pub fn sgx_config_init(cfg: *mut SgxConfig) -> c_int;
+    pub fn sgx_create(cfg: *const SgxConfig, out: *mut *mut SgxCtx) -> c_int;
+    pub fn sgx_destroy(ctx: *mut SgxCtx);
+    pub fn sgx_last_error(ctx: *const SgxCtx) -> *const c_char;
+    pub fn sgx_num_frames(ctx: *const SgxCtx, n_samples: usize) -> usize;
+    pub fn sgx_process_one(ctx: *mut SgxCtx, h_lr: *const f32, n_avail: usize, h_out: *mut f32) -> c_int;
+    pub fn sgx_stft_batch(ctx: *mut SgxCtx, d_pcm: *const f32, n_samples: usize, first_frame: usize,
+                          max_frames: usize, d_mags: *mut f32, n_out: *mut usize) -> c_int;
+    pub fn sgx_render_batch(ctx: *mut SgxCtx, d_pcm: *const f32, n_samples: usize, first_frame: usize,
+                            max_frames: usize, d_rgba: *mut u8, n_out: *mut usize) -> c_int;
+    pub fn sgx_set_gradient(ctx: *mut SgxCtx, h_rgb: *const u8, n: u32, stereo: c_int) -> c_int;
+    pub fn sgx_lookup_table(ctx: *mut SgxCtx, resolution: u32, h_out: *mut f32) -> c_int;
+    pub fn sgx_sync(ctx: *mut SgxCtx) -> c_int;
+}
+extern "C" {   // from libamdhip64, for staging buffers
+    pub fn hipMalloc(p: *mut *mut c_void, bytes: usize) -> c_int;
+    pub fn hipFree(p: *mut c_void) -> c_int;
+    pub fn hipMemcpy(dst: *mut c_void, src: *const c_void, bytes: usize, kind: c_int) -> c_int;
+}

@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsgx.so")
+LIB_PATH = os.environ.get("SGX_LIB", os.path.join(_HERE, "libsgx.so"))  # SGX_LIB: A/B builds during kernel development
 
 SGX_OK = 0
 SGX_ERR_INVALID_ARG = -1

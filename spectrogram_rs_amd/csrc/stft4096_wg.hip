@@ -54,6 +54,16 @@ __device__ __forceinline__ void lds_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+__device__ __forceinline__ void store2(float *row, int j, float a, float b)
+{
+#ifdef SGX_NT_STORES
+    typedef float f2s __attribute__((ext_vector_type(2)));
+    __builtin_nontemporal_store(f2s{a, b}, reinterpret_cast<f2s *>(row) + j);
+#else
+    reinterpret_cast<float2 *>(row)[j] = make_float2(a, b);
+#endif
+}
+
 __device__ __forceinline__ float2 cmulf(float2 a, float2 b)
 {
     return make_float2(fmaf(a.x, b.x, -(a.y * b.y)), fmaf(a.x, b.y, a.y * b.x));
@@ -206,10 +216,10 @@ __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
             const int k = tid + 256 * q3;
             if (k >= 1) {
                 if (MONO) {
-                    reinterpret_cast<float2 *>(row0)[k - 1] = make_float2(left, left);
-                    if (have_second) reinterpret_cast<float2 *>(row1)[k - 1] = make_float2(right, right);
+                    store2(row0, k - 1, left, left);
+                    if (have_second) store2(row1, k - 1, right, right);
                 } else {
-                    reinterpret_cast<float2 *>(row0)[k - 1] = make_float2(left, right);
+                    store2(row0, k - 1, left, right);
                 }
             }
         }

@@ -1,0 +1,82 @@
+"""Frame sharding across the GPUs of a node, and the one exchange step of the path.
+
+The reference is a single-process desktop app (no collectives).  The hop loop
+(src/fourier/audio_transform.rs:34-42) makes frame t depend only on samples [t*H, t*H + W), so a
+long stream shards embarrassingly by contiguous frame ranges; neighbouring ranks share a halo of
+W - H samples of *input*, never any intermediate.  The only exchange is the gather of finished
+pixel columns (4 KB each) to the rank that owns the image.
+
+One process per GPU; `torch.distributed` with backend "nccl" (= RCCL over xGMI) on MI355X, "gloo"
+in the CPU tests.  Nothing here computes: it only says who owns what and moves finished bytes.
+"""
+from __future__ import annotations
+
+from typing import Callable, Iterator, List, Optional, Tuple
+
+
+def frame_range(rank: int, world: int, total_frames: int) -> Tuple[int, int]:
+    """Contiguous frame range [first, first + count) owned by `rank` (ranges differ by at most one)."""
+    base, extra = divmod(total_frames, world)
+    first = rank * base + min(rank, extra)
+    return first, base + (1 if rank < extra else 0)
+
+
+def sample_range(first_frame: int, n_frames: int, W: int, H: int) -> Tuple[int, int]:
+    """Samples (per channel) a rank must hold for its frames: [first*H, (first+n-1)*H + W) --
+    the W - H sample halo is shared with the next rank."""
+    if n_frames <= 0:
+        return first_frame * H, 0
+    return first_frame * H, (n_frames - 1) * H + W
+
+
+def chunks(n: int, chunk: int) -> Iterator[Tuple[int, int]]:
+    for c0 in range(0, n, chunk):
+        yield c0, min(chunk, n - c0)
+
+
+def gather_columns(local, counts: List[int], dst: int = 0, chunk: int = 65536,
+                   consume: Optional[Callable] = None, group=None):
+    """Gather pixel columns [n_local][...] from every rank to `dst`, in chunks of at most `chunk`
+    columns per rank so that the root never holds more than world * chunk columns at once (1e8
+    columns are 410 GB: more than one GPU's HBM).  `counts[r]` is rank r's column count (known from
+    frame_range).  On the root, `consume(global_first_column, tensor)` is called for every piece in
+    stream order per rank; without `consume` the pieces are concatenated and returned (small runs).
+
+    Traffic shape on MI355X: world - 1 independent point-to-point flows into the root, one per
+    xGMI link -- per-link bound, no ring, no reduction."""
+    import torch
+    import torch.distributed as dist
+
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    assert len(counts) == world and counts[rank] == local.shape[0]
+    starts = [sum(counts[:r]) for r in range(world)]
+    rounds = max((c + chunk - 1) // chunk for c in counts) if counts else 0
+    kept = [[] for _ in range(world)]
+    for i in range(rounds):
+        c0 = i * chunk
+        mine = local[c0:c0 + chunk]
+        if rank == dst:
+            for r in range(world):
+                n_r = max(min(chunk, counts[r] - c0), 0)
+                if n_r == 0:
+                    continue
+                if r == dst:
+                    piece = mine
+                else:
+                    piece = torch.empty((n_r,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+                    dist.recv(piece, src=r, group=group)
+                if consume is not None:
+                    consume(starts[r] + c0, piece)
+                else:
+                    kept[r].append(piece.clone() if r == dst else piece)
+        elif mine.shape[0] > 0:
+            dist.send(mine.contiguous(), dst=dst, group=group)
+    if rank == dst and consume is None:
+        flat = [p for r in range(world) for p in kept[r]]
+        return torch.cat(flat) if flat else local[:0]
+    return None
+
+
+def combine_checksums(parts: List[int]) -> int:
+    """sgx_checksum is a sum of per-word mixes with global word indices: shards add (mod 2^64)."""
+    return sum(parts) & ((1 << 64) - 1)
