@@ -82,6 +82,7 @@ typedef struct sgx_config {
 } sgx_config;
 
 #define SGX_FLAG_FORCE_GENERIC 1u /* use the generic power-of-two kernel even where a tuned one exists (testing) */
+#define SGX_FLAG_NO_FUSED_RENDER 4u /* sgx_render_batch: run STFT and pixel stage as two kernels even where the fused one applies (A/B) */
 #define SGX_FLAG_WAVE_KERNEL 2u   /* W = 2048: use the wave-per-transform kernel instead of the workgroup-per-transform one (A/B) */
 
 typedef struct sgx_info {

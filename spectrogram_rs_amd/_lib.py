@@ -22,6 +22,7 @@ INTERP_CUBIC, INTERP_COSINE = 0, 1
 LUT_FLOOR_N, LUT_ROUND_NM1 = 0, 1
 FLAG_FORCE_GENERIC = 1
 FLAG_WAVE_KERNEL = 2
+FLAG_NO_FUSED_RENDER = 4
 
 
 class SgxError(RuntimeError):

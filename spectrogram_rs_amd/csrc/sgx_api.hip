@@ -321,7 +321,14 @@ int sgx_render_batch(sgx_ctx *c, const float *d_pcm, size_t n_samples, size_t fi
     if (n > max_frames) n = max_frames;
     if (!d_pcm || !d_rgba) return fail(c, SGX_ERR_INVALID_ARG, "sgx_render_batch: null buffer");
     SGX_HIP(c, hipSetDevice(c->device));
-    // magnitudes stay in a bounded, reused workspace (L2 / Infinity-Cache sized chunks)
+    if (c->stft_kernel == 2 && !(c->cfg.flags & SGX_FLAG_NO_FUSED_RENDER) && sgx::wg4096_can_fuse_render(c, c->d_fast_wg)) {
+        // one kernel from PCM to pixels: magnitudes never leave LDS (5 120 B of HBM traffic per frame)
+        hipError_t e = sgx::launch_render_wg4096(c, c->d_fast_wg, d_pcm, c->C, c->pairs, first_frame, n, d_rgba);
+        if (e != hipSuccess) return fail_hip(c, e, "sgx_render_batch: fused launch");
+        if (n_out) *n_out = n;
+        return SGX_OK;
+    }
+    // two kernels; magnitudes stay in a bounded, reused workspace (L2 / Infinity-Cache sized chunks)
     const size_t bytes_per_frame = (size_t)c->pairs * c->M * 2 * sizeof(float);
     size_t chunk = (size_t)(192u << 20) / bytes_per_frame;
     if (chunk < 1) chunk = 1;

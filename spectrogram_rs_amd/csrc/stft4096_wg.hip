@@ -37,6 +37,12 @@ constexpr int kS1 = 272;            // row stride (complex) of the pass-1 -> pas
 constexpr int kS2 = 257;            // row stride (complex) of the pass-2 -> pass-3 image [t0][q1 + 16 q2]
 constexpr int kBufComplex = 16 * kS1;  // 4352 complex = 34 816 B (also holds 16*257 and 9*256)
 constexpr size_t kLdsBytes = (size_t)(kBufComplex + 256) * sizeof(float2);
+constexpr size_t kLdsBytesRender = kLdsBytes + 256 * sizeof(float) + 256 * sizeof(uchar4);
+
+struct PackedSample {
+    int32_t i0;   // cubic: floor(index); cosine: low
+    float w;      // cubic: mu;           cosine: o' (the cosine-eased offset)
+};
 
 struct Params {
     const float *pcm;
@@ -46,6 +52,14 @@ struct Params {
     float *mags;
     unsigned long long first_frame, n_frames, n_jobs, jobs_per_block;
     uint32_t H, C, pair_l, pair_r, pairs, pair;
+    // fused pixel path (RENDER): magnitudes never leave LDS
+    const uint32_t *rows;      // [R]  first | count << 16
+    const PackedSample *samples;
+    const float *lut_thr;      // [255]
+    const uchar4 *lut_rgba;    // [256]
+    uint8_t *rgba;             // [F][pairs][R][4]
+    uint32_t R, interp;
+    float guess_a, guess_b;    // LUT index ~ floor(log2(power + 1e-7) * a + b), then exact fix-up
 };
 
 __device__ __forceinline__ void lds_barrier()
@@ -69,15 +83,22 @@ __device__ __forceinline__ float2 cmulf(float2 a, float2 b)
     return make_float2(fmaf(a.x, b.x, -(a.y * b.y)), fmaf(a.x, b.y, a.y * b.x));
 }
 
-template <bool MONO, bool HOP256, bool C2>
+template <bool MONO, bool HOP256, bool C2, bool RENDER>
 __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float2 *buf = reinterpret_cast<float2 *>(smem_raw);
     float2 *tw2 = buf + kBufComplex;
 
+    float *thr = reinterpret_cast<float *>(tw2 + 256);          // RENDER only: [256] (255 used)
+    uchar4 *lut = reinterpret_cast<uchar4 *>(thr + 256);        // RENDER only: [256]
+
     const int tid = threadIdx.x;
     tw2[tid] = p.tw2[tid];
+    if (RENDER) {
+        thr[tid] = tid < 255 ? p.lut_thr[tid] : __builtin_nanf("");
+        lut[tid] = p.lut_rgba[tid];
+    }
 
     // per-thread constants, kept in registers for the life of the (persistent) workgroup
     float win[8];
@@ -200,9 +221,8 @@ __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
         }
         lds_barrier();
 
-        // ---- split + magnitude + store (fft.rs:81-98)
-        float *row0 = p.mags + ((f0 * p.pairs + p.pair) * (size_t)kM) * 2;
-        float *row1 = MONO ? row0 + (size_t)p.pairs * kM * 2 : row0;
+        // ---- split + magnitude (fft.rs:81-98)
+        float ml[8], mr[8];
 #pragma unroll
         for (int q3 = 0; q3 < 8; ++q3) {
             const int pos = FFT16_OUT[q3];
@@ -211,15 +231,111 @@ __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
             const float ar = xr[pos], ai = xi[pos];
             const float pr = ar + b.x, pi = ai - b.y;   // a + conj(b) = 2 L^
             const float qr = ar - b.x, qi = ai + b.y;   // a - conj(b) = 2i R^
-            const float left = __builtin_amdgcn_sqrtf(fmaf(pr, pr, pi * pi)) * inv_w;
-            const float right = __builtin_amdgcn_sqrtf(fmaf(qr, qr, qi * qi)) * inv_w;
-            const int k = tid + 256 * q3;
-            if (k >= 1) {
-                if (MONO) {
-                    store2(row0, k - 1, left, left);
-                    if (have_second) store2(row1, k - 1, right, right);
-                } else {
-                    store2(row0, k - 1, left, right);
+            ml[q3] = __builtin_amdgcn_sqrtf(fmaf(pr, pr, pi * pi)) * inv_w;
+            mr[q3] = __builtin_amdgcn_sqrtf(fmaf(qr, qr, qi * qi)) * inv_w;
+        }
+
+        if (!RENDER) {
+            // ---- store [F][pairs][M][2]
+            float *row0 = p.mags + ((f0 * p.pairs + p.pair) * (size_t)kM) * 2;
+            float *row1 = MONO ? row0 + (size_t)p.pairs * kM * 2 : row0;
+#pragma unroll
+            for (int q3 = 0; q3 < 8; ++q3) {
+                const int k = tid + 256 * q3;
+                if (k >= 1) {
+                    if (MONO) {
+                        store2(row0, k - 1, ml[q3], ml[q3]);
+                        if (have_second) store2(row1, k - 1, mr[q3], mr[q3]);
+                    } else {
+                        store2(row0, k - 1, ml[q3], mr[q3]);
+                    }
+                }
+            }
+        } else {
+            // ---- fused pixel column(s): magnitude_in -> color_for -> put_pixel
+            //      (simple_spectrogram.rs:141-161), magnitudes staged in LDS only
+            float *m0 = reinterpret_cast<float *>(buf);   // MONO: column of frame f0 ; else interleaved (l, r)
+            float *m1 = m0 + 2048;                        // MONO: column of frame f0 + 1
+            lds_barrier();  // partner reads done: the buffer can be overwritten
+#pragma unroll
+            for (int q3 = 0; q3 < 8; ++q3) {
+                const int k = tid + 256 * q3;
+                if (k >= 1) {
+                    if (MONO) { m0[k - 1] = ml[q3]; m1[k - 1] = mr[q3]; }
+                    else reinterpret_cast<float2 *>(m0)[k - 1] = make_float2(ml[q3], mr[q3]);
+                }
+            }
+            lds_barrier();
+            const int last = kM - 1;
+            const int n_cols = MONO ? (have_second ? 2 : 1) : 1;
+            for (int col = 0; col < n_cols; ++col) {
+                const float *mc = MONO ? (col ? m1 : m0) : m0;
+                uchar4 *dst = reinterpret_cast<uchar4 *>(p.rgba) + ((f0 + col) * p.pairs + p.pair) * (size_t)p.R;
+                for (uint32_t py = tid; py < p.R; py += 256) {
+                    const uint32_t re = p.rows[py];
+                    const uint32_t first = re & 0xffffu, cnt = re >> 16;
+                    float sl = 0.0f, sr = 0.0f;  // Complex::sum starts at zero
+                    for (uint32_t i = 0; i < cnt; ++i) {
+                        const PackedSample se = p.samples[first + i];
+                        float vl, vr = 0.0f;
+                        if (p.interp == SGX_INTERP_COSINE) {
+                            // interpolated_frequency_sample.rs:79-86
+                            const int lo = se.i0, hi = lo + 1 < last ? lo + 1 : last;
+                            const float w1 = 1.0f - se.w;
+                            if (MONO) {
+                                vl = mc[lo] * w1 + mc[hi] * se.w;
+                            } else {
+                                const float2 a = reinterpret_cast<const float2 *>(mc)[lo], b = reinterpret_cast<const float2 *>(mc)[hi];
+                                vl = a.x * w1 + b.x * se.w;
+                                vr = a.y * w1 + b.y * se.w;
+                            }
+                        } else {
+                            // :89-105
+                            const int x1 = se.i0;
+                            const int x0 = x1 > 0 ? x1 - 1 : 0;
+                            const int x2 = x1 + 1 < last ? x1 + 1 : last;
+                            const int x3 = x1 + 2 < last ? x1 + 2 : last;
+                            const float mu = se.w, mu2 = mu * mu, mu3 = mu * mu2;
+                            if (MONO) {
+                                const float y0 = mc[x0], y1 = mc[x1], y2 = mc[x2], y3 = mc[x3];
+                                const float a0 = ((y3 - y2) - y0) + y1;
+                                const float a1 = (y0 - y1) - a0;
+                                const float a2 = y2 - y0;
+                                vl = ((a0 * mu3) + (a1 * mu2)) + ((a2 * mu) + y1);
+                            } else {
+                                const float2 *m2 = reinterpret_cast<const float2 *>(mc);
+                                const float2 y0 = m2[x0], y1 = m2[x1], y2 = m2[x2], y3 = m2[x3];
+                                {
+                                    const float a0 = ((y3.x - y2.x) - y0.x) + y1.x;
+                                    const float a1 = (y0.x - y1.x) - a0;
+                                    const float a2 = y2.x - y0.x;
+                                    vl = ((a0 * mu3) + (a1 * mu2)) + ((a2 * mu) + y1.x);
+                                }
+                                {
+                                    const float a0 = ((y3.y - y2.y) - y0.y) + y1.y;
+                                    const float a1 = (y0.y - y1.y) - a0;
+                                    const float a2 = y2.y - y0.y;
+                                    vr = ((a0 * mu3) + (a1 * mu2)) + ((a2 * mu) + y1.y);
+                                }
+                            }
+                        }
+                        sl = sl + vl;
+                        if (!MONO) sr = sr + vr;
+                    }
+                    float l = sl, r = sr;
+                    if (cnt > 1) {  // x / 1.0 == x: only rows that average several samples divide (:72)
+                        const float nf = (float)cnt;
+                        l = sl / nf;
+                        if (!MONO) r = sr / nf;
+                    }
+                    if (MONO) r = l;  // mono -> (s, s): both channels carry the same magnitude
+                    // colorscheme.rs:59-61 as a threshold count; the log2 only seeds the search
+                    const float power = (l * l) + (r * r);
+                    int idx = (int)floorf(fmaf(__builtin_amdgcn_logf(power + 1e-7f), p.guess_a, p.guess_b));
+                    idx = idx < 0 ? 0 : (idx > 255 ? 255 : idx);
+                    while (idx < 255 && power >= thr[idx]) ++idx;
+                    while (idx > 0 && !(power >= thr[idx - 1])) --idx;
+                    dst[p.R - 1 - py] = lut[idx];  // simple_spectrogram.rs:150; alpha = 1.0 -> 255
                 }
             }
         }
@@ -229,6 +345,9 @@ __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
 struct WgTables {
     float2 *d_tw1 = nullptr;
     float2 *d_tw2 = nullptr;
+    uint32_t *d_rows = nullptr;        // packed row table for the fused pixel path
+    PackedSample *d_samples = nullptr;
+    bool fusable = false;
 };
 
 }  // namespace wg
@@ -249,20 +368,40 @@ hipError_t wg4096_init(sgx_ctx *c, void **out)
         return make_float2((float)cs, (float)sn);
     };
     for (int q = 0; q < 16; ++q)
-        for (int t = 0; t < 256; ++t) tw1[q * 256 + t] = unit(t * q, kP);
+        for (int tt = 0; tt < 256; ++tt) tw1[q * 256 + tt] = unit(tt * q, kP);
     for (int q = 0; q < 16; ++q)
         for (int t0 = 0; t0 < 16; ++t0) tw2[q * 16 + t0] = unit(t0 * q, 256);
-    hipError_t e = hipMalloc(reinterpret_cast<void **>(&t->d_tw1), tw1.size() * sizeof(float2));
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&t->d_tw2), tw2.size() * sizeof(float2));
-    if (e == hipSuccess) e = hipMemcpy(t->d_tw1, tw1.data(), tw1.size() * sizeof(float2), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(t->d_tw2, tw2.data(), tw2.size() * sizeof(float2), hipMemcpyHostToDevice);
+
+    // packed tables of the fused pixel path: 4 B per row, 8 B per sample (the kernel re-derives
+    // mu^2, mu^3 and 1 - o' with the same single-rounded operations the host table holds)
+    std::vector<uint32_t> rows(c->tab.rows.size());
+    std::vector<PackedSample> samples(c->tab.samples.size());
+    bool fusable = c->tab.samples.size() < 65536;
+    for (size_t i = 0; i < rows.size(); ++i) {
+        const auto &r = c->tab.rows[i];
+        if (r.count >= 65536) fusable = false;
+        rows[i] = (r.first & 0xffffu) | (r.count << 16);
+    }
+    for (size_t i = 0; i < samples.size(); ++i) {
+        const auto &se = c->tab.samples[i];
+        samples[i].i0 = se.i0;
+        samples[i].w = c->cfg.interp == SGX_INTERP_COSINE ? se.w2 : se.w0;
+    }
+    t->fusable = fusable;
+
+    auto up = [](auto **dst, const auto &v) {
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(dst), v.size() * sizeof(v[0]));
+        if (e == hipSuccess) e = hipMemcpy(*dst, v.data(), v.size() * sizeof(v[0]), hipMemcpyHostToDevice);
+        return e;
+    };
+    hipError_t e = up(&t->d_tw1, tw1);
+    if (e == hipSuccess) e = up(&t->d_tw2, tw2);
+    if (e == hipSuccess) e = up(&t->d_rows, rows);
+    if (e == hipSuccess) e = up(&t->d_samples, samples);
     if (e != hipSuccess) {
-        if (t->d_tw1) (void)hipFree(t->d_tw1);
-        if (t->d_tw2) (void)hipFree(t->d_tw2);
-        delete t;
+        wg4096_destroy(t);
         return e;
     }
-    (void)c;
     *out = t;
     return hipSuccess;
 }
@@ -273,11 +412,23 @@ void wg4096_destroy(void *tables)
     if (!t) return;
     if (t->d_tw1) (void)hipFree(t->d_tw1);
     if (t->d_tw2) (void)hipFree(t->d_tw2);
+    if (t->d_rows) (void)hipFree(t->d_rows);
+    if (t->d_samples) (void)hipFree(t->d_samples);
     delete t;
 }
 
-hipError_t launch_stft_wg4096(const sgx_ctx *c, const void *tables, const float *d_pcm, uint32_t channels, uint32_t pairs,
-                              size_t first_frame, size_t n_frames, float *d_mags)
+bool wg4096_can_fuse_render(const sgx_ctx *c, const void *tables)
+{
+    const auto *t = static_cast<const wg::WgTables *>(tables);
+    // mono (sequential) colour schemes with a 256-entry ramp; diverging schemes take the two-kernel path
+    return t && t->fusable && c->pal.n == 256 && !c->pal.stereo;
+}
+
+namespace {
+
+template <bool RENDER>
+hipError_t launch_wg(const sgx_ctx *c, const void *tables, const float *d_pcm, uint32_t channels, uint32_t pairs,
+                     size_t first_frame, size_t n_frames, float *d_mags, uint8_t *d_rgba)
 {
     using namespace wg;
     if (n_frames == 0) return hipSuccess;
@@ -285,7 +436,7 @@ hipError_t launch_stft_wg4096(const sgx_ctx *c, const void *tables, const float 
     int n_cu = 256;
     (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device);
     for (uint32_t pair = 0; pair < pairs; ++pair) {
-        Params p;
+        Params p{};
         p.pcm = d_pcm;
         p.tw1 = t->d_tw1;
         p.tw2 = t->d_tw2;
@@ -299,6 +450,20 @@ hipError_t launch_stft_wg4096(const sgx_ctx *c, const void *tables, const float 
         p.pair = pair;
         p.pair_l = channels == 1 ? 0 : 2 * pair;
         p.pair_r = channels == 1 ? 0 : 2 * pair + 1;
+        if (RENDER) {
+            p.rows = t->d_rows;
+            p.samples = t->d_samples;
+            p.lut_thr = c->d_lut_thr;
+            p.lut_rgba = c->d_lut_rgba;
+            p.rgba = d_rgba;
+            p.R = c->R;
+            p.interp = c->cfg.interp;
+            // t * n = (10 log10(x) - min_db) * n / (max_db - min_db) = log2(x) * a + b   (seed only)
+            const double span = (double)c->cfg.max_db - (double)c->cfg.min_db;
+            const double n = c->cfg.lut_index_mode == SGX_LUT_ROUND_NM1 ? 255.0 : 256.0;
+            p.guess_a = (float)(10.0 * log10(2.0) * n / span);
+            p.guess_b = (float)(-(double)c->cfg.min_db * n / span + (c->cfg.lut_index_mode == SGX_LUT_ROUND_NM1 ? 0.5 : 0.0));
+        }
         const bool mono = channels == 1;
         p.n_jobs = mono ? (n_frames + 1) / 2 : n_frames;
         // persistent workgroups, 4 per CU; each owns a contiguous run of transforms so that the
@@ -309,18 +474,33 @@ hipError_t launch_stft_wg4096(const sgx_ctx *c, const void *tables, const float 
         blocks = (p.n_jobs + per - 1) / per;
         p.jobs_per_block = per;
         const dim3 grid((unsigned)blocks), block(256);
+        const size_t lds = RENDER ? kLdsBytesRender : kLdsBytes;
         if (mono) {
-            if (c->H == 256) hipLaunchKernelGGL((stft4096_wg_kernel<true, true, false>), grid, block, kLdsBytes, c->stream, p);
-            else hipLaunchKernelGGL((stft4096_wg_kernel<true, false, false>), grid, block, kLdsBytes, c->stream, p);
+            if (c->H == 256) hipLaunchKernelGGL((stft4096_wg_kernel<true, true, false, RENDER>), grid, block, lds, c->stream, p);
+            else hipLaunchKernelGGL((stft4096_wg_kernel<true, false, false, RENDER>), grid, block, lds, c->stream, p);
         } else if (channels == 2) {
-            hipLaunchKernelGGL((stft4096_wg_kernel<false, false, true>), grid, block, kLdsBytes, c->stream, p);
+            hipLaunchKernelGGL((stft4096_wg_kernel<false, false, true, RENDER>), grid, block, lds, c->stream, p);
         } else {
-            hipLaunchKernelGGL((stft4096_wg_kernel<false, false, false>), grid, block, kLdsBytes, c->stream, p);
+            hipLaunchKernelGGL((stft4096_wg_kernel<false, false, false, RENDER>), grid, block, lds, c->stream, p);
         }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
     return hipSuccess;
+}
+
+}  // namespace
+
+hipError_t launch_stft_wg4096(const sgx_ctx *c, const void *tables, const float *d_pcm, uint32_t channels, uint32_t pairs,
+                              size_t first_frame, size_t n_frames, float *d_mags)
+{
+    return launch_wg<false>(c, tables, d_pcm, channels, pairs, first_frame, n_frames, d_mags, nullptr);
+}
+
+hipError_t launch_render_wg4096(const sgx_ctx *c, const void *tables, const float *d_pcm, uint32_t channels, uint32_t pairs,
+                                size_t first_frame, size_t n_frames, uint8_t *d_rgba)
+{
+    return launch_wg<true>(c, tables, d_pcm, channels, pairs, first_frame, n_frames, nullptr, d_rgba);
 }
 
 }  // namespace sgx

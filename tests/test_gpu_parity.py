@@ -1,6 +1,8 @@
 """Parity tests proper: the HIP path, called through the C ABI, against the CPU oracle on the same
 seeded inputs, against the committed golden fixtures, and -- at sizes the oracle cannot reach --
 through size-independent properties.  Run with -m gpu on an MI355X."""
+import os
+
 import numpy as np
 import pytest
 
@@ -238,6 +240,27 @@ def test_fused_pcm_to_rgba_end_to_end(torch_cuda, gradients):
         # and exactly equal to the render stage applied to the engine's own magnitudes
         own = eng.render_mags(eng.stft_batch(to_dev(torch, pcm))[:, 0].contiguous()).cpu().numpy()
         assert np.array_equal(got, own)
+
+
+@pytest.mark.parametrize("channels,frames", [(1, 37), (1, 64), (2, 21)])
+@pytest.mark.parametrize("interp", [0, 1])
+def test_fused_kernel_equals_two_kernel_path(torch_cuda, channels, frames, interp):
+    # the fused PCM -> RGBA kernel (magnitudes stay in LDS) must write the bytes of STFT + pixel stage
+    torch = torch_cuda
+    n = W + (frames - 1) * H
+    pcm = to_dev(torch, oracle.white_noise(n * channels, seed=77) * np.float32(0.1))
+    fused = engine(window_samples=W, hop_samples=H, channels=channels, interp=interp, gradient="magma")
+    split = engine(window_samples=W, hop_samples=H, channels=channels, interp=interp, gradient="magma", fused_render=False)
+    a = fused.render_batch(pcm).cpu().numpy()
+    b = split.render_batch(pcm).cpu().numpy()
+    assert a.shape == (frames, 1, R, 4) and np.array_equal(a, b)
+    # sub-ranges and odd counts (a mono transform carries two frames)
+    c = fused.render_batch(pcm, first_frame=5, max_frames=7).cpu().numpy()
+    assert np.array_equal(c, a[5:12])
+    # a diverging scheme is not fused: still correct through the same entry point
+    fused.set_gradient(np.load(os.path.join(os.path.dirname(__file__), "golden", "gradients.npz"))["plasma"], stereo=True)
+    split.set_gradient(np.load(os.path.join(os.path.dirname(__file__), "golden", "gradients.npz"))["plasma"], stereo=True)
+    assert np.array_equal(fused.render_batch(pcm).cpu().numpy(), split.render_batch(pcm).cpu().numpy())
 
 
 def test_lookup_table_and_widget_ring(torch_cuda, gradients):
