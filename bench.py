@@ -37,8 +37,10 @@ ALGO_BYTES_PIXEL = H * 1 * 4 + R * 4     # 5 120 B / frame
 KERNEL_NAMES = {
     0: ("generic power-of-two (workgroup per frame, LDS radix-2)", "sgx::stft_generic_kernel"),
     1: ("stft4096 wave-per-transform", "sgx::stft4096_kernel<6, true>"),
-    2: ("stft4096 workgroup-per-transform (256 threads x 16 points, radix-16 x3, mono frame pairs)",
-        "sgx::wg::stft4096_wg_kernel<true, true, false>"),
+    2: ("stft4096 workgroup-per-transform (256 threads x 16 points, radix-16 x3, mono frame pairs), scalar codelets",
+        "sgx::wg::stft4096_wg_kernel<true, 2, false, false>"),
+    3: ("stft4096 workgroup-per-transform (256 threads x 16 points, radix-16 x3, mono frame pairs), packed (re, im) codelets",
+        "sgx::wgp::stft4096_wgp_kernel<true, 2, false, false>"),
 }
 
 

@@ -83,6 +83,7 @@ typedef struct sgx_config {
 
 #define SGX_FLAG_FORCE_GENERIC 1u /* use the generic power-of-two kernel even where a tuned one exists (testing) */
 #define SGX_FLAG_NO_FUSED_RENDER 4u /* sgx_render_batch: run STFT and pixel stage as two kernels even where the fused one applies (A/B) */
+#define SGX_FLAG_PACKED_KERNEL 8u  /* W = 2048: workgroup-per-transform kernel with packed (re, im) arithmetic instead of scalar (A/B) */
 #define SGX_FLAG_WAVE_KERNEL 2u   /* W = 2048: use the wave-per-transform kernel instead of the workgroup-per-transform one (A/B) */
 
 typedef struct sgx_info {
@@ -96,7 +97,7 @@ typedef struct sgx_info {
     uint32_t rows;            /* R */
     uint32_t sample_rate_u32; /* SampleRate(sample_rate as u32)      simple_spectrogram.rs:138 */
     uint32_t total_samples_per_column; /* sum over rows of magnitude_in's sample count */
-    uint32_t stft_kernel;     /* 0 = generic power-of-two, 1 = 4096-point wave-per-transform, 2 = 4096-point workgroup-per-transform */
+    uint32_t stft_kernel;     /* 0 = generic power-of-two, 1 = 4096-point wave-per-transform, 2 = 4096-point workgroup-per-transform (default), 3 = the same with packed (re, im) arithmetic */
     uint32_t reserved;
     uint64_t mags_bytes_per_frame; /* pairs * M * 2 * 4 */
     uint64_t rgba_bytes_per_frame; /* pairs * R * 4     */

@@ -23,6 +23,7 @@ LUT_FLOOR_N, LUT_ROUND_NM1 = 0, 1
 FLAG_FORCE_GENERIC = 1
 FLAG_WAVE_KERNEL = 2
 FLAG_NO_FUSED_RENDER = 4
+FLAG_PACKED_KERNEL = 8
 
 
 class SgxError(RuntimeError):

@@ -91,6 +91,7 @@ int ensure_workspace(sgx_ctx *c, size_t frames)
 hipError_t run_stft(const sgx_ctx *c, const float *d_pcm, uint32_t channels, uint32_t pairs, size_t first, size_t n,
                     float *d_mags)
 {
+    if (c->stft_kernel == 3) return sgx::launch_stft_wgp4096(c, c->d_fast_wg, d_pcm, channels, pairs, first, n, d_mags);
     if (c->stft_kernel == 2) return sgx::launch_stft_wg4096(c, c->d_fast_wg, d_pcm, channels, pairs, first, n, d_mags);
     if (c->stft_kernel == 1) return sgx::launch_stft_fast4096(c, d_pcm, channels, pairs, first, n, d_mags);
     return sgx::launch_stft_generic(c, d_pcm, channels, pairs, first, n, d_mags);
@@ -205,7 +206,7 @@ int sgx_create(const sgx_config *cfg, sgx_ctx **out_ctx)
         if (e != hipSuccess) return bail(SGX_ERR_HIP, std::string("sgx_create: tuned kernel tables: ") + hipGetErrorString(e));
         e = sgx::wg4096_init(c, &c->d_fast_wg);
         if (e != hipSuccess) return bail(SGX_ERR_HIP, std::string("sgx_create: tuned kernel tables: ") + hipGetErrorString(e));
-        c->stft_kernel = (cfg->flags & SGX_FLAG_WAVE_KERNEL) ? 1 : 2;
+        c->stft_kernel = (cfg->flags & SGX_FLAG_WAVE_KERNEL) ? 1 : ((cfg->flags & SGX_FLAG_PACKED_KERNEL) ? 3 : 2);
     }
     *out_ctx = c;
     return SGX_OK;
@@ -321,9 +322,11 @@ int sgx_render_batch(sgx_ctx *c, const float *d_pcm, size_t n_samples, size_t fi
     if (n > max_frames) n = max_frames;
     if (!d_pcm || !d_rgba) return fail(c, SGX_ERR_INVALID_ARG, "sgx_render_batch: null buffer");
     SGX_HIP(c, hipSetDevice(c->device));
-    if (c->stft_kernel == 2 && !(c->cfg.flags & SGX_FLAG_NO_FUSED_RENDER) && sgx::wg4096_can_fuse_render(c, c->d_fast_wg)) {
+    if (c->stft_kernel >= 2 && !(c->cfg.flags & SGX_FLAG_NO_FUSED_RENDER) && sgx::wg4096_can_fuse_render(c, c->d_fast_wg)) {
         // one kernel from PCM to pixels: magnitudes never leave LDS (5 120 B of HBM traffic per frame)
-        hipError_t e = sgx::launch_render_wg4096(c, c->d_fast_wg, d_pcm, c->C, c->pairs, first_frame, n, d_rgba);
+        hipError_t e = c->stft_kernel == 3
+                           ? sgx::launch_render_wgp4096(c, c->d_fast_wg, d_pcm, c->C, c->pairs, first_frame, n, d_rgba)
+                           : sgx::launch_render_wg4096(c, c->d_fast_wg, d_pcm, c->C, c->pairs, first_frame, n, d_rgba);
         if (e != hipSuccess) return fail_hip(c, e, "sgx_render_batch: fused launch");
         if (n_out) *n_out = n;
         return SGX_OK;

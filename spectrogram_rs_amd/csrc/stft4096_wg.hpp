@@ -1,0 +1,84 @@
+// stft4096_wg.hpp -- declarations shared by the two workgroup-per-transform kernels
+// (stft4096_wg.hip: scalar codelets; stft4096_wgp.hip: packed (re, im) codelets).
+#pragma once
+#include "sgx_internal.hpp"
+
+namespace sgx {
+namespace wg {
+
+constexpr int kW = 2048, kP = 4096, kM = 2047;
+// Sliding the sample window in registers (2 new rows per mono transform instead of 9 loads): every
+// sample is fetched once per workgroup.  It pins 7 VGPRs across the FFT passes (the scalar kernel
+// then spills 3 registers) but the launch is bound by total HBM traffic, and dropping the overlap
+// re-reads (3.3 -> 1.0 KB per frame) was worth +5 % (same-device A/B, 1e6 frames).
+constexpr bool kSlideWindow = true;
+constexpr int kS1 = 272;            // row stride (complex) of the pass-1 -> pass-2 image [q1][t]
+constexpr int kS2 = 257;            // row stride (complex) of the pass-2 -> pass-3 image [t0][q1 + 16 q2]
+constexpr int kBufComplex = 16 * kS1;  // 4352 complex = 34 816 B (also holds 16*257 and 9*256)
+constexpr size_t kLdsBytes = (size_t)(kBufComplex + 256) * sizeof(float2);
+constexpr size_t kLdsBytesRender = kLdsBytes + 256 * sizeof(float) + 256 * sizeof(uchar4);
+
+struct PackedSample {
+    int32_t i0;   // cubic: floor(index); cosine: low
+    float w;      // cubic: mu;           cosine: o' (the cosine-eased offset)
+};
+
+struct Params {
+    const float *pcm;
+    const float2 *tw1;   // [16][256]  w_4096^{t q1}
+    const float2 *tw2;   // [16][16]   w_256^{t0 q2} at [q2][t0]
+    const float *window; // [2048]
+    float *mags;
+    unsigned long long first_frame, n_frames, n_jobs, jobs_per_block;
+    uint32_t H, C, pair_l, pair_r, pairs, pair;
+    // fused pixel path (RENDER): magnitudes never leave LDS
+    const uint32_t *rows;      // [R]  first | count << 16
+    const PackedSample *samples;
+    const float *lut_thr;      // [255]
+    const uchar4 *lut_rgba;    // [256]
+    uint8_t *rgba;             // [F][pairs][R][4]
+    uint32_t R, interp;
+    float guess_a, guess_b;    // LUT index ~ floor(log2(power + 1e-7) * a + b), then exact fix-up
+};
+
+// Which two mono frames share a transform: always (2j, 2j+1).
+//   kPairAdjacentRow : H = 256: frame 2j+1's rows are frame 2j's rows shifted by one (9 rows feed both)
+//   kPairAdjacent    : any other hop (16 row loads)
+// (Tried and rejected, same-device A/B on 1e6 frames: pairing (f, f+16) plus a per-row lane rotation
+// so that both rows' stores are 128-byte aligned: -10 %, the extra row loads cost more than the
+// alignment buys; 16-byte stores via a DPP lane-pair exchange: -8 %.  The launch is bound by total
+// HBM traffic, not by store alignment or store instruction count.)
+constexpr int kPairAdjacentRow = 0, kPairAdjacent = 1;
+
+struct WgTables {
+    float2 *d_tw1 = nullptr;
+    float2 *d_tw2 = nullptr;
+    uint32_t *d_rows = nullptr;        // packed row table for the fused pixel path
+    PackedSample *d_samples = nullptr;
+    bool fusable = false;
+};
+
+__device__ __forceinline__ void lds_barrier()
+{
+    // LDS-only workgroup barrier: outstanding global stores are NOT waited for
+#ifdef SGX_ABL_NOBARRIER
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+}
+
+// one row of [M][2] floats; rowm8 = row base - 8 bytes (bin k lives at byte 8 k of rowm8): a uniform
+// (SGPR) row base plus one 32-bit lane offset, immediate offsets per segment
+template <bool DUP>  // DUP: mono, the row holds (m, m); else (va, vb) = (left, right)
+__device__ __forceinline__ void store_row(char *rowm8, int col, const float (&va)[8], const float (&vb)[8])
+{
+    const uint32_t lane_off = (uint32_t)col * 8u;
+#pragma unroll
+    for (int q3 = 0; q3 < 8; ++q3)
+        if (q3 > 0 || col != 0)  // k = 0 (DC) is not part of the output (fft.rs:81)
+            *reinterpret_cast<float2 *>(rowm8 + 2048 * q3 + lane_off) = DUP ? make_float2(va[q3], va[q3]) : make_float2(va[q3], vb[q3]);
+}
+
+}  // namespace wg
+}  // namespace sgx

@@ -1,57 +1,62 @@
-// stft4096_wg.hip -- tuned STFT for W = 2048 (P = 4096): one 256-thread workgroup per transform,
-// 16 points per thread, three radix-16 passes.
+// stft4096_wgp.hip -- the workgroup-per-transform 4096-point STFT (see stft4096_wg.hip for the
+// algorithm) with its arithmetic on packed (re, im) pairs.
 //
-// Why this shape (measured on MI355X, tools/microbench.hip): a single wave per SIMD issues one
-// VALU instruction every ~7 cycles, four waves per SIMD one every ~2.  64 points per lane (the
-// wave-per-transform kernel in stft4096.hip) needs > 128 VGPRs and so caps at 2 waves per SIMD;
-// 16 points per thread fits 4 waves per SIMD and keeps 16 waves per CU in flight to cover LDS,
-// barrier and memory latency.
-//
-// Replaces FastFourierTransform::process (fft.rs:43-99) + the hop loop (audio_transform.rs:34-42).
-//
-//   sample index  n = t + 256 a           (t = thread, a < 8 non-zero rows: padding never touched)
-//   pass 1  thread t        : 16-point DFT over a (8 non-zero inputs = two 8-point FFTs), -> q1
-//                             twiddle w_4096^{t q1}            (15 per-thread constants in VGPRs)
-//   pass 2  thread (q1, t0) : t = t0 + 16 t1; 16-point FFT over t1 -> q2; twiddle w_256^{t0 q2} (LDS)
-//   pass 3  thread q1+16 q2 : 16-point FFT over t0 -> q3;  bin k = q1 + 16 q2 + 256 q3
-//   split   F[k] and F[P-k] -> |L^[k]|, |R^[k]| (fft.rs:81-89): the partner of thread u is thread
-//           (256 - u) % 256, exchanged through LDS (upper 8 registers only; k = 1..2047 is kept)
-//
-// Mono streams (a mono sample is duplicated into (s, s): audio_input_list_model.rs:67-69) pack
-// TWO consecutive frames into one transform: frame 2j in the real part, frame 2j+1 in the
-// imaginary part; the same split that separates left from right separates the two frames.
+// A complex value lives in one aligned VGPR pair, so a complex add is ONE v_pk_add_f32, the
+// radix-4 rotations (+-i) are the same instruction with op_sel / neg modifiers, and a twiddle
+// multiply is v_pk_mul_f32 + v_pk_fma_f32.  Measured on MI355X (profiles/r01_microbench.txt) a
+// packed op costs ~1.5x a scalar op at 4 waves/SIMD while doing the work of two: the FFT passes
+// drop from ~690 to ~360 VALU instructions per thread and transform.  hipcc does not fold the
+// swap-and-negate of a rotation or of a variable twiddle into operand modifiers (it emits
+// v_mov + v_xor pairs), hence the three one-instruction asm helpers below; everything else is
+// ordinary vector arithmetic that hipcc selects packed instructions for.
 #include "stft4096_wg.hpp"
-#ifndef SGX_ABL_NSTORE
-#define SGX_ABL_NSTORE 8
-#endif
 
 namespace sgx {
 
-namespace wg {
+namespace wgp {
+
+using namespace sgx::wg;
 
 typedef float f2v __attribute__((ext_vector_type(2)));
+
+// a - i b = (a.x + b.y, a.y - b.x)
+__device__ __forceinline__ f2v cx_add_mi(f2v a, f2v b)
+{
+    f2v r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// a + i b = (a.x - b.y, a.y + b.x)
+__device__ __forceinline__ f2v cx_add_pi(f2v a, f2v b)
+{
+    f2v r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// v * w for a twiddle held in registers: t = (-v.y w.y, v.y w.x); r = (v.x w.x, v.x w.y) + t
+__device__ __forceinline__ f2v cx_mul_v(f2v v, f2v w)
+{
+    f2v t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(t) : "v"(v), "v"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(r) : "v"(v), "v"(w), "v"(t));
+    return r;
+}
+// v * (c + i d) for a literal twiddle (constants land in SGPR pairs)
+__device__ __forceinline__ f2v cx_mul_k(f2v v, float c, float d)
+{
+    const f2v t = f2v{v.y, v.y} * f2v{-d, c};
+    return __builtin_elementwise_fma(f2v{v.x, v.x}, f2v{c, d}, t);
+}
+__device__ __forceinline__ f2v cx_mul_mi(f2v v) { return f2v{v.y, -v.x}; }
+__device__ __forceinline__ f2v cx_mul_pi(f2v v) { return f2v{-v.y, v.x}; }
+
 __device__ __forceinline__ float cl_fma(float a, float c, float u) { return fmaf(a, c, u); }
 __device__ __forceinline__ f2v cl_fma(f2v a, float c, f2v u) { return __builtin_elementwise_fma(a, f2v{c, c}, u); }
-
-#include "fft_codelets.inc"
-
-__device__ __forceinline__ void store2(float *row, int j, float a, float b)
-{
-#ifdef SGX_NT_STORES
-    typedef float f2s __attribute__((ext_vector_type(2)));
-    __builtin_nontemporal_store(f2s{a, b}, reinterpret_cast<f2s *>(row) + j);
-#else
-    reinterpret_cast<float2 *>(row)[j] = make_float2(a, b);
-#endif
-}
-
-__device__ __forceinline__ float2 cmulf(float2 a, float2 b)
-{
-    return make_float2(fmaf(a.x, b.x, -(a.y * b.y)), fmaf(a.x, b.y, a.y * b.x));
-}
+#include "fft_codelets.inc"     // FFT8_OUT / FFT16_OUT (same radices, same output permutation)
+#include "fft_codelets_cx.inc"
 
 template <bool MONO, int PAIRING, bool C2, bool RENDER>
-__global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
+__global__ void __launch_bounds__(256, 4) stft4096_wgp_kernel(Params p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float2 *buf = reinterpret_cast<float2 *>(smem_raw);
@@ -73,9 +78,9 @@ __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
 #pragma unroll
     for (int a = 0; a < 8; ++a) win[a] = p.window[tid + 256 * a];
 #endif
-    float2 tw1[16];
+    f2v tw1[16];
 #pragma unroll
-    for (int q = 1; q < 16; ++q) tw1[q] = p.tw1[q * 256 + tid];
+    for (int q = 1; q < 16; ++q) { const float2 t = p.tw1[q * 256 + tid]; tw1[q] = f2v{t.x, t.y}; }
 
     const int q1_2 = tid >> 4, t0_2 = tid & 15;                 // pass-2 role
     const float inv_w = 1.0f / (float)kW;                       // (hypot / 2) * (2 / W)
@@ -142,95 +147,75 @@ __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
 
     for (unsigned long long job = job_begin; job < job_end; ++job) {
         // ---- Hann (fft.rs:53-63) on the prefetched samples
-        float er[8], ei[8];
-#ifdef SGX_WIN_RELOAD
-        // the Hann factors are re-read (L1-resident 8 KB table) instead of pinning 8 VGPRs
-        float win[8];
-#pragma unroll
-        for (int a = 0; a < 8; ++a) win[a] = p.window[tid + 256 * a];
-#endif
+        f2v e[8];
         const unsigned long long f0 = MONO ? 2 * job : job;
         const unsigned long long f1 = f0 + 1;
         const bool have_second = !MONO || f1 < p.n_frames;
 #pragma unroll
         for (int a = 0; a < 8; ++a) {
-            er[a] = sa[a] * win[a];
-            if (MONO && PAIRING == kPairAdjacentRow) ei[a] = have_second ? sa[a + 1] * win[a] : 0.0f;
-            else ei[a] = have_second ? sb[a] * win[a] : 0.0f;
+            e[a].x = sa[a] * win[a];
+            if (MONO && PAIRING == kPairAdjacentRow) e[a].y = have_second ? sa[a + 1] * win[a] : 0.0f;
+            else e[a].y = have_second ? sb[a] * win[a] : 0.0f;
         }
         const int col = tid;                           // pass-3 / output column of this thread
         const int pcol = col == 0 ? 256 : 256 - col;   // partner column (column 0 is its own partner, one row up)
 
         // ---- pass 1: 16-point DFT over a, inputs a >= 8 are the zero padding:
         //      even q1 = FFT8(z), odd q1 = FFT8(z * w_16^a)
-        float orr[8], oi[8];
+        f2v o[8];
 #pragma unroll
-        for (int a = 0; a < 8; ++a) { orr[a] = er[a]; oi[a] = ei[a]; }
-        pretwiddle8_w16(orr, oi);
-        fft8(er, ei);
-        fft8(orr, oi);
+        for (int a = 0; a < 8; ++a) o[a] = e[a];
+        pretwiddle8c_w16(o);
+        fft8c(e);
+        fft8c(o);
 
         lds_barrier();  // the previous transform's partner reads are complete
+        f2v *cbuf = reinterpret_cast<f2v *>(buf);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int pos = FFT8_OUT[j];
-            const float2 ve = make_float2(er[pos], ei[pos]);
-            const float2 vo = make_float2(orr[pos], oi[pos]);
-            buf[(2 * j) * kS1 + tid] = j == 0 ? ve : cmulf(ve, tw1[2 * j]);
-            buf[(2 * j + 1) * kS1 + tid] = cmulf(vo, tw1[2 * j + 1]);
+            cbuf[(2 * j) * kS1 + tid] = j == 0 ? e[pos] : cx_mul_v(e[pos], tw1[2 * j]);
+            cbuf[(2 * j + 1) * kS1 + tid] = cx_mul_v(o[pos], tw1[2 * j + 1]);
         }
         lds_barrier();
 
         // ---- pass 2: thread (q1, t0): 16-point FFT over t1, then twiddle w_256^{t0 q2}
-        float xr[16], xi[16];
+        f2v x[16];
 #pragma unroll
-        for (int t1 = 0; t1 < 16; ++t1) {
-            const float2 v = buf[q1_2 * kS1 + t0_2 + 16 * t1];
-            xr[t1] = v.x; xi[t1] = v.y;
-        }
-#ifndef SGX_ABL_NOFFT
-        fft16(xr, xi);
-#endif
+        for (int t1 = 0; t1 < 16; ++t1) x[t1] = cbuf[q1_2 * kS1 + t0_2 + 16 * t1];
+        fft16c(x);
         lds_barrier();  // everyone has read image 1
+        const f2v *ctw2 = reinterpret_cast<const f2v *>(tw2);
 #pragma unroll
         for (int q2 = 0; q2 < 16; ++q2) {
             const int pos = FFT16_OUT[q2];
-            const float2 v = make_float2(xr[pos], xi[pos]);
-            buf[t0_2 * kS2 + q1_2 + 16 * q2] = q2 == 0 ? v : cmulf(v, tw2[q2 * 16 + t0_2]);
+            cbuf[t0_2 * kS2 + q1_2 + 16 * q2] = q2 == 0 ? x[pos] : cx_mul_v(x[pos], ctw2[q2 * 16 + t0_2]);
         }
         lds_barrier();
 
-        // ---- pass 3: thread u = q1 + 16 q2: 16-point FFT over t0 -> bins k = u + 256 q3
+        // ---- pass 3: thread u owns column col = q1 + 16 q2: 16-point FFT over t0 -> bins k = col + 256 q3
 #pragma unroll
-        for (int t0 = 0; t0 < 16; ++t0) {
-            const float2 v = buf[t0 * kS2 + col];
-            xr[t0] = v.x; xi[t0] = v.y;
-        }
-#ifndef SGX_ABL_NOFFT
-        fft16(xr, xi);
-#endif
+        for (int t0 = 0; t0 < 16; ++t0) x[t0] = cbuf[t0 * kS2 + col];
+        fft16c(x);
         if (job + 1 < job_end) fetch(job + 1, true);  // ahead of this transform's stores (see above)
         lds_barrier();  // everyone has read image 2
         // partner exchange: publish q3 = 8..15 (the bins P-k of the kept half)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int pos = FFT16_OUT[8 + j];
-            buf[j * 256 + col] = make_float2(xr[pos], xi[pos]);
-        }
+        for (int j = 0; j < 8; ++j) cbuf[j * 256 + col] = x[FFT16_OUT[8 + j]];
         lds_barrier();
 
         // ---- split + magnitude (fft.rs:81-98)
         float ml[8], mr[8];
 #pragma unroll
         for (int q3 = 0; q3 < 8; ++q3) {
-            const int pos = FFT16_OUT[q3];
-            // F[P-k]: thread 256-u holds it as q3' = 15 - q3 (row 7 - q3); thread 0 as q3' = 16 - q3
-            const float2 b = buf[(7 - q3) * 256 + pcol];
-            const float ar = xr[pos], ai = xi[pos];
-            const float pr = ar + b.x, pi = ai - b.y;   // a + conj(b) = 2 L^
-            const float qr = ar - b.x, qi = ai + b.y;   // a - conj(b) = 2i R^
-            ml[q3] = __builtin_amdgcn_sqrtf(fmaf(pr, pr, pi * pi)) * inv_w;
-            mr[q3] = __builtin_amdgcn_sqrtf(fmaf(qr, qr, qi * qi)) * inv_w;
+            // F[P-k]: column 256-col holds it as q3' = 15 - q3 (row 7 - q3); column 0 as q3' = 16 - q3
+            const f2v b = cbuf[(7 - q3) * 256 + pcol];
+            const f2v a = x[FFT16_OUT[q3]];
+            const f2v sp = a + f2v{b.x, -b.y};   // a + conj(b) = 2 L^
+            const f2v sq = a - f2v{b.x, -b.y};   // a - conj(b) = 2i R^
+            const f2v pp = sp * sp, qq = sq * sq;
+            ml[q3] = __builtin_amdgcn_sqrtf(pp.x + pp.y) * inv_w;
+            mr[q3] = __builtin_amdgcn_sqrtf(qq.x + qq.y) * inv_w;
         }
 
         if (!RENDER) {
@@ -336,87 +321,16 @@ __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
     }
 }
 
-}  // namespace wg
-
-hipError_t wg4096_init(sgx_ctx *c, void **out)
-{
-    using namespace wg;
-    auto *t = new WgTables();
-    std::vector<float2> tw1(16 * 256), tw2(256);
-    auto unit = [](int idx, int N) {
-        idx %= N;
-        const double ang = -2.0 * M_PI * (double)idx / (double)N;
-        double cs = cos(ang), sn = sin(ang);
-        if (idx == 0) { cs = 1.0; sn = 0.0; }
-        if (4 * idx == N) { cs = 0.0; sn = -1.0; }
-        if (2 * idx == N) { cs = -1.0; sn = 0.0; }
-        if (4 * idx == 3 * N) { cs = 0.0; sn = 1.0; }
-        return make_float2((float)cs, (float)sn);
-    };
-    for (int q = 0; q < 16; ++q)
-        for (int tt = 0; tt < 256; ++tt) tw1[q * 256 + tt] = unit(tt * q, kP);
-    for (int q = 0; q < 16; ++q)
-        for (int t0 = 0; t0 < 16; ++t0) tw2[q * 16 + t0] = unit(t0 * q, 256);
-
-    // packed tables of the fused pixel path: 4 B per row, 8 B per sample (the kernel re-derives
-    // mu^2, mu^3 and 1 - o' with the same single-rounded operations the host table holds)
-    std::vector<uint32_t> rows(c->tab.rows.size());
-    std::vector<PackedSample> samples(c->tab.samples.size());
-    bool fusable = c->tab.samples.size() < 65536;
-    for (size_t i = 0; i < rows.size(); ++i) {
-        const auto &r = c->tab.rows[i];
-        if (r.count >= 65536) fusable = false;
-        rows[i] = (r.first & 0xffffu) | (r.count << 16);
-    }
-    for (size_t i = 0; i < samples.size(); ++i) {
-        const auto &se = c->tab.samples[i];
-        samples[i].i0 = se.i0;
-        samples[i].w = c->cfg.interp == SGX_INTERP_COSINE ? se.w2 : se.w0;
-    }
-    t->fusable = fusable;
-
-    auto up = [](auto **dst, const auto &v) {
-        hipError_t e = hipMalloc(reinterpret_cast<void **>(dst), v.size() * sizeof(v[0]));
-        if (e == hipSuccess) e = hipMemcpy(*dst, v.data(), v.size() * sizeof(v[0]), hipMemcpyHostToDevice);
-        return e;
-    };
-    hipError_t e = up(&t->d_tw1, tw1);
-    if (e == hipSuccess) e = up(&t->d_tw2, tw2);
-    if (e == hipSuccess) e = up(&t->d_rows, rows);
-    if (e == hipSuccess) e = up(&t->d_samples, samples);
-    if (e != hipSuccess) {
-        wg4096_destroy(t);
-        return e;
-    }
-    *out = t;
-    return hipSuccess;
-}
-
-void wg4096_destroy(void *tables)
-{
-    auto *t = static_cast<wg::WgTables *>(tables);
-    if (!t) return;
-    if (t->d_tw1) (void)hipFree(t->d_tw1);
-    if (t->d_tw2) (void)hipFree(t->d_tw2);
-    if (t->d_rows) (void)hipFree(t->d_rows);
-    if (t->d_samples) (void)hipFree(t->d_samples);
-    delete t;
-}
-
-bool wg4096_can_fuse_render(const sgx_ctx *c, const void *tables)
-{
-    const auto *t = static_cast<const wg::WgTables *>(tables);
-    // mono (sequential) colour schemes with a 256-entry ramp; diverging schemes take the two-kernel path
-    return t && t->fusable && c->pal.n == 256 && !c->pal.stereo;
-}
+}  // namespace wgp
 
 namespace {
 
 template <bool RENDER>
-hipError_t launch_wg(const sgx_ctx *c, const void *tables, const float *d_pcm, uint32_t channels, uint32_t pairs,
-                     size_t first_frame, size_t n_frames, float *d_mags, uint8_t *d_rgba)
+hipError_t launch_wgp(const sgx_ctx *c, const void *tables, const float *d_pcm, uint32_t channels, uint32_t pairs,
+                      size_t first_frame, size_t n_frames, float *d_mags, uint8_t *d_rgba)
 {
     using namespace wg;
+    using namespace wgp;
     if (n_frames == 0) return hipSuccess;
     const auto *t = static_cast<const WgTables *>(tables);
     int n_cu = 256;
@@ -444,7 +358,6 @@ hipError_t launch_wg(const sgx_ctx *c, const void *tables, const float *d_pcm, u
             p.rgba = d_rgba;
             p.R = c->R;
             p.interp = c->cfg.interp;
-            // t * n = (10 log10(x) - min_db) * n / (max_db - min_db) = log2(x) * a + b   (seed only)
             const double span = (double)c->cfg.max_db - (double)c->cfg.min_db;
             const double n = c->cfg.lut_index_mode == SGX_LUT_ROUND_NM1 ? 255.0 : 256.0;
             p.guess_a = (float)(10.0 * log10(2.0) * n / span);
@@ -452,8 +365,6 @@ hipError_t launch_wg(const sgx_ctx *c, const void *tables, const float *d_pcm, u
         }
         const bool mono = channels == 1;
         p.n_jobs = mono ? (n_frames + 1) / 2 : n_frames;
-        // persistent workgroups, 4 per CU; each owns a contiguous run of transforms so that the
-        // overlapping audio of consecutive frames is re-read from L1/L2, not HBM
         unsigned long long blocks = (unsigned long long)n_cu * 4;
         unsigned long long per = (p.n_jobs + blocks - 1) / blocks;
         if (per < 1) per = 1;
@@ -462,12 +373,12 @@ hipError_t launch_wg(const sgx_ctx *c, const void *tables, const float *d_pcm, u
         const dim3 grid((unsigned)blocks), block(256);
         const size_t lds = RENDER ? kLdsBytesRender : kLdsBytes;
         if (mono) {
-            if (c->H == 256) hipLaunchKernelGGL((stft4096_wg_kernel<true, kPairAdjacentRow, false, RENDER>), grid, block, lds, c->stream, p);
-            else hipLaunchKernelGGL((stft4096_wg_kernel<true, kPairAdjacent, false, RENDER>), grid, block, lds, c->stream, p);
+            if (c->H == 256) hipLaunchKernelGGL((stft4096_wgp_kernel<true, kPairAdjacentRow, false, RENDER>), grid, block, lds, c->stream, p);
+            else hipLaunchKernelGGL((stft4096_wgp_kernel<true, kPairAdjacent, false, RENDER>), grid, block, lds, c->stream, p);
         } else if (channels == 2) {
-            hipLaunchKernelGGL((stft4096_wg_kernel<false, kPairAdjacent, true, RENDER>), grid, block, lds, c->stream, p);
+            hipLaunchKernelGGL((stft4096_wgp_kernel<false, kPairAdjacent, true, RENDER>), grid, block, lds, c->stream, p);
         } else {
-            hipLaunchKernelGGL((stft4096_wg_kernel<false, kPairAdjacent, false, RENDER>), grid, block, lds, c->stream, p);
+            hipLaunchKernelGGL((stft4096_wgp_kernel<false, kPairAdjacent, false, RENDER>), grid, block, lds, c->stream, p);
         }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
@@ -477,16 +388,16 @@ hipError_t launch_wg(const sgx_ctx *c, const void *tables, const float *d_pcm, u
 
 }  // namespace
 
-hipError_t launch_stft_wg4096(const sgx_ctx *c, const void *tables, const float *d_pcm, uint32_t channels, uint32_t pairs,
-                              size_t first_frame, size_t n_frames, float *d_mags)
+hipError_t launch_stft_wgp4096(const sgx_ctx *c, const void *tables, const float *d_pcm, uint32_t channels, uint32_t pairs,
+                               size_t first_frame, size_t n_frames, float *d_mags)
 {
-    return launch_wg<false>(c, tables, d_pcm, channels, pairs, first_frame, n_frames, d_mags, nullptr);
+    return launch_wgp<false>(c, tables, d_pcm, channels, pairs, first_frame, n_frames, d_mags, nullptr);
 }
 
-hipError_t launch_render_wg4096(const sgx_ctx *c, const void *tables, const float *d_pcm, uint32_t channels, uint32_t pairs,
-                                size_t first_frame, size_t n_frames, uint8_t *d_rgba)
+hipError_t launch_render_wgp4096(const sgx_ctx *c, const void *tables, const float *d_pcm, uint32_t channels, uint32_t pairs,
+                                 size_t first_frame, size_t n_frames, uint8_t *d_rgba)
 {
-    return launch_wg<true>(c, tables, d_pcm, channels, pairs, first_frame, n_frames, nullptr, d_rgba);
+    return launch_wgp<true>(c, tables, d_pcm, channels, pairs, first_frame, n_frames, nullptr, d_rgba);
 }
 
 }  // namespace sgx

@@ -32,11 +32,15 @@ def to_dev(torch, a):
 
 # ---- the transform -----------------------------------------------------------------------------
 
-@pytest.mark.parametrize("force_generic", [False, True])
+@pytest.mark.parametrize("variant", ["default", "packed", "wave", "generic"])
 @pytest.mark.parametrize("channels", [1, 2])
-def test_stft_batch_matches_oracle(torch_cuda, mags_err, force_generic, channels):
+def test_stft_batch_matches_oracle(torch_cuda, mags_err, variant, channels):
+    # every kernel that can serve W = 2048: workgroup-per-transform (default), its packed-arithmetic
+    # twin, the wave-per-transform kernel, and the generic power-of-two kernel
     torch = torch_cuda
-    eng = engine(window_samples=W, hop_samples=H, channels=channels, force_generic=force_generic)
+    kw = {"default": {}, "packed": {"packed_kernel": True}, "wave": {"wave_kernel": True}, "generic": {"force_generic": True}}[variant]
+    eng = engine(window_samples=W, hop_samples=H, channels=channels, **kw)
+    assert eng.info.stft_kernel == {"default": 2, "packed": 3, "wave": 1, "generic": 0}[variant]
     n = W + H * 130 + 77
     pcm = oracle.white_noise(n * channels, seed=11 + channels)
     got = eng.stft_batch(to_dev(torch, pcm)).cpu().numpy()

@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Turn the FETCH_SIZE / WRITE_SIZE passes into per-launch HBM bytes, calibrated on kernels whose
+byte counts are known (MI355X_MICROARCH.md: the counters are only calibrated for 16 B/lane accesses).
+usage: tools/pmc_traffic.py gpurun_out/<fetch>_bench gpurun_out/<fetch>_micro gpurun_out/<write>_bench gpurun_out/<write>_micro
+"""
+import collections
+import csv
+import glob
+import json
+import sys
+
+
+def load(d):
+    acc = collections.defaultdict(list)
+    for path in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(path)):
+            acc[(r["Kernel_Name"], int(r["Grid_Size"]), r["Counter_Name"])].append(float(r["Counter_Value"]))
+    return acc
+
+
+fb, fm, wb, wm = [load(d) for d in sys.argv[1:5]]
+out = {"unit_note": "FETCH_SIZE/WRITE_SIZE are reported in KiB; values below are bytes"}
+
+
+def pick(acc, name_part, counter, biggest=True):
+    c = [(k, v) for k, v in acc.items() if name_part in k[0] and k[2] == counter]
+    if not c:
+        return None, None
+    k, v = max(c, key=lambda kv: kv[0][1]) if biggest else min(c, key=lambda kv: kv[0][1])
+    return k, sum(v) / len(v) * 1024.0
+
+
+# calibration: float2 streaming stores in the STFT layout (microbench store_kernel<2>, 262144 rows x 16376 B)
+k, w = pick(wm, "store_kernel<2>", "WRITE_SIZE")
+known_w = 262144 * 4094 * 4.0
+# three cases share the kernel name; take the mean over all (two of three write 16384-B rows)
+vals = [sum(v) / len(v) * 1024.0 for kk, v in wm.items() if "store_kernel<2>" in kk[0] and kk[2] == "WRITE_SIZE"]
+out["calib_write_float2"] = {"counter_bytes_mean": sum(vals) / len(vals) if vals else None,
+                             "known_bytes_range": [known_w, 262144 * 4096 * 4.0]}
+k, f = pick(fm, "copy_kernel", "FETCH_SIZE")
+out["calib_fetch_float4_copy"] = {"counter_bytes": f, "known_bytes": 262144 * 4096 * 4.0,
+                                  "ratio": (f / (262144 * 4096 * 4.0)) if f else None}
+# checksum kernel in bench.py reads 4096 frames * 16376 B with 4-byte loads
+k, f = pick(fb, "checksum_kernel", "FETCH_SIZE")
+out["calib_fetch_dword"] = {"counter_bytes": f, "known_bytes": 4096 * 16376.0, "ratio": (f / (4096 * 16376.0)) if f else None}
+
+k, w = pick(wb, "stft4096_wg_kernel<true, true, false, false>", "WRITE_SIZE")
+k2, f = pick(fb, "stft4096_wg_kernel<true, true, false, false>", "FETCH_SIZE")
+out["stft_raw"] = {"WRITE_SIZE_bytes": w, "FETCH_SIZE_bytes": f, "grid": k[1] if k else None}
+k, w = pick(wb, "stft4096_wg_kernel<true, true, false, true>", "WRITE_SIZE")
+k2, f = pick(fb, "stft4096_wg_kernel<true, true, false, true>", "FETCH_SIZE")
+out["render_fused_raw"] = {"WRITE_SIZE_bytes": w, "FETCH_SIZE_bytes": f, "grid": k[1] if k else None}
+print(json.dumps(out, indent=1))

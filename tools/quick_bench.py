@@ -27,11 +27,12 @@ def main():
     ap.add_argument("--frames", type=int, default=200_000)
     ap.add_argument("--generic", action="store_true")
     ap.add_argument("--render", action="store_true")
+    ap.add_argument("--packed", action="store_true")
     args = ap.parse_args()
     F = args.frames
     for ch in (1, 2):
         eng = SpectrogramEngine(48000.0, window_samples=2048, hop_samples=256, channels=ch, force_generic=args.generic,
-                                gradient="viridis")
+                                gradient="viridis", packed_kernel=args.packed)
         n = (F - 1) * eng.H + eng.W
         pcm = eng.white_noise(n)
         out = torch.empty((F, 1, eng.M, 2), dtype=torch.float32, device="cuda")
