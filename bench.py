@@ -38,9 +38,9 @@ KERNEL_NAMES = {
     0: ("generic power-of-two (workgroup per frame, LDS radix-2)", "sgx::stft_generic_kernel"),
     1: ("stft4096 wave-per-transform", "sgx::stft4096_kernel<6, true>"),
     2: ("stft4096 workgroup-per-transform (256 threads x 16 points, radix-16 x3, mono frame pairs), scalar codelets",
-        "sgx::wg::stft4096_wg_kernel<true, 2, false, false>"),
+        "sgx::wg::stft4096_wg_kernel<true, 0, false, false>"),
     3: ("stft4096 workgroup-per-transform (256 threads x 16 points, radix-16 x3, mono frame pairs), packed (re, im) codelets",
-        "sgx::wgp::stft4096_wgp_kernel<true, 2, false, false>"),
+        "sgx::wgp::stft4096_wgp_kernel<true, 0, false, false>"),
 }
 
 
@@ -217,7 +217,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": (traffic or {}).get("stft_bytes_per_launch"),
+                "traffic": ((traffic or {}).get("stft_bytes_per_frame") or 0) * F or None,
                 "kernel": KERNEL_NAMES[eng.info.stft_kernel][1],
                 "launch_ms": kernel_ms, "bytes_per_frame": ALGO_BYTES_STFT, "frames_per_launch": F,
             },

@@ -44,10 +44,10 @@ out["calib_fetch_float4_copy"] = {"counter_bytes": f, "known_bytes": 262144 * 40
 k, f = pick(fb, "checksum_kernel", "FETCH_SIZE")
 out["calib_fetch_dword"] = {"counter_bytes": f, "known_bytes": 4096 * 16376.0, "ratio": (f / (4096 * 16376.0)) if f else None}
 
-k, w = pick(wb, "stft4096_wg_kernel<true, true, false, false>", "WRITE_SIZE")
-k2, f = pick(fb, "stft4096_wg_kernel<true, true, false, false>", "FETCH_SIZE")
+k, w = pick(wb, "stft4096_wg_kernel<true, 0, false, false>", "WRITE_SIZE")
+k2, f = pick(fb, "stft4096_wg_kernel<true, 0, false, false>", "FETCH_SIZE")
 out["stft_raw"] = {"WRITE_SIZE_bytes": w, "FETCH_SIZE_bytes": f, "grid": k[1] if k else None}
-k, w = pick(wb, "stft4096_wg_kernel<true, true, false, true>", "WRITE_SIZE")
-k2, f = pick(fb, "stft4096_wg_kernel<true, true, false, true>", "FETCH_SIZE")
+k, w = pick(wb, "stft4096_wg_kernel<true, 0, false, true>", "WRITE_SIZE")
+k2, f = pick(fb, "stft4096_wg_kernel<true, 0, false, true>", "FETCH_SIZE")
 out["render_fused_raw"] = {"WRITE_SIZE_bytes": w, "FETCH_SIZE_bytes": f, "grid": k[1] if k else None}
 print(json.dumps(out, indent=1))
