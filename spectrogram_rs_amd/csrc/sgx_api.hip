@@ -91,6 +91,7 @@ int ensure_workspace(sgx_ctx *c, size_t frames)
 hipError_t run_stft(const sgx_ctx *c, const float *d_pcm, uint32_t channels, uint32_t pairs, size_t first, size_t n,
                     float *d_mags)
 {
+    if (c->stft_kernel == 4) return sgx::launch_stft_bluestein(c, c->d_blu, d_pcm, channels, pairs, first, n, d_mags);
     if (c->stft_kernel == 3) return sgx::launch_stft_wgp4096(c, c->d_fast_wg, d_pcm, channels, pairs, first, n, d_mags);
     if (c->stft_kernel == 2) return sgx::launch_stft_wg4096(c, c->d_fast_wg, d_pcm, channels, pairs, first, n, d_mags);
     if (c->stft_kernel == 1) return sgx::launch_stft_fast4096(c, d_pcm, channels, pairs, first, n, d_mags);
@@ -167,10 +168,11 @@ int sgx_create(const sgx_config *cfg, sgx_ctx **out_ctx)
     if (cfg->interp > SGX_INTERP_COSINE) return bail(SGX_ERR_INVALID_ARG, "sgx_create: unknown interpolation");
     if (cfg->lut_index_mode > SGX_LUT_ROUND_NM1) return bail(SGX_ERR_INVALID_ARG, "sgx_create: unknown lut_index_mode");
     if (c->sr_u32 == 0) return bail(SGX_ERR_INVALID_ARG, "sgx_create: sample_rate must be at least 1 Hz");
-    if ((c->P & (c->P - 1)) != 0 || c->P > 16384)
+    const bool pow2 = (c->P & (c->P - 1)) == 0 && c->P <= 16384;
+    if (!pow2 && !sgx::bluestein_supported(c->W))
         return bail(SGX_ERR_UNSUPPORTED,
                     "sgx_create: transform length 2W = " + std::to_string(c->P) +
-                        " is not supported by this build (power of two, at most 16384)");
+                        " is not supported by this build (power of two up to 16384, or any 2W with 3W - 1 <= 16384)");
     c->logP = 0;
     while ((1u << c->logP) < c->P) ++c->logP;
 
@@ -201,7 +203,11 @@ int sgx_create(const sgx_config *cfg, sgx_ctx **out_ctx)
     if (rc != SGX_OK) { std::string m = c->err; return bail(rc, m); }
 
     c->stft_kernel = 0;
-    if (!(cfg->flags & SGX_FLAG_FORCE_GENERIC) && sgx::fast4096_supported(c)) {
+    if (!pow2) {
+        e = sgx::bluestein_init(c, &c->d_blu);
+        if (e != hipSuccess) return bail(SGX_ERR_HIP, std::string("sgx_create: Bluestein tables: ") + hipGetErrorString(e));
+        c->stft_kernel = 4;
+    } else if (!(cfg->flags & SGX_FLAG_FORCE_GENERIC) && sgx::fast4096_supported(c)) {
         e = sgx::fast4096_init(c);
         if (e != hipSuccess) return bail(SGX_ERR_HIP, std::string("sgx_create: tuned kernel tables: ") + hipGetErrorString(e));
         e = sgx::wg4096_init(c, &c->d_fast_wg);
@@ -219,6 +225,8 @@ void sgx_destroy(sgx_ctx *c)
     sgx::fast4096_destroy(c);
     sgx::wg4096_destroy(c->d_fast_wg);
     c->d_fast_wg = nullptr;
+    sgx::bluestein_destroy(c->d_blu);
+    c->d_blu = nullptr;
     void *ptrs[] = {c->d_window, c->d_twiddle, c->d_rows, c->d_samples, c->d_lut_thr, c->d_alpha_thr,
                     c->d_lut_rgba, c->d_ws_mags, c->d_one_in, c->d_one_out, c->d_cksum};
     for (void *p : ptrs)

@@ -62,7 +62,7 @@ struct sgx_ctx {
     uint32_t W = 0, P = 0, M = 0, H = 0, C = 0, pairs = 0, R = 0, sr_u32 = 0, logP = 0;
     int device = 0;
     hipStream_t stream = nullptr;
-    int stft_kernel = 0;  // 0 generic, 1 tuned 4096 wave-per-transform, 2 tuned 4096 workgroup-per-transform (scalar codelets), 3 the same with packed (re, im) arithmetic
+    int stft_kernel = 0;  // 0 generic, 1 tuned 4096 wave-per-transform, 2 tuned 4096 workgroup-per-transform (scalar codelets), 3 the same with packed (re, im) arithmetic, 4 Bluestein (2W not a power of two)
 
     sgx::Tables tab;
     sgx::Palette pal;
@@ -77,6 +77,7 @@ struct sgx_ctx {
     uchar4 *d_lut_rgba = nullptr;  // [n]
     void *d_fast = nullptr;        // tables of the wave-per-transform kernel (opaque here)
     void *d_fast_wg = nullptr;     // tables of the workgroup-per-transform kernel
+    void *d_blu = nullptr;         // tables of the Bluestein (non-power-of-two) kernel
 
     // workspaces (grown on demand, kept)
     float *d_ws_mags = nullptr;
@@ -108,6 +109,11 @@ hipError_t launch_stft_wgp4096(const sgx_ctx *c, const void *tables, const float
                                size_t first_frame, size_t n_frames, float *d_mags);
 hipError_t launch_render_wgp4096(const sgx_ctx *c, const void *tables, const float *d_pcm, uint32_t channels, uint32_t pairs,
                                  size_t first_frame, size_t n_frames, uint8_t *d_rgba);
+bool bluestein_supported(uint32_t W);
+hipError_t bluestein_init(sgx_ctx *c, void **out);
+void bluestein_destroy(void *tables);
+hipError_t launch_stft_bluestein(const sgx_ctx *c, const void *tables, const float *d_pcm, uint32_t channels, uint32_t pairs,
+                                 size_t first_frame, size_t n_frames, float *d_mags);
 hipError_t launch_render(const sgx_ctx *c, const float *d_mags, size_t n_columns, uint8_t *d_rgba);
 hipError_t launch_white_noise(const sgx_ctx *c, float *d_out, uint64_t first, size_t n, uint32_t channels, uint32_t seed);
 hipError_t launch_checksum(const sgx_ctx *c, const uint32_t *d_words, size_t n_words, uint64_t base_word,

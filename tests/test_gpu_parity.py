@@ -114,8 +114,34 @@ def test_process_one_mirrors_process(torch_cuda, mags_err):
 def test_unsupported_length_is_reported_not_approximated(torch_cuda):
     from spectrogram_rs_amd import SgxError
     with pytest.raises(SgxError) as ei:
-        engine(period=0.05)  # W = 2400, P = 4800: not a power of two
-    assert ei.value.code == -2 and "4800" in str(ei.value)
+        engine(window_samples=6000)  # 2W = 12000 is not a power of two and 3W - 1 > 16384
+    assert ei.value.code == -2 and "12000" in str(ei.value)
+    with pytest.raises(SgxError):
+        engine(window_samples=16384)  # 2W = 32768 does not fit the LDS
+
+
+@pytest.mark.parametrize("sr,period,Wexp", [(48000.0, 0.05, 2400), (44100.0, 0.05, 2205), (48000.0, 0.01, 480), (8000.0, 0.0125, 100)])
+def test_duration_sized_windows_like_the_app(torch_cuda, mags_err, sr, period, Wexp):
+    # FastFourierTransform::new(sample_rate, 0.05) (gpu_spectrogram.rs:323): W = 2400 / 2205, 2W not a power of two
+    torch = torch_cuda
+    from spectrogram_rs_amd import SpectrogramEngine
+    eng = SpectrogramEngine(sr, period=period, stride=2.0 / 1024, channels=2)
+    assert eng.W == Wexp == oracle.window_samples(sr, period) and eng.info.stft_kernel == 4
+    Ht = eng.H
+    assert Ht == oracle.hop_samples(sr, 2.0 / 1024)
+    n = Wexp + 12 * Ht + 5
+    pcm = oracle.white_noise(2 * n, seed=13)
+    got = eng.stft_batch(to_dev(torch, pcm)).cpu().numpy()
+    ref = oracle.stream_process(pcm, 2, Wexp, Ht, threads=8)
+    assert got.shape == ref.shape == (13, 1, Wexp - 1, 2)
+    truth = np.stack([oracle.np_truth_frame(pcm.reshape(-1, 2)[t * Ht:t * Ht + Wexp], Wexp) for t in (0, 7, 12)])
+    assert mags_err(got[[0, 7, 12], 0], truth) <= 2.0   # chirp-z: two FFTs + three chirp products in float32
+    assert mags_err(got, ref) <= 3.0
+    # the pixel path rides on it (two-kernel route) and is bit-exact on the engine's own magnitudes
+    eng.set_builtin_gradient("viridis")
+    rgba = eng.render_batch(to_dev(torch, pcm)).cpu().numpy()
+    own = oracle.render_columns(got[:, 0], int(sr), np.load(os.path.join(os.path.dirname(__file__), "golden", "gradients.npz"))["viridis"])
+    assert np.array_equal(rgba[:, 0], own)
 
 
 def test_stream_wrapper_on_gpu(torch_cuda, mags_err):
