@@ -79,10 +79,18 @@ def main():
             raise SystemExit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU fallback"
+    # rehearsal knobs (one-GPU box): BENCH_BACKEND=gloo BENCH_SINGLE_DEVICE=1 run every rank on cuda:0 so
+    # that the N > 1 control flow can be exercised without a second GPU; the driver never sets them
+    backend = os.environ.get("BENCH_BACKEND", "nccl")
+    if os.environ.get("BENCH_SINGLE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from spectrogram_rs_amd import SpectrogramEngine
     from spectrogram_rs_amd.sharding import chunks, frame_range, gather_columns, sample_range
@@ -117,7 +125,8 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     kernel_ms = sum(a.elapsed_time(b) for a, b in evs) / max(len(evs), 1)
-    t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=eng.device)
+    red_dev = eng.device if backend == "nccl" else "cpu"
+    t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed, kernel_ms = float(t[0]), float(t[1])
@@ -154,7 +163,7 @@ def main():
             pixel_pass()
         torch.cuda.synchronize()
         barrier()
-        tp = torch.tensor([time.perf_counter() - tp0], dtype=torch.float64, device=eng.device)
+        tp = torch.tensor([time.perf_counter() - tp0], dtype=torch.float64, device=red_dev)
         if world > 1:
             dist.all_reduce(tp, op=dist.ReduceOp.MAX)
         fps = world * Fp * reps / float(tp[0])

@@ -49,6 +49,9 @@ def gather_columns(local, counts: List[int], dst: int = 0, chunk: int = 65536,
 
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     assert len(counts) == world and counts[rank] == local.shape[0]
+    # gloo moves host memory only: stage device tensors through the host there (rehearsals, CPU tests);
+    # with nccl (RCCL) the pieces go GPU to GPU over xGMI
+    staged = local.is_cuda and dist.get_backend(group) != "nccl"
     starts = [sum(counts[:r]) for r in range(world)]
     rounds = max((c + chunk - 1) // chunk for c in counts) if counts else 0
     kept = [[] for _ in range(world)]
@@ -63,14 +66,17 @@ def gather_columns(local, counts: List[int], dst: int = 0, chunk: int = 65536,
                 if r == dst:
                     piece = mine
                 else:
-                    piece = torch.empty((n_r,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+                    piece = torch.empty((n_r,) + tuple(local.shape[1:]), dtype=local.dtype,
+                                        device="cpu" if staged else local.device)
                     dist.recv(piece, src=r, group=group)
+                    if staged:
+                        piece = piece.to(local.device)
                 if consume is not None:
                     consume(starts[r] + c0, piece)
                 else:
                     kept[r].append(piece.clone() if r == dst else piece)
         elif mine.shape[0] > 0:
-            dist.send(mine.contiguous(), dst=dst, group=group)
+            dist.send(mine.cpu() if staged else mine.contiguous(), dst=dst, group=group)
     if rank == dst and consume is None:
         flat = [p for r in range(world) for p in kept[r]]
         return torch.cat(flat) if flat else local[:0]

@@ -48,5 +48,33 @@ def main():
             print(f"render_mags only: median {med:.3f} ms -> {F / med / 1e3:.1f} M columns/s", flush=True)
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "--extra" not in sys.argv:
     main()
+
+
+def config4(frames=20000):
+    """BASELINE config 4: 16384-point STFT, hop 512, 8 interleaved channels (4 pairs)"""
+    eng = SpectrogramEngine(48000.0, window_samples=8192, hop_samples=512, channels=8)
+    n = (frames - 1) * eng.H + eng.W
+    pcm = eng.white_noise(n)
+    out = torch.empty((frames, 4, eng.M, 2), dtype=torch.float32, device="cuda")
+    med, best = timeit(lambda: eng.stft_batch(pcm, out=out), iters=5)
+    byts = frames * (512 * 8 * 4 + 4 * eng.M * 8)
+    print(f"config4 kernel={eng.info.stft_kernel} hops={frames}: median {med:.3f} ms -> {frames / med / 1e3:.3f} M hop positions/s "
+          f"({4 * frames / med / 1e3:.3f} M transforms/s), {byts / med / 1e6:.1f} GB/s algorithmic", flush=True)
+
+
+def app_default(frames=20000):
+    """the app's own operating point: 0.05 s window at 48 kHz (W 2400, Bluestein), hop 93, stereo"""
+    eng = SpectrogramEngine(48000.0, period=0.05, stride=2.0 / 1024, channels=2)
+    n = (frames - 1) * eng.H + eng.W
+    pcm = eng.white_noise(n)
+    out = torch.empty((frames, 1, eng.M, 2), dtype=torch.float32, device="cuda")
+    med, best = timeit(lambda: eng.stft_batch(pcm, out=out), iters=5)
+    print(f"app default W={eng.W} H={eng.H} kernel={eng.info.stft_kernel}: median {med:.3f} ms -> {frames / med / 1e3:.3f} M frames/s "
+          f"(real time is {48000 / eng.H:.0f} frames/s)", flush=True)
+
+
+if __name__ == "__main__" and "--extra" in sys.argv:
+    config4()
+    app_default()
