@@ -84,6 +84,8 @@ typedef struct sgx_config {
 #define SGX_FLAG_FORCE_GENERIC 1u /* use the generic power-of-two kernel even where a tuned one exists (testing) */
 #define SGX_FLAG_NO_FUSED_RENDER 4u /* sgx_render_batch: run STFT and pixel stage as two kernels even where the fused one applies (A/B) */
 #define SGX_FLAG_PACKED_KERNEL 8u  /* W = 2048: workgroup-per-transform kernel with packed (re, im) arithmetic instead of scalar (A/B) */
+#define SGX_FLAG_INDEPENDENT_FRAMES 16u /* mono: one transform per frame (the reference's (s, s) dataflow) instead of two frames
+                                           per transform; half the throughput, no cross-frame rounding floor */
 #define SGX_FLAG_WAVE_KERNEL 2u   /* W = 2048: use the wave-per-transform kernel instead of the workgroup-per-transform one (A/B) */
 
 typedef struct sgx_info {

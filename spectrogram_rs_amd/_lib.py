@@ -24,6 +24,7 @@ FLAG_FORCE_GENERIC = 1
 FLAG_WAVE_KERNEL = 2
 FLAG_NO_FUSED_RENDER = 4
 FLAG_PACKED_KERNEL = 8
+FLAG_INDEPENDENT_FRAMES = 16
 
 
 class SgxError(RuntimeError):

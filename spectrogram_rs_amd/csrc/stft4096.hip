@@ -276,7 +276,7 @@ hipError_t launch_stft_fast4096(const sgx_ctx *c, const float *d_pcm, uint32_t c
         p.pair = pair;
         p.pair_l = channels == 1 ? 0 : 2 * pair;
         p.pair_r = channels == 1 ? 0 : 2 * pair + 1;
-        const bool mono = channels == 1;
+        const bool mono = channels == 1 && !(c->cfg.flags & SGX_FLAG_INDEPENDENT_FRAMES);
         p.n_jobs = mono ? (n_frames + 1) / 2 : n_frames;
         // one persistent workgroup per CU; each owns a contiguous run of jobs, a multiple of the
         // wave count so that its waves stay on neighbouring frames (shared audio stays in L1)

@@ -450,7 +450,8 @@ hipError_t launch_wg(const sgx_ctx *c, const void *tables, const float *d_pcm, u
             p.guess_a = (float)(10.0 * log10(2.0) * n / span);
             p.guess_b = (float)(-(double)c->cfg.min_db * n / span + (c->cfg.lut_index_mode == SGX_LUT_ROUND_NM1 ? 0.5 : 0.0));
         }
-        const bool mono = channels == 1;
+        // mono normally rides two frames per transform; SGX_FLAG_INDEPENDENT_FRAMES runs it as (s, s) pairs
+        const bool mono = channels == 1 && !(c->cfg.flags & SGX_FLAG_INDEPENDENT_FRAMES);
         p.n_jobs = mono ? (n_frames + 1) / 2 : n_frames;
         // persistent workgroups, 4 per CU; each owns a contiguous run of transforms so that the
         // overlapping audio of consecutive frames is re-read from L1/L2, not HBM

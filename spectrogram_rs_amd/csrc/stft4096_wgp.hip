@@ -363,7 +363,8 @@ hipError_t launch_wgp(const sgx_ctx *c, const void *tables, const float *d_pcm, 
             p.guess_a = (float)(10.0 * log10(2.0) * n / span);
             p.guess_b = (float)(-(double)c->cfg.min_db * n / span + (c->cfg.lut_index_mode == SGX_LUT_ROUND_NM1 ? 0.5 : 0.0));
         }
-        const bool mono = channels == 1;
+        // mono normally rides two frames per transform; SGX_FLAG_INDEPENDENT_FRAMES runs it as (s, s) pairs
+        const bool mono = channels == 1 && !(c->cfg.flags & SGX_FLAG_INDEPENDENT_FRAMES);
         p.n_jobs = mono ? (n_frames + 1) / 2 : n_frames;
         unsigned long long blocks = (unsigned long long)n_cu * 4;
         unsigned long long per = (p.n_jobs + blocks - 1) / blocks;

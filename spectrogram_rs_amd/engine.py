@@ -20,7 +20,8 @@ class SpectrogramEngine:
                  f_min: float = 32.0, f_max: float = 22030.0, min_db: float = -70.0, max_db: float = -10.0,
                  interp: int = _lib.INTERP_CUBIC, lut_index_mode: int = _lib.LUT_FLOOR_N,
                  device: Optional[int] = None, force_generic: bool = False, gradient: Optional[str] = None,
-                 wave_kernel: bool = False, fused_render: bool = True, packed_kernel: bool = False):
+                 wave_kernel: bool = False, fused_render: bool = True, packed_kernel: bool = False,
+                 independent_frames: bool = False):
         import torch
 
         self._lib = _lib.load()
@@ -40,7 +41,8 @@ class SpectrogramEngine:
         cfg.interp, cfg.lut_index_mode = interp, lut_index_mode
         cfg.device = -1 if device is None else int(device)
         cfg.flags = (_lib.FLAG_FORCE_GENERIC if force_generic else 0) | (_lib.FLAG_WAVE_KERNEL if wave_kernel else 0) \
-            | (0 if fused_render else _lib.FLAG_NO_FUSED_RENDER) | (_lib.FLAG_PACKED_KERNEL if packed_kernel else 0)
+            | (0 if fused_render else _lib.FLAG_NO_FUSED_RENDER) | (_lib.FLAG_PACKED_KERNEL if packed_kernel else 0) \
+            | (_lib.FLAG_INDEPENDENT_FRAMES if independent_frames else 0)
         if device is not None and torch.cuda.is_available():
             torch.cuda.set_device(int(device))
         rc = self._lib.sgx_create(C.byref(cfg), C.byref(self._ctx))

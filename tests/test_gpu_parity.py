@@ -293,6 +293,72 @@ def test_fused_kernel_equals_two_kernel_path(torch_cuda, channels, frames, inter
     assert np.array_equal(fused.render_batch(pcm).cpu().numpy(), split.render_batch(pcm).cpu().numpy())
 
 
+@pytest.mark.parametrize("cfg", [
+    dict(rows=1000, f_min=20.0, f_max=24000.0, min_db=-90.0, max_db=0.0, interp=0),      # rows not a multiple of 256, f_max at Nyquist
+    dict(rows=7, f_min=100.0, f_max=8000.0, min_db=-60.0, max_db=-20.0, interp=1),        # fewer rows than threads
+    dict(rows=2048, f_min=32.0, f_max=22030.0, min_db=-70.0, max_db=-10.0, interp=0, lut_index_mode=1),  # round-to-nearest LUT rule
+    dict(rows=300, f_min=1.0, f_max=90000.0, min_db=-70.0, max_db=-10.0, interp=0),       # axis far outside the spectrum: index clamps at both ends
+])
+def test_pixel_path_configuration_space(torch_cuda, gradients, cfg):
+    # fused kernel, two-kernel path and oracle agree for every axis / dB range / LUT rule (on the engine's own magnitudes)
+    torch = torch_cuda
+    pcm = to_dev(torch, oracle.white_noise(W + 20 * H, seed=101) * np.float32(0.2))
+    kw = dict(window_samples=W, hop_samples=H, channels=1, gradient="inferno", **cfg)
+    fused, split = engine(**kw), engine(fused_render=False, **kw)
+    a = fused.render_batch(pcm).cpu().numpy()[:, 0]
+    b = split.render_batch(pcm).cpu().numpy()[:, 0]
+    mags = fused.stft_batch(pcm).cpu().numpy()[:, 0]
+    ref = oracle.render_columns(mags, SR, gradients["inferno"], R=cfg["rows"], f_min=cfg["f_min"], f_max=cfg["f_max"],
+                                interp=cfg["interp"], min_db=cfg["min_db"], max_db=cfg["max_db"], mode=cfg.get("lut_index_mode", 0))
+    assert a.shape == ref.shape == (21, cfg["rows"], 4)
+    assert np.array_equal(a, b) and np.array_equal(a, ref)
+    assert np.array_equal(fused.bin_edges(), oracle.bin_edges(cfg["rows"], cfg["f_min"], cfg["f_max"]))
+
+
+def test_non_finite_and_extreme_samples(torch_cuda, gradients):
+    # NaN / inf / huge samples must not fault or poison neighbouring frames; colours follow Rust's
+    # saturating casts (NaN -> index 0); frames without bad samples are unaffected
+    torch = torch_cuda
+    x = oracle.white_noise(W + 40 * H, seed=5) * np.float32(0.1)
+    bad = x.copy()
+    bad[W + 20 * H + 5] = np.nan          # touches frames 13..28 (every frame whose window covers it)
+    bad[100] = np.float32(3e38)           # frame 0 only (sample 100 < H): overflows to inf in the FFT
+    eng = engine(window_samples=W, hop_samples=H, channels=1, gradient="viridis")
+    good_m = eng.stft_batch(to_dev(torch, x)).cpu().numpy()
+    bad_m = eng.stft_batch(to_dev(torch, bad)).cpu().numpy()
+    touched = np.zeros(41, bool)
+    touched[0] = True
+    n_idx = W + 20 * H + 5
+    touched[[t for t in range(41) if t * H <= n_idx < t * H + W]] = True
+    # a mono transform carries frames 2j and 2j+1 (real / imaginary part): a non-finite sample also
+    # reaches the partner frame of the same transform -- exactly as a non-finite LEFT sample reaches the
+    # RIGHT channel of its frame in the reference's own (l + i r) packing (fft.rs:57,87-88)
+    touched = touched | np.array([touched[min(t ^ 1, 40)] for t in range(41)])
+    assert np.array_equal(bad_m[~touched], good_m[~touched])
+    assert not np.isfinite(bad_m[touched]).all()
+    rg = eng.render_batch(to_dev(torch, bad)).cpu().numpy()[:, 0]
+    ref = oracle.render_columns(bad_m[:, 0], SR, gradients["viridis"])
+    assert np.array_equal(rg, ref)
+
+
+def test_frame_pairing_dynamic_range_and_independent_frames(torch_cuda, mags_err):
+    # A mono transform carries two frames; float32 rounding of the louder one is the noise floor of the
+    # quieter one (as left / right share one transform in the reference).  Frames that share 7/8 of their
+    # samples are never far apart in level -- except across an isolated transient.  With
+    # independent_frames=True every frame gets its own transform, exactly the reference's dataflow.
+    torch = torch_cuda
+    x = oracle.white_noise(W + 3 * H, seed=9) * np.float32(1e-3)
+    x[10] = 1.0                                  # a click inside frame 0 only (sample 10 < H)
+    ref = np.stack([oracle.np_truth_frame(np.stack([x[t * H:t * H + W]] * 2, 1), W) for t in range(4)])
+    paired = engine(window_samples=W, hop_samples=H, channels=1).stft_batch(to_dev(torch, x)).cpu().numpy()[:, 0]
+    indep = engine(window_samples=W, hop_samples=H, channels=1, independent_frames=True).stft_batch(to_dev(torch, x)).cpu().numpy()[:, 0]
+    assert mags_err(indep, ref) <= 1.0                       # every frame within tolerance of the truth
+    assert mags_err(paired[[0, 2, 3]], ref[[0, 2, 3]]) <= 1.0
+    # frame 1 rides with the click: its error is bounded relative to the PAIR's peak, not its own
+    pair_peak = np.abs(ref[:2]).max()
+    assert np.abs(paired[1] - ref[1]).max() <= 1e-6 * pair_peak
+
+
 def test_lookup_table_and_widget_ring(torch_cuda, gradients):
     torch = torch_cuda
     from spectrogram_rs_amd import ColorScheme, RingBuffer, SimpleSpectrogram
