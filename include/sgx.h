@@ -149,6 +149,14 @@ SGX_API int sgx_sync(sgx_ctx *ctx);
 SGX_API int sgx_stft_batch(sgx_ctx *ctx, const float *d_pcm, size_t n_samples, size_t first_frame,
                            size_t max_frames, float *d_mags, size_t *n_out);
 
+/* The same transform with the magnitudes stored as IEEE half (l, r) pairs, 4 bytes per bin
+ * (round to nearest even): d_mags_f16 [n_out][pairs][M][2] half.  This is the texel format of the
+ * F16F16 ring texture the default widget uploads its frames into (gpu_spectrogram.rs:218-226,
+ * 268-274: rows of M texels), so a GL-interop consumer can take the rows as they are; it also
+ * halves the bytes the transform writes. */
+SGX_API int sgx_stft_batch_f16(sgx_ctx *ctx, const float *d_pcm, size_t n_samples, size_t first_frame,
+                               size_t max_frames, void *d_mags_f16, size_t *n_out);
+
 /* One call of AudioTransform::process (audio_transform.rs:10, fft.rs:43) on HOST buffers, for a
  * per-frame shim: h_lr [n_avail][2] (l, r) pairs, h_out [M][2].  Returns 1 (Some), 0 (None:
  * n_avail < W) or a negative sgx_status.  Synchronous. */

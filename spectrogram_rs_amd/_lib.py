@@ -87,6 +87,7 @@ SIGNATURES = [
     ("sgx_set_stream", C.c_int, [_ctx, _vp]),
     ("sgx_sync", C.c_int, [_ctx]),
     ("sgx_stft_batch", C.c_int, [_ctx, _vp, _sz, _sz, _sz, _vp, C.POINTER(_sz)]),
+    ("sgx_stft_batch_f16", C.c_int, [_ctx, _vp, _sz, _sz, _sz, _vp, C.POINTER(_sz)]),
     ("sgx_process_one", C.c_int, [_ctx, _vp, _sz, _vp]),
     ("sgx_render_batch", C.c_int, [_ctx, _vp, _sz, _sz, _sz, _vp, C.POINTER(_sz)]),
     ("sgx_render_mags", C.c_int, [_ctx, _vp, _sz, _vp]),

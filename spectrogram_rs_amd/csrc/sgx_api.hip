@@ -88,13 +88,14 @@ int ensure_workspace(sgx_ctx *c, size_t frames)
     return SGX_OK;
 }
 
+// `total`: frames the stream holds (mono transforms carry frame pairs and pair by global index)
 hipError_t run_stft(const sgx_ctx *c, const float *d_pcm, uint32_t channels, uint32_t pairs, size_t first, size_t n,
-                    float *d_mags)
+                    size_t total, float *d_mags)
 {
     if (c->stft_kernel == 4) return sgx::launch_stft_bluestein(c, c->d_blu, d_pcm, channels, pairs, first, n, d_mags);
-    if (c->stft_kernel == 3) return sgx::launch_stft_wgp4096(c, c->d_fast_wg, d_pcm, channels, pairs, first, n, d_mags);
-    if (c->stft_kernel == 2) return sgx::launch_stft_wg4096(c, c->d_fast_wg, d_pcm, channels, pairs, first, n, d_mags);
-    if (c->stft_kernel == 1) return sgx::launch_stft_fast4096(c, d_pcm, channels, pairs, first, n, d_mags);
+    if (c->stft_kernel == 3) return sgx::launch_stft_wgp4096(c, c->d_fast_wg, d_pcm, channels, pairs, first, n, total, d_mags);
+    if (c->stft_kernel == 2) return sgx::launch_stft_wg4096(c, c->d_fast_wg, d_pcm, channels, pairs, first, n, total, d_mags);
+    if (c->stft_kernel == 1) return sgx::launch_stft_fast4096(c, d_pcm, channels, pairs, first, n, total, d_mags);
     return sgx::launch_stft_generic(c, d_pcm, channels, pairs, first, n, d_mags);
 }
 
@@ -288,8 +289,42 @@ int sgx_stft_batch(sgx_ctx *c, const float *d_pcm, size_t n_samples, size_t firs
     if (n > max_frames) n = max_frames;
     if (!d_pcm || !d_mags) return fail(c, SGX_ERR_INVALID_ARG, "sgx_stft_batch: null buffer");
     SGX_HIP(c, hipSetDevice(c->device));
-    hipError_t e = run_stft(c, d_pcm, c->C, c->pairs, first_frame, n, d_mags);
+    hipError_t e = run_stft(c, d_pcm, c->C, c->pairs, first_frame, n, total, d_mags);
     if (e != hipSuccess) return fail_hip(c, e, "sgx_stft_batch: kernel launch");
+    if (n_out) *n_out = n;
+    return SGX_OK;
+}
+
+int sgx_stft_batch_f16(sgx_ctx *c, const float *d_pcm, size_t n_samples, size_t first_frame, size_t max_frames,
+                       void *d_mags_f16, size_t *n_out)
+{
+    if (n_out) *n_out = 0;
+    if (!c) return SGX_ERR_INVALID_ARG;
+    const size_t total = sgx_num_frames(c, n_samples);
+    if (first_frame >= total || max_frames == 0) return SGX_OK;
+    size_t n = total - first_frame;
+    if (n > max_frames) n = max_frames;
+    if (!d_pcm || !d_mags_f16) return fail(c, SGX_ERR_INVALID_ARG, "sgx_stft_batch_f16: null buffer");
+    SGX_HIP(c, hipSetDevice(c->device));
+    if (c->stft_kernel == 2) {
+        hipError_t e = sgx::launch_stft_wg4096_f16(c, c->d_fast_wg, d_pcm, c->C, c->pairs, first_frame, n, total, d_mags_f16);
+        if (e != hipSuccess) return fail_hip(c, e, "sgx_stft_batch_f16: kernel launch");
+    } else {
+        // kernels without a native half store: float32 into the bounded workspace, then one conversion pass
+        const size_t per_frame = (size_t)c->pairs * c->M;  // (l, r) pairs per frame
+        size_t chunk = (size_t)(192u << 20) / (per_frame * 8);
+        if (chunk < 1) chunk = 1;
+        if (chunk > n) chunk = n;
+        int rc = ensure_workspace(c, chunk);
+        if (rc != SGX_OK) return rc;
+        for (size_t done = 0; done < n; done += chunk) {
+            const size_t m = n - done < chunk ? n - done : chunk;
+            hipError_t e = run_stft(c, d_pcm, c->C, c->pairs, first_frame + done, m, total, c->d_ws_mags);
+            if (e == hipSuccess)
+                e = sgx::launch_to_half(c, c->d_ws_mags, static_cast<char *>(d_mags_f16) + done * per_frame * 4, m * per_frame);
+            if (e != hipSuccess) return fail_hip(c, e, "sgx_stft_batch_f16: kernel launch");
+        }
+    }
     if (n_out) *n_out = n;
     return SGX_OK;
 }
@@ -301,7 +336,7 @@ int sgx_process_one(sgx_ctx *c, const float *h_lr, size_t n_avail, float *h_out)
     if (!h_lr || !h_out) return fail(c, SGX_ERR_INVALID_ARG, "sgx_process_one: null buffer");
     SGX_HIP(c, hipSetDevice(c->device));
     SGX_HIP(c, hipMemcpyAsync(c->d_one_in, h_lr, (size_t)c->W * 2 * sizeof(float), hipMemcpyHostToDevice, c->stream));
-    hipError_t e = run_stft(c, c->d_one_in, 2, 1, 0, 1, c->d_one_out);
+    hipError_t e = run_stft(c, c->d_one_in, 2, 1, 0, 1, 1, c->d_one_out);
     if (e != hipSuccess) return fail_hip(c, e, "sgx_process_one: kernel launch");
     SGX_HIP(c, hipMemcpyAsync(h_out, c->d_one_out, (size_t)c->M * 2 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     SGX_HIP(c, hipStreamSynchronize(c->stream));
@@ -333,8 +368,8 @@ int sgx_render_batch(sgx_ctx *c, const float *d_pcm, size_t n_samples, size_t fi
     if (c->stft_kernel >= 2 && !(c->cfg.flags & SGX_FLAG_NO_FUSED_RENDER) && sgx::wg4096_can_fuse_render(c, c->d_fast_wg)) {
         // one kernel from PCM to pixels: magnitudes never leave LDS (5 120 B of HBM traffic per frame)
         hipError_t e = c->stft_kernel == 3
-                           ? sgx::launch_render_wgp4096(c, c->d_fast_wg, d_pcm, c->C, c->pairs, first_frame, n, d_rgba)
-                           : sgx::launch_render_wg4096(c, c->d_fast_wg, d_pcm, c->C, c->pairs, first_frame, n, d_rgba);
+                           ? sgx::launch_render_wgp4096(c, c->d_fast_wg, d_pcm, c->C, c->pairs, first_frame, n, total, d_rgba)
+                           : sgx::launch_render_wg4096(c, c->d_fast_wg, d_pcm, c->C, c->pairs, first_frame, n, total, d_rgba);
         if (e != hipSuccess) return fail_hip(c, e, "sgx_render_batch: fused launch");
         if (n_out) *n_out = n;
         return SGX_OK;
@@ -348,7 +383,7 @@ int sgx_render_batch(sgx_ctx *c, const float *d_pcm, size_t n_samples, size_t fi
     if (rc != SGX_OK) return rc;
     for (size_t done = 0; done < n; done += chunk) {
         const size_t m = n - done < chunk ? n - done : chunk;
-        hipError_t e = run_stft(c, d_pcm, c->C, c->pairs, first_frame + done, m, c->d_ws_mags);
+        hipError_t e = run_stft(c, d_pcm, c->C, c->pairs, first_frame + done, m, total, c->d_ws_mags);
         if (e != hipSuccess) return fail_hip(c, e, "sgx_render_batch: stft launch");
         e = sgx::launch_render(c, c->d_ws_mags, m * c->pairs, d_rgba + done * (size_t)c->pairs * c->R * 4);
         if (e != hipSuccess) return fail_hip(c, e, "sgx_render_batch: render launch");

@@ -97,23 +97,26 @@ bool fast4096_supported(const sgx_ctx *c);
 hipError_t fast4096_init(sgx_ctx *c);
 void fast4096_destroy(sgx_ctx *c);
 hipError_t launch_stft_fast4096(const sgx_ctx *c, const float *d_pcm, uint32_t channels, uint32_t pairs, size_t first_frame,
-                                size_t n_frames, float *d_mags);
+                                size_t n_frames, size_t total_frames, float *d_mags);
 hipError_t wg4096_init(sgx_ctx *c, void **out);
 void wg4096_destroy(void *tables);
 hipError_t launch_stft_wg4096(const sgx_ctx *c, const void *tables, const float *d_pcm, uint32_t channels, uint32_t pairs,
-                              size_t first_frame, size_t n_frames, float *d_mags);
+                              size_t first_frame, size_t n_frames, size_t total_frames, float *d_mags);
 bool wg4096_can_fuse_render(const sgx_ctx *c, const void *tables);
 hipError_t launch_render_wg4096(const sgx_ctx *c, const void *tables, const float *d_pcm, uint32_t channels, uint32_t pairs,
-                                size_t first_frame, size_t n_frames, uint8_t *d_rgba);
+                                size_t first_frame, size_t n_frames, size_t total_frames, uint8_t *d_rgba);
 hipError_t launch_stft_wgp4096(const sgx_ctx *c, const void *tables, const float *d_pcm, uint32_t channels, uint32_t pairs,
-                               size_t first_frame, size_t n_frames, float *d_mags);
+                               size_t first_frame, size_t n_frames, size_t total_frames, float *d_mags);
 hipError_t launch_render_wgp4096(const sgx_ctx *c, const void *tables, const float *d_pcm, uint32_t channels, uint32_t pairs,
-                                 size_t first_frame, size_t n_frames, uint8_t *d_rgba);
+                                 size_t first_frame, size_t n_frames, size_t total_frames, uint8_t *d_rgba);
 bool bluestein_supported(uint32_t W);
 hipError_t bluestein_init(sgx_ctx *c, void **out);
 void bluestein_destroy(void *tables);
 hipError_t launch_stft_bluestein(const sgx_ctx *c, const void *tables, const float *d_pcm, uint32_t channels, uint32_t pairs,
                                  size_t first_frame, size_t n_frames, float *d_mags);
+hipError_t launch_stft_wg4096_f16(const sgx_ctx *c, const void *tables, const float *d_pcm, uint32_t channels, uint32_t pairs,
+                                  size_t first_frame, size_t n_frames, size_t total_frames, void *d_mags_f16);
+hipError_t launch_to_half(const sgx_ctx *c, const float *d_in, void *d_out, size_t n_pairs);
 hipError_t launch_render(const sgx_ctx *c, const float *d_mags, size_t n_columns, uint8_t *d_rgba);
 hipError_t launch_white_noise(const sgx_ctx *c, float *d_out, uint64_t first, size_t n, uint32_t channels, uint32_t seed);
 hipError_t launch_checksum(const sgx_ctx *c, const uint32_t *d_words, size_t n_words, uint64_t base_word,

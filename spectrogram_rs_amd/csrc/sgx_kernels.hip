@@ -6,6 +6,8 @@
 //
 // Compiled with -ffp-contract=off: the pixel path must round every f32 operation exactly once
 // so that its bytes equal the CPU restatement's; FFT code asks for FMAs explicitly.
+#include <hip/hip_fp16.h>
+
 #include "sgx_internal.hpp"
 
 namespace sgx {
@@ -268,6 +270,28 @@ hipError_t launch_render(const sgx_ctx *c, const float *d_mags, size_t n_columns
         done += chunk;
     }
     return hipSuccess;
+}
+
+// ------------------------------------------------------------------------------------------------
+// f32 -> f16 magnitudes (only for STFT kernels that have no native half store)
+// ------------------------------------------------------------------------------------------------
+
+__global__ void to_half_kernel(const float2 *in, __half2 *out, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float2 v = in[i];
+        out[i] = __floats2half2_rn(v.x, v.y);
+    }
+}
+
+hipError_t launch_to_half(const sgx_ctx *c, const float *d_in, void *d_out, size_t n_pairs)
+{
+    if (n_pairs == 0) return hipSuccess;
+    size_t blocks = (n_pairs + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(to_half_kernel, dim3((unsigned)blocks), dim3(256), 0, c->stream, reinterpret_cast<const float2 *>(d_in),
+                       static_cast<__half2 *>(d_out), n_pairs);
+    return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------------

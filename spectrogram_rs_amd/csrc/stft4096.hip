@@ -47,6 +47,8 @@ struct Fast4096Params {
     unsigned long long n_frames;
     unsigned long long n_jobs;
     unsigned long long jobs_per_block;
+    unsigned long long pair_base;  // mono: global index of the first frame pair
+    unsigned long long total_frames;
     uint32_t H, C, pair_l, pair_r, pairs, pair;
 };
 
@@ -76,18 +78,22 @@ __global__ void __launch_bounds__(NWAVES * 64) stft4096_kernel(Fast4096Params p)
     for (unsigned long long job = job_begin + wave; job < job_end; job += NWAVES) {
         // ---- load + Hann (fft.rs:53-63); real part = left / frame f0, imaginary part = right / frame f0+1
         float er[32], ei[32], orr[32], oi[32];
-        unsigned long long f0;
-        bool have_second = true;
+        long long f0;  // local (output) index of the first frame of the job; -1 when it precedes the range
+        bool have_first = true, have_second = true;
         if (MONO) {
-            f0 = 2 * job;
-            have_second = f0 + 1 < p.n_frames;
-            const float *s0 = p.pcm + (p.first_frame + f0) * p.H + lane;
-            const float *s1 = have_second ? s0 + p.H : s0;
+            // pairs follow the GLOBAL frame index so that results do not depend on where a range starts
+            const unsigned long long g0 = 2 * (p.pair_base + job);
+            f0 = (long long)g0 - (long long)p.first_frame;
+            have_first = f0 >= 0;
+            have_second = f0 + 1 < (long long)p.n_frames;
+            const bool data_second = g0 + 1 < p.total_frames;  // the partner is transformed whenever the stream holds it
+            const float *s0 = p.pcm + g0 * p.H + lane;
+            const float *s1 = data_second ? s0 + p.H : s0;
 #pragma unroll
             for (int a = 0; a < 32; ++a) {
                 const float w = win[64 * a + lane];
                 er[a] = s0[64 * a] * w;
-                ei[a] = have_second ? s1[64 * a] * w : 0.0f;
+                ei[a] = data_second ? s1[64 * a] * w : 0.0f;
             }
         } else {
             f0 = job;
@@ -151,8 +157,8 @@ __global__ void __launch_bounds__(NWAVES * 64) stft4096_kernel(Fast4096Params p)
         // ---- split + magnitude + store (fft.rs:81-98); only k = 1 .. W-1 is kept (k2 < 32)
         float *row0, *row1;
         if (MONO) {
-            row0 = p.mags + ((f0 * p.pairs + p.pair) * (size_t)kM) * 2;
-            row1 = row0 + (size_t)p.pairs * kM * 2;
+            row0 = p.mags + (((size_t)(have_first ? f0 : 0) * p.pairs + p.pair) * (size_t)kM) * 2;
+            row1 = p.mags + (((size_t)(f0 + 1) * p.pairs + p.pair) * (size_t)kM) * 2;
         } else {
             row0 = p.mags + ((f0 * p.pairs + p.pair) * (size_t)kM) * 2;
             row1 = row0;
@@ -177,7 +183,7 @@ __global__ void __launch_bounds__(NWAVES * 64) stft4096_kernel(Fast4096Params p)
                 const int k = lane + 64 * (2 * m);
                 if (k >= 1) {
                     if (MONO) {
-                        reinterpret_cast<float2 *>(row0)[k - 1] = make_float2(left, left);
+                        if (have_first) reinterpret_cast<float2 *>(row0)[k - 1] = make_float2(left, left);
                         if (have_second) reinterpret_cast<float2 *>(row1)[k - 1] = make_float2(right, right);
                     } else {
                         reinterpret_cast<float2 *>(row0)[k - 1] = make_float2(left, right);
@@ -197,7 +203,7 @@ __global__ void __launch_bounds__(NWAVES * 64) stft4096_kernel(Fast4096Params p)
                 const float right = __builtin_amdgcn_sqrtf(fmaf(qr, qr, qi * qi)) * inv_w;
                 const int k = lane + 64 * (2 * m + 1);
                 if (MONO) {
-                    reinterpret_cast<float2 *>(row0)[k - 1] = make_float2(left, left);
+                    if (have_first) reinterpret_cast<float2 *>(row0)[k - 1] = make_float2(left, left);
                     if (have_second) reinterpret_cast<float2 *>(row1)[k - 1] = make_float2(right, right);
                 } else {
                     reinterpret_cast<float2 *>(row0)[k - 1] = make_float2(left, right);
@@ -256,7 +262,7 @@ void fast4096_destroy(sgx_ctx *c)
 }
 
 hipError_t launch_stft_fast4096(const sgx_ctx *c, const float *d_pcm, uint32_t channels, uint32_t pairs, size_t first_frame,
-                                size_t n_frames, float *d_mags)
+                                size_t n_frames, size_t total_frames, float *d_mags)
 {
     if (n_frames == 0) return hipSuccess;
     const auto *t = static_cast<const Fast4096Tables *>(c->d_fast);
@@ -270,6 +276,7 @@ hipError_t launch_stft_fast4096(const sgx_ctx *c, const float *d_pcm, uint32_t c
         p.mags = d_mags;
         p.first_frame = first_frame;
         p.n_frames = n_frames;
+        p.total_frames = total_frames;
         p.H = c->H;
         p.C = channels;
         p.pairs = pairs;
@@ -277,7 +284,8 @@ hipError_t launch_stft_fast4096(const sgx_ctx *c, const float *d_pcm, uint32_t c
         p.pair_l = channels == 1 ? 0 : 2 * pair;
         p.pair_r = channels == 1 ? 0 : 2 * pair + 1;
         const bool mono = channels == 1 && !(c->cfg.flags & SGX_FLAG_INDEPENDENT_FRAMES);
-        p.n_jobs = mono ? (n_frames + 1) / 2 : n_frames;
+        p.pair_base = mono ? first_frame / 2 : 0;
+        p.n_jobs = mono ? (first_frame + n_frames + 1) / 2 - first_frame / 2 : n_frames;
         // one persistent workgroup per CU; each owns a contiguous run of jobs, a multiple of the
         // wave count so that its waves stay on neighbouring frames (shared audio stays in L1)
         unsigned long long blocks = (unsigned long long)n_cu;

@@ -91,10 +91,12 @@ __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
     float sa[(MONO && PAIRING == kPairAdjacentRow) ? 9 : 8], sb[8];
     auto fetch = [&](unsigned long long job, bool sequential) {
         if (MONO) {
-            const unsigned long long f = 2 * job;
+            // frames are paired by their GLOBAL index (2q, 2q+1), so the bytes do not depend on where a
+            // range starts: an odd first_frame computes frame first_frame-1 too and simply does not store it
+            const unsigned long long f = 2 * (p.pair_base + job);
             const unsigned long long fb = f + 1;
-            const bool second = fb < p.n_frames;
-            const float *s0 = p.pcm + (p.first_frame + f) * p.H;
+            const bool second = fb < p.total_frames;  // the partner is transformed whenever the stream holds it
+            const float *s0 = p.pcm + f * p.H;
             if (PAIRING == kPairAdjacentRow) {
                 // H = 256 = one row: frame f+1 row a is frame f row a+1, and the next transform
                 // (two frames on) re-uses rows 2..8 of this one: slide the register window and
@@ -109,7 +111,7 @@ __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
                 }
                 sa[8] = second ? s0[tid + 256 * 8] : 0.0f;
             } else {
-                const float *s1 = second ? p.pcm + (p.first_frame + fb) * p.H : s0;
+                const float *s1 = second ? p.pcm + fb * p.H : s0;
 #pragma unroll
                 for (int a = 0; a < 8; ++a) { sa[a] = s0[tid + 256 * a]; sb[a] = s1[tid + 256 * a]; }
             }
@@ -149,14 +151,17 @@ __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
 #pragma unroll
         for (int a = 0; a < 8; ++a) win[a] = p.window[tid + 256 * a];
 #endif
-        const unsigned long long f0 = MONO ? 2 * job : job;
-        const unsigned long long f1 = f0 + 1;
-        const bool have_second = !MONO || f1 < p.n_frames;
+        // local (output) frame indices; for mono f0 may be -1 (the pair's first frame precedes the range)
+        const long long f0 = MONO ? (long long)(2 * (p.pair_base + job)) - (long long)p.first_frame : (long long)job;
+        const long long f1 = f0 + 1;
+        const bool have_first = !MONO || f0 >= 0;
+        const bool data_second = !MONO || (unsigned long long)(f1 + (long long)p.first_frame) < p.total_frames;
+        const bool have_second = !MONO || f1 < (long long)p.n_frames;  // ... but stored only inside the requested range
 #pragma unroll
         for (int a = 0; a < 8; ++a) {
             er[a] = sa[a] * win[a];
-            if (MONO && PAIRING == kPairAdjacentRow) ei[a] = have_second ? sa[a + 1] * win[a] : 0.0f;
-            else ei[a] = have_second ? sb[a] * win[a] : 0.0f;
+            if (MONO && PAIRING == kPairAdjacentRow) ei[a] = data_second ? sa[a + 1] * win[a] : 0.0f;
+            else ei[a] = data_second ? sb[a] * win[a] : 0.0f;
         }
         const int col = tid;                           // pass-3 / output column of this thread
         const int pcol = col == 0 ? 256 : 256 - col;   // partner column (column 0 is its own partner, one row up)
@@ -234,16 +239,27 @@ __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
         }
 
         if (!RENDER) {
-            // ---- store [F][pairs][M][2]: uniform row base (SGPR) + one 32-bit lane offset, 8 bytes per lane
-            char *row0 = reinterpret_cast<char *>(p.mags + ((f0 * p.pairs + p.pair) * (size_t)kM) * 2) - 8;
-            if (MONO) {
-                store_row<true>(row0, col, ml, ml);
-                if (have_second) {
-                    char *row1 = reinterpret_cast<char *>(p.mags + ((f1 * p.pairs + p.pair) * (size_t)kM) * 2) - 8;
-                    store_row<true>(row1, col, mr, mr);
+            // ---- store [F][pairs][M][2]: uniform row base (SGPR) + one 32-bit lane offset
+            if (p.out_f16) {
+                char *base = reinterpret_cast<char *>(p.mags);
+                char *row0 = base + ((size_t)(have_first ? f0 : 0) * p.pairs + p.pair) * (size_t)kM * 4 - 4;
+                if (MONO) {
+                    if (have_first) store_row_f16<true>(row0, col, ml, ml);
+                    if (have_second) store_row_f16<true>(base + (f1 * p.pairs + p.pair) * (size_t)kM * 4 - 4, col, mr, mr);
+                } else {
+                    store_row_f16<false>(row0, col, ml, mr);
                 }
             } else {
-                store_row<false>(row0, col, ml, mr);
+                char *row0 = reinterpret_cast<char *>(p.mags + (((size_t)(have_first ? f0 : 0) * p.pairs + p.pair) * (size_t)kM) * 2) - 8;
+                if (MONO) {
+                    if (have_first) store_row<true>(row0, col, ml, ml);
+                    if (have_second) {
+                        char *row1 = reinterpret_cast<char *>(p.mags + ((f1 * p.pairs + p.pair) * (size_t)kM) * 2) - 8;
+                        store_row<true>(row1, col, mr, mr);
+                    }
+                } else {
+                    store_row<false>(row0, col, ml, mr);
+                }
             }
         } else {
             // ---- fused pixel column(s): magnitude_in -> color_for -> put_pixel
@@ -261,10 +277,10 @@ __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
             }
             lds_barrier();
             const int last = kM - 1;
-            const int n_cols = MONO ? (have_second ? 2 : 1) : 1;
-            for (int c_i = 0; c_i < n_cols; ++c_i) {
+            for (int c_i = 0; c_i < (MONO ? 2 : 1); ++c_i) {
+                if (MONO && !(c_i ? have_second : have_first)) continue;
                 const float *mc = MONO ? (c_i ? m1 : m0) : m0;
-                uchar4 *dst = reinterpret_cast<uchar4 *>(p.rgba) + ((c_i ? f1 : f0) * p.pairs + p.pair) * (size_t)p.R;
+                uchar4 *dst = reinterpret_cast<uchar4 *>(p.rgba) + ((size_t)(c_i ? f1 : f0) * p.pairs + p.pair) * (size_t)p.R;
                 for (uint32_t py = tid; py < p.R; py += 256) {
                     const uint32_t re = p.rows[py];
                     const uint32_t first = re & 0xffffu, cnt = re >> 16;
@@ -414,7 +430,7 @@ namespace {
 
 template <bool RENDER>
 hipError_t launch_wg(const sgx_ctx *c, const void *tables, const float *d_pcm, uint32_t channels, uint32_t pairs,
-                     size_t first_frame, size_t n_frames, float *d_mags, uint8_t *d_rgba)
+                     size_t first_frame, size_t n_frames, size_t total_frames, float *d_mags, uint8_t *d_rgba, bool out_f16 = false)
 {
     using namespace wg;
     if (n_frames == 0) return hipSuccess;
@@ -428,8 +444,10 @@ hipError_t launch_wg(const sgx_ctx *c, const void *tables, const float *d_pcm, u
         p.tw2 = t->d_tw2;
         p.window = c->d_window;
         p.mags = d_mags;
+        p.out_f16 = out_f16 ? 1u : 0u;
         p.first_frame = first_frame;
         p.n_frames = n_frames;
+        p.total_frames = total_frames;
         p.H = c->H;
         p.C = channels;
         p.pairs = pairs;
@@ -452,7 +470,8 @@ hipError_t launch_wg(const sgx_ctx *c, const void *tables, const float *d_pcm, u
         }
         // mono normally rides two frames per transform; SGX_FLAG_INDEPENDENT_FRAMES runs it as (s, s) pairs
         const bool mono = channels == 1 && !(c->cfg.flags & SGX_FLAG_INDEPENDENT_FRAMES);
-        p.n_jobs = mono ? (n_frames + 1) / 2 : n_frames;
+        p.pair_base = mono ? first_frame / 2 : 0;
+        p.n_jobs = mono ? (first_frame + n_frames + 1) / 2 - first_frame / 2 : n_frames;
         // persistent workgroups, 4 per CU; each owns a contiguous run of transforms so that the
         // overlapping audio of consecutive frames is re-read from L1/L2, not HBM
         unsigned long long blocks = (unsigned long long)n_cu * 4;
@@ -479,15 +498,21 @@ hipError_t launch_wg(const sgx_ctx *c, const void *tables, const float *d_pcm, u
 }  // namespace
 
 hipError_t launch_stft_wg4096(const sgx_ctx *c, const void *tables, const float *d_pcm, uint32_t channels, uint32_t pairs,
-                              size_t first_frame, size_t n_frames, float *d_mags)
+                              size_t first_frame, size_t n_frames, size_t total_frames, float *d_mags)
 {
-    return launch_wg<false>(c, tables, d_pcm, channels, pairs, first_frame, n_frames, d_mags, nullptr);
+    return launch_wg<false>(c, tables, d_pcm, channels, pairs, first_frame, n_frames, total_frames, d_mags, nullptr);
+}
+
+hipError_t launch_stft_wg4096_f16(const sgx_ctx *c, const void *tables, const float *d_pcm, uint32_t channels, uint32_t pairs,
+                                  size_t first_frame, size_t n_frames, size_t total_frames, void *d_mags_f16)
+{
+    return launch_wg<false>(c, tables, d_pcm, channels, pairs, first_frame, n_frames, total_frames, static_cast<float *>(d_mags_f16), nullptr, true);
 }
 
 hipError_t launch_render_wg4096(const sgx_ctx *c, const void *tables, const float *d_pcm, uint32_t channels, uint32_t pairs,
-                                size_t first_frame, size_t n_frames, uint8_t *d_rgba)
+                                size_t first_frame, size_t n_frames, size_t total_frames, uint8_t *d_rgba)
 {
-    return launch_wg<true>(c, tables, d_pcm, channels, pairs, first_frame, n_frames, nullptr, d_rgba);
+    return launch_wg<true>(c, tables, d_pcm, channels, pairs, first_frame, n_frames, total_frames, nullptr, d_rgba);
 }
 
 }  // namespace sgx

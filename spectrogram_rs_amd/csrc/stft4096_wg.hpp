@@ -1,6 +1,8 @@
 // stft4096_wg.hpp -- declarations shared by the two workgroup-per-transform kernels
 // (stft4096_wg.hip: scalar codelets; stft4096_wgp.hip: packed (re, im) codelets).
 #pragma once
+#include <hip/hip_fp16.h>
+
 #include "sgx_internal.hpp"
 
 namespace sgx {
@@ -30,7 +32,10 @@ struct Params {
     const float *window; // [2048]
     float *mags;
     unsigned long long first_frame, n_frames, n_jobs, jobs_per_block;
+    unsigned long long pair_base;  // mono: global index of the first frame PAIR (first_frame / 2)
+    unsigned long long total_frames;  // frames the stream holds (a pair's second frame is transformed whenever it exists)
     uint32_t H, C, pair_l, pair_r, pairs, pair;
+    uint32_t out_f16;          // magnitudes are stored as (l, r) half pairs, 4 B per bin (the F16F16 ring of gpu_spectrogram.rs:218-226)
     // fused pixel path (RENDER): magnitudes never leave LDS
     const uint32_t *rows;      // [R]  first | count << 16
     const PackedSample *samples;
@@ -78,6 +83,19 @@ __device__ __forceinline__ void store_row(char *rowm8, int col, const float (&va
     for (int q3 = 0; q3 < 8; ++q3)
         if (q3 > 0 || col != 0)  // k = 0 (DC) is not part of the output (fft.rs:81)
             *reinterpret_cast<float2 *>(rowm8 + 2048 * q3 + lane_off) = DUP ? make_float2(va[q3], va[q3]) : make_float2(va[q3], vb[q3]);
+}
+
+// the same row as IEEE half pairs (round to nearest even): bin k at byte 4 k of rowm4
+template <bool DUP>
+__device__ __forceinline__ void store_row_f16(char *rowm4, int col, const float (&va)[8], const float (&vb)[8])
+{
+    const uint32_t lane_off = (uint32_t)col * 4u;
+#pragma unroll
+    for (int q3 = 0; q3 < 8; ++q3)
+        if (q3 > 0 || col != 0) {
+            const __half2 h = __floats2half2_rn(va[q3], DUP ? va[q3] : vb[q3]);
+            *reinterpret_cast<__half2 *>(rowm4 + 1024 * q3 + lane_off) = h;
+        }
 }
 
 }  // namespace wg

@@ -125,6 +125,25 @@ class SpectrogramEngine:
             assert got.value == n
         return out
 
+    def stft_batch_f16(self, pcm, first_frame: int = 0, max_frames: Optional[int] = None, out=None):
+        """As stft_batch, magnitudes as float16 (l, r) pairs: [frames][pairs][M][2] torch.float16
+        (the texel format of the widget's F16F16 ring texture, gpu_spectrogram.rs:218-226)."""
+        import torch
+
+        n_samples = pcm.numel() // self.channels
+        total = self.num_frames(n_samples)
+        n = max(total - first_frame, 0)
+        if max_frames is not None:
+            n = min(n, max_frames)
+        if out is None:
+            out = torch.empty((n, self.pairs, self.M, 2), dtype=torch.float16, device=pcm.device)
+        got = C.c_size_t(0)
+        if n:
+            self._check(self._lib.sgx_stft_batch_f16(self._ctx, self._dev_f32(pcm), n_samples, first_frame, n,
+                                                     C.c_void_p(out.data_ptr()), C.byref(got)))
+            assert got.value == n
+        return out
+
     def process_one(self, lr: np.ndarray) -> Optional[np.ndarray]:
         """AudioTransform::process on host (l, r) pairs: [n][2] -> [M][2] or None."""
         lr = np.ascontiguousarray(lr, np.float32).reshape(-1, 2)

@@ -14,11 +14,16 @@ from __future__ import annotations
 from typing import Callable, Iterator, List, Optional, Tuple
 
 
-def frame_range(rank: int, world: int, total_frames: int) -> Tuple[int, int]:
-    """Contiguous frame range [first, first + count) owned by `rank` (ranges differ by at most one)."""
-    base, extra = divmod(total_frames, world)
-    first = rank * base + min(rank, extra)
-    return first, base + (1 if rank < extra else 0)
+def frame_range(rank: int, world: int, total_frames: int, granule: int = 2) -> Tuple[int, int]:
+    """Contiguous frame range [first, first + count) owned by `rank`.  Boundaries fall on multiples of
+    `granule` frames (default 2: a mono transform carries the frame pair (2j, 2j+1), so even
+    boundaries make every rank compute exactly the transforms a single GPU would -- same bytes)."""
+    units = (total_frames + granule - 1) // granule
+    base, extra = divmod(units, world)
+    u0 = rank * base + min(rank, extra)
+    u1 = u0 + base + (1 if rank < extra else 0)
+    first = min(u0 * granule, total_frames)
+    return first, min(u1 * granule, total_frames) - first
 
 
 def sample_range(first_frame: int, n_frames: int, W: int, H: int) -> Tuple[int, int]:

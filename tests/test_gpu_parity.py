@@ -98,6 +98,14 @@ def test_short_ragged_and_empty_inputs(torch_cuda):
     part = eng.stft_batch(to_dev(torch, pcm), first_frame=3, max_frames=2).cpu().numpy()
     assert np.array_equal(part, full[3:5])
     assert eng.stft_batch(to_dev(torch, pcm), first_frame=99).shape[0] == 0
+    # mono: two frames share a transform, paired by GLOBAL index -- any sub-range gives the same bytes
+    for kw in (dict(), dict(wave_kernel=True), dict(packed_kernel=True)):
+        mono = engine(window_samples=W, hop_samples=H, channels=1, **kw)
+        m = to_dev(torch, oracle.white_noise(W + 12 * H, seed=6))
+        full = mono.stft_batch(m)
+        for first, cnt in ((1, 5), (3, 2), (4, 9), (12, 1), (7, 100)):
+            assert torch.equal(mono.stft_batch(m, first_frame=first, max_frames=cnt), full[first:first + cnt])
+        assert torch.equal(mono.render_batch(m, first_frame=5, max_frames=4), mono.render_batch(m)[5:9])
 
 
 def test_process_one_mirrors_process(torch_cuda, mags_err):
@@ -357,6 +365,26 @@ def test_frame_pairing_dynamic_range_and_independent_frames(torch_cuda, mags_err
     # frame 1 rides with the click: its error is bounded relative to the PAIR's peak, not its own
     pair_peak = np.abs(ref[:2]).max()
     assert np.abs(paired[1] - ref[1]).max() <= 1e-6 * pair_peak
+
+
+@pytest.mark.parametrize("kw", [dict(channels=1), dict(channels=2), dict(channels=1, force_generic=True),
+                                dict(channels=2, window_samples=2400, hop_samples=93)])
+def test_half_precision_ring_rows(torch_cuda, kw):
+    # the F16F16 ring format of the default widget: the half rows are the float rows rounded to nearest even
+    torch = torch_cuda
+    kw = dict(dict(window_samples=W, hop_samples=H), **kw)
+    eng = engine(**kw)
+    n = eng.W + 40 * eng.H + 3
+    pcm = to_dev(torch, oracle.white_noise(n * eng.channels, seed=3))
+    f32 = eng.stft_batch(pcm)
+    f16 = eng.stft_batch_f16(pcm)
+    assert f16.dtype == torch.float16 and f16.shape == f32.shape
+    assert torch.equal(f16, f32.to(torch.float16))
+    part = eng.stft_batch_f16(pcm, first_frame=7, max_frames=9)
+    assert torch.equal(part, f16[7:16])
+    ref = oracle.stream_process(pcm.cpu().numpy(), eng.channels, eng.W, eng.H, threads=8)
+    rel = np.abs(f16.cpu().numpy().astype(np.float64) - ref) / np.maximum(np.abs(ref), 0.05 * np.abs(ref).max())
+    assert rel.max() < 1e-3  # half has an 11-bit significand
 
 
 def test_lookup_table_and_widget_ring(torch_cuda, gradients):

@@ -78,3 +78,17 @@ def app_default(frames=20000):
 if __name__ == "__main__" and "--extra" in sys.argv:
     config4()
     app_default()
+
+
+def f16(frames=1_000_000):
+    eng = SpectrogramEngine(48000.0, window_samples=2048, hop_samples=256, channels=1)
+    n = (frames - 1) * eng.H + eng.W
+    pcm = eng.white_noise(n)
+    out = torch.empty((frames, 1, eng.M, 2), dtype=torch.float16, device="cuda")
+    med, best = timeit(lambda: eng.stft_batch_f16(pcm, out=out))
+    byts = frames * (256 * 4 + eng.M * 4)
+    print(f"stft f16 ring rows F={frames}: median {med:.3f} ms -> {frames / med / 1e3:.1f} M frames/s, {byts / med / 1e6:.1f} GB/s algorithmic", flush=True)
+
+
+if __name__ == "__main__" and "--extra" in sys.argv:
+    f16()
