@@ -99,7 +99,7 @@ typedef struct sgx_info {
     uint32_t rows;            /* R */
     uint32_t sample_rate_u32; /* SampleRate(sample_rate as u32)      simple_spectrogram.rs:138 */
     uint32_t total_samples_per_column; /* sum over rows of magnitude_in's sample count */
-    uint32_t stft_kernel;     /* 0 = generic power-of-two, 1 = 4096-point wave-per-transform, 2 = 4096-point workgroup-per-transform (default), 3 = the same with packed (re, im) arithmetic, 4 = Bluestein (2W not a power of two) */
+    uint32_t stft_kernel;     /* 0 = generic power-of-two, 1 = 4096-point wave-per-transform, 2 = 4096-point workgroup-per-transform (default), 3 = the same with packed (re, im) arithmetic, 4 = Bluestein (2W not a power of two), 5 = 16384-point workgroup-per-transform */
     uint32_t reserved;
     uint64_t mags_bytes_per_frame; /* pairs * M * 2 * 4 */
     uint64_t rgba_bytes_per_frame; /* pairs * R * 4     */

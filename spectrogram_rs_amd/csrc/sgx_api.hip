@@ -92,6 +92,8 @@ int ensure_workspace(sgx_ctx *c, size_t frames)
 hipError_t run_stft(const sgx_ctx *c, const float *d_pcm, uint32_t channels, uint32_t pairs, size_t first, size_t n,
                     size_t total, float *d_mags)
 {
+    if (c->stft_kernel == 5 && (channels != 1 || !(c->cfg.flags & SGX_FLAG_INDEPENDENT_FRAMES)))
+        return sgx::launch_stft_wg16384(c, c->d_fast_16k, d_pcm, channels, pairs, first, n, total, d_mags);
     if (c->stft_kernel == 4) return sgx::launch_stft_bluestein(c, c->d_blu, d_pcm, channels, pairs, first, n, d_mags);
     if (c->stft_kernel == 3) return sgx::launch_stft_wgp4096(c, c->d_fast_wg, d_pcm, channels, pairs, first, n, total, d_mags);
     if (c->stft_kernel == 2) return sgx::launch_stft_wg4096(c, c->d_fast_wg, d_pcm, channels, pairs, first, n, total, d_mags);
@@ -214,6 +216,10 @@ int sgx_create(const sgx_config *cfg, sgx_ctx **out_ctx)
         e = sgx::wg4096_init(c, &c->d_fast_wg);
         if (e != hipSuccess) return bail(SGX_ERR_HIP, std::string("sgx_create: tuned kernel tables: ") + hipGetErrorString(e));
         c->stft_kernel = (cfg->flags & SGX_FLAG_WAVE_KERNEL) ? 1 : ((cfg->flags & SGX_FLAG_PACKED_KERNEL) ? 3 : 2);
+    } else if (!(cfg->flags & SGX_FLAG_FORCE_GENERIC) && sgx::wg16384_supported(c)) {
+        e = sgx::wg16384_init(c, &c->d_fast_16k);
+        if (e != hipSuccess) return bail(SGX_ERR_HIP, std::string("sgx_create: 16384-point kernel tables: ") + hipGetErrorString(e));
+        c->stft_kernel = 5;
     }
     *out_ctx = c;
     return SGX_OK;
@@ -228,6 +234,8 @@ void sgx_destroy(sgx_ctx *c)
     c->d_fast_wg = nullptr;
     sgx::bluestein_destroy(c->d_blu);
     c->d_blu = nullptr;
+    sgx::wg16384_destroy(c->d_fast_16k);
+    c->d_fast_16k = nullptr;
     void *ptrs[] = {c->d_window, c->d_twiddle, c->d_rows, c->d_samples, c->d_lut_thr, c->d_alpha_thr,
                     c->d_lut_rgba, c->d_ws_mags, c->d_one_in, c->d_one_out, c->d_cksum};
     for (void *p : ptrs)
@@ -365,7 +373,7 @@ int sgx_render_batch(sgx_ctx *c, const float *d_pcm, size_t n_samples, size_t fi
     if (n > max_frames) n = max_frames;
     if (!d_pcm || !d_rgba) return fail(c, SGX_ERR_INVALID_ARG, "sgx_render_batch: null buffer");
     SGX_HIP(c, hipSetDevice(c->device));
-    if (c->stft_kernel >= 2 && !(c->cfg.flags & SGX_FLAG_NO_FUSED_RENDER) && sgx::wg4096_can_fuse_render(c, c->d_fast_wg)) {
+    if ((c->stft_kernel == 2 || c->stft_kernel == 3) && !(c->cfg.flags & SGX_FLAG_NO_FUSED_RENDER) && sgx::wg4096_can_fuse_render(c, c->d_fast_wg)) {
         // one kernel from PCM to pixels: magnitudes never leave LDS (5 120 B of HBM traffic per frame)
         hipError_t e = c->stft_kernel == 3
                            ? sgx::launch_render_wgp4096(c, c->d_fast_wg, d_pcm, c->C, c->pairs, first_frame, n, total, d_rgba)

@@ -62,7 +62,7 @@ struct sgx_ctx {
     uint32_t W = 0, P = 0, M = 0, H = 0, C = 0, pairs = 0, R = 0, sr_u32 = 0, logP = 0;
     int device = 0;
     hipStream_t stream = nullptr;
-    int stft_kernel = 0;  // 0 generic, 1 tuned 4096 wave-per-transform, 2 tuned 4096 workgroup-per-transform (scalar codelets), 3 the same with packed (re, im) arithmetic, 4 Bluestein (2W not a power of two)
+    int stft_kernel = 0;  // 0 generic, 1 tuned 4096 wave-per-transform, 2 tuned 4096 workgroup-per-transform (scalar codelets), 3 the same with packed (re, im) arithmetic, 4 Bluestein (2W not a power of two), 5 tuned 16384
 
     sgx::Tables tab;
     sgx::Palette pal;
@@ -78,6 +78,7 @@ struct sgx_ctx {
     void *d_fast = nullptr;        // tables of the wave-per-transform kernel (opaque here)
     void *d_fast_wg = nullptr;     // tables of the workgroup-per-transform kernel
     void *d_blu = nullptr;         // tables of the Bluestein (non-power-of-two) kernel
+    void *d_fast_16k = nullptr;    // tables of the 16384-point workgroup-per-transform kernel
 
     // workspaces (grown on demand, kept)
     float *d_ws_mags = nullptr;
@@ -109,6 +110,11 @@ hipError_t launch_stft_wgp4096(const sgx_ctx *c, const void *tables, const float
                                size_t first_frame, size_t n_frames, size_t total_frames, float *d_mags);
 hipError_t launch_render_wgp4096(const sgx_ctx *c, const void *tables, const float *d_pcm, uint32_t channels, uint32_t pairs,
                                  size_t first_frame, size_t n_frames, size_t total_frames, uint8_t *d_rgba);
+bool wg16384_supported(const sgx_ctx *c);
+hipError_t wg16384_init(sgx_ctx *c, void **out);
+void wg16384_destroy(void *tables);
+hipError_t launch_stft_wg16384(const sgx_ctx *c, const void *tables, const float *d_pcm, uint32_t channels, uint32_t pairs,
+                               size_t first_frame, size_t n_frames, size_t total_frames, float *d_mags);
 bool bluestein_supported(uint32_t W);
 hipError_t bluestein_init(sgx_ctx *c, void **out);
 void bluestein_destroy(void *tables);

@@ -82,6 +82,32 @@ def test_other_sizes_and_channel_pairs(torch_cuda, mags_err, Wt, Ht, ch):
     assert mags_err(got, ref) <= 2.0
 
 
+@pytest.mark.parametrize("ch,force_generic", [(8, False), (2, False), (1, False), (8, True)])
+def test_config4_16384_point_kernel(torch_cuda, mags_err, ch, force_generic):
+    # BASELINE config 4: W 8192 / P 16384, hop 512, interleaved channel pairs; tuned kernel vs generic vs oracle
+    torch = torch_cuda
+    Wt, Ht = 8192, 512
+    eng = engine(window_samples=Wt, hop_samples=Ht, channels=ch, force_generic=force_generic)
+    assert eng.info.stft_kernel == (0 if force_generic else 5)
+    n = Wt + 21 * Ht + 9
+    pcm = oracle.white_noise(n * ch, seed=40 + ch)
+    dev = to_dev(torch, pcm)
+    got = eng.stft_batch(dev).cpu().numpy()
+    ref = oracle.stream_process(pcm, ch, Wt, Ht, threads=8)
+    assert got.shape == ref.shape == (22, max(ch // 2, 1), Wt - 1, 2)
+    assert mags_err(got, ref) <= 2.0
+    lr = pcm.reshape(-1, ch)
+    truth = oracle.np_truth_frame(np.stack([lr[5 * Ht:5 * Ht + Wt, 0], lr[5 * Ht:5 * Ht + Wt, min(1, ch - 1)]], 1), Wt)
+    assert mags_err(got[5, 0], truth) <= 1.0
+    for first, cnt in ((1, 4), (6, 3), (21, 1)):   # sub-ranges give the same bytes (mono pairs by global index)
+        assert np.array_equal(eng.stft_batch(dev, first_frame=first, max_frames=cnt).cpu().numpy(), got[first:first + cnt])
+    # the pixel path rides on it through the two-kernel route
+    eng.set_builtin_gradient("viridis")
+    rg = eng.render_batch(dev).cpu().numpy()
+    own = oracle.render_columns(got.reshape(-1, Wt - 1, 2), SR, np.load(os.path.join(os.path.dirname(__file__), "golden", "gradients.npz"))["viridis"])
+    assert np.array_equal(rg.reshape(own.shape), own)
+
+
 def test_short_ragged_and_empty_inputs(torch_cuda):
     torch = torch_cuda
     eng = engine(window_samples=W, hop_samples=H, channels=2)
