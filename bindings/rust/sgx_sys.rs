@@ -23,6 +23,8 @@ extern "C" {
     pub fn sgx_process_one(ctx: *mut SgxCtx, h_lr: *const f32, n_avail: usize, h_out: *mut f32) -> c_int;
     pub fn sgx_stft_batch(ctx: *mut SgxCtx, d_pcm: *const f32, n_samples: usize, first_frame: usize,
                           max_frames: usize, d_mags: *mut f32, n_out: *mut usize) -> c_int;
+    pub fn sgx_stft_batch_f16(ctx: *mut SgxCtx, d_pcm: *const f32, n_samples: usize, first_frame: usize,
+                              max_frames: usize, d_mags_f16: *mut c_void, n_out: *mut usize) -> c_int;   // F16F16 ring rows
     pub fn sgx_render_batch(ctx: *mut SgxCtx, d_pcm: *const f32, n_samples: usize, first_frame: usize,
                             max_frames: usize, d_rgba: *mut u8, n_out: *mut usize) -> c_int;
     pub fn sgx_set_gradient(ctx: *mut SgxCtx, h_rgb: *const u8, n: u32, stereo: c_int) -> c_int;

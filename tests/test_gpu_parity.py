@@ -413,6 +413,27 @@ def test_half_precision_ring_rows(torch_cuda, kw):
     assert rel.max() < 1e-3  # half has an 11-bit significand
 
 
+@pytest.mark.parametrize("period,Wexp", [(2048 / 48000.0 + 1e-7, 2048), (0.05, 2400)])
+def test_cpp_host_mirror_program(torch_cuda, mags_err, tmp_path, period, Wexp):
+    # include/sgx.hpp (C++ mirror of fourier::{AudioTransform, FastFourierTransform, AudioStreamTransform}) driven
+    # by a compiled C++ program: ring -> hop loop -> frames, compared with the oracle
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    subprocess.run(["make", "-C", os.path.join(here, "cpp"), "-s"], check=True)
+    out = str(tmp_path / "frames.bin")
+    stride, n = 2.0 / 1024, Wexp + 6 * 93 + 40
+    r = subprocess.run([os.path.join(here, "cpp", "host_mirror_test"), out, "48000", repr(period), repr(stride), str(n)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    raw = np.fromfile(out, dtype=np.uint8)
+    frames, M_, Hs, left = np.frombuffer(raw[:32].tobytes(), dtype=np.uint64)
+    assert (frames, M_, Hs) == (7, Wexp - 1, 93) and left == n - 8 * 93   # incl. the skip of the terminating read
+    got = np.frombuffer(raw[32:].tobytes(), dtype=np.float32).reshape(int(frames), int(M_), 2)
+    lr = oracle.white_noise(2 * n).reshape(-1, 2)
+    ref = oracle.stream_process(lr, 2, Wexp, 93)
+    assert mags_err(got, ref[:, 0]) <= (2.0 if Wexp == 2048 else 3.0)
+
+
 def test_lookup_table_and_widget_ring(torch_cuda, gradients):
     torch = torch_cuda
     from spectrogram_rs_amd import ColorScheme, RingBuffer, SimpleSpectrogram

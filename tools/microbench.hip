@@ -102,6 +102,26 @@ __global__ void store_kernel(float *out, size_t rows, int row_floats)
     }
 }
 
+// the STFT kernel's exact store pattern and nothing else: persistent 256-thread workgroups, each
+// streaming through its own contiguous run of 16 376-byte rows, thread t writing float2 at bins
+// t + 256 q (q = 0..7) of two rows per iteration
+__global__ void stft_store_pattern_kernel(float *out, size_t rows_total, size_t rows_per_block)
+{
+    const int tid = threadIdx.x;
+    size_t r0 = (size_t)blockIdx.x * rows_per_block, r1 = r0 + rows_per_block;
+    if (r1 > rows_total) r1 = rows_total;
+    for (size_t r = r0; r + 1 < r1; r += 2) {
+        char *row0 = reinterpret_cast<char *>(out) + r * 16376 - 8;
+        char *row1 = row0 + 16376;
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (q > 0 || tid != 0) *reinterpret_cast<float2 *>(row0 + 2048 * q + tid * 8) = make_float2((float)r, (float)q);
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (q > 0 || tid != 0) *reinterpret_cast<float2 *>(row1 + 2048 * q + tid * 8) = make_float2((float)r, (float)q);
+    }
+}
+
 __global__ void copy_kernel(const float4 *in, float4 *out, size_t n)
 {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = in[i];
@@ -196,6 +216,27 @@ int main()
                 printf("STORE %-40s blocks=%d  %.3f ms  %.2f TB/s\n", c.name, blocks, best,
                        rows * (double)c.row_floats * 4 / best / 1e9);
             }
+        }
+        {
+            const size_t rows_total = 1000000;
+            float *big;
+            CK(hipMalloc(&big, rows_total * 16376 + 64));
+            for (int blocks : {1024, 2048}) {
+                float best = 1e9f;
+                const size_t per = ((rows_total + blocks - 1) / blocks + 1) & ~(size_t)1;
+                for (int rep = 0; rep < 5; ++rep) {
+                    CK(hipEventRecord(e0));
+                    stft_store_pattern_kernel<<<blocks, 256>>>(big, rows_total, per);
+                    CK(hipEventRecord(e1));
+                    CK(hipEventSynchronize(e1));
+                    float ms;
+                    CK(hipEventElapsedTime(&ms, e0, e1));
+                    if (ms < best) best = ms;
+                }
+                printf("STORE stft pattern (1e6 rows of 16376 B, persistent WGs) blocks=%d  %.3f ms  %.2f TB/s\n", blocks, best,
+                       rows_total * 16376.0 / best / 1e9);
+            }
+            CK(hipFree(big));
         }
         float *src;
         CK(hipMalloc(&src, rows * 4096 * sizeof(float)));
