@@ -184,6 +184,15 @@ SGX_API int sgx_render_mags(sgx_ctx *ctx, const float *d_mags, size_t n_columns,
  * selects the diverging branch of color_for (colorscheme.rs:63-66: colour from the left/right
  * balance, alpha from the bounded dB magnitude). */
 SGX_API int sgx_set_gradient(sgx_ctx *ctx, const uint8_t *h_rgb, uint32_t n, int stereo);
+/* The same two constructors for ANY continuous gradient: `eval` stands in for colorous'
+ * Gradient::eval_continuous(t) (colorscheme.rs:43-69) -- the integrator passes a thunk around colorous
+ * itself, so spline (ColorBrewer) and closed-form (Turbo, Cividis, Cubehelix ...) gradients are rendered
+ * with exactly the bytes colorous returns and no table of this library is involved.  `eval` is called
+ * on the host, only inside this function (and sgx_lookup_table), never during a launch: the colour
+ * as a function of the bounded dB value (or of the left/right balance) is a step function of bytes; its
+ * switch points are located by bisection over float (double) bit patterns and uploaded as thresholds. */
+typedef void (*sgx_gradient_fn)(double t, uint8_t rgb_out[3], void *user);
+SGX_API int sgx_set_gradient_fn(sgx_ctx *ctx, sgx_gradient_fn eval, void *user, int stereo);
 /* "viridis" | "magma" | "inferno" | "plasma" (colorscheme.rs:131-139) */
 SGX_API int sgx_set_builtin_gradient(sgx_ctx *ctx, const char *name);
 SGX_API int sgx_builtin_gradient(const char *name, uint8_t *h_rgb_out /* [256][3] */);

@@ -77,6 +77,8 @@ def lib():
                                         C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, u8p]
         L.orc_lookup_table.restype = None
         L.orc_lookup_table.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int, fp]
+        L.orc_set_gradient_fn.restype = None
+        L.orc_set_gradient_fn.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_lowbias32.restype = C.c_uint32
         L.orc_lowbias32.argtypes = [C.c_uint32]
         L.orc_white_noise.restype = None
@@ -92,7 +94,34 @@ def _fp(a):
 
 
 def _u8p(a):
-    return a.ctypes.data_as(C.POINTER(C.c_uint8))
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_uint8))
+
+
+GRADIENT_FN = C.CFUNCTYPE(None, C.c_double, C.POINTER(C.c_uint8), C.c_void_p)
+_gradient_cb = None
+
+
+def set_gradient_fn(fn):
+    """Continuous gradient fn(t) -> (r, g, b), used wherever a gradient TABLE argument is None."""
+    global _gradient_cb
+    if fn is None:
+        _gradient_cb = None
+        lib().orc_set_gradient_fn(None, None)
+        return
+
+    def thunk(t, out, _user):
+        r, g, b = fn(t)
+        out[0], out[1], out[2] = int(r), int(g), int(b)
+    _gradient_cb = GRADIENT_FN(thunk)
+    lib().orc_set_gradient_fn(C.cast(_gradient_cb, C.c_void_p), None)
+
+
+def _grad(g):
+    """(table or None) -> (contiguous [n][3] u8 or None, n)"""
+    if g is None:
+        return None, 0
+    g = np.ascontiguousarray(g, np.uint8).reshape(-1, 3)
+    return g, g.shape[0]
 
 
 def _f32c(a):
@@ -204,10 +233,10 @@ def alpha_u8(alpha: float) -> int:
 
 def color_for(gradient: np.ndarray, l: float, r: float, stereo: bool = False, min_db: float = -70.0,
               max_db: float = -10.0, mode: int = LUT_FLOOR_N):
-    g = np.ascontiguousarray(gradient, np.uint8).reshape(-1, 3)
+    g, n = _grad(gradient)
     rgb = np.empty(3, np.uint8)
     alpha = C.c_float(0)
-    lib().orc_color_for(_u8p(g), g.shape[0], mode, int(stereo), min_db, max_db, l, r, _u8p(rgb), C.byref(alpha))
+    lib().orc_color_for(_u8p(g), n, mode, int(stereo), min_db, max_db, l, r, _u8p(rgb), C.byref(alpha))
     return rgb, float(alpha.value)
 
 
@@ -216,9 +245,9 @@ def render_column(mags: np.ndarray, sample_rate: int, gradient: np.ndarray, R: i
                   max_db: float = -10.0, mode: int = LUT_FLOOR_N) -> np.ndarray:
     """mags [M][2] -> rgba [R][4] u8 indexed by image row (row 0 = highest frequency)."""
     mags = _f32c(mags).reshape(-1, 2)
-    g = np.ascontiguousarray(gradient, np.uint8).reshape(-1, 3)
+    g, n = _grad(gradient)
     out = np.empty((R, 4), np.uint8)
-    lib().orc_render_column(_fp(mags), mags.shape[0], sample_rate, R, f_min, f_max, interp, _u8p(g), g.shape[0],
+    lib().orc_render_column(_fp(mags), mags.shape[0], sample_rate, R, f_min, f_max, interp, _u8p(g), n,
                             mode, int(stereo), min_db, max_db, _u8p(out))
     return out
 
@@ -230,9 +259,9 @@ def render_columns(mags: np.ndarray, sample_rate: int, gradient: np.ndarray, **k
 
 
 def lookup_table(gradient: np.ndarray, resolution: int = 32, stereo: bool = False, mode: int = LUT_FLOOR_N) -> np.ndarray:
-    g = np.ascontiguousarray(gradient, np.uint8).reshape(-1, 3)
+    g, n = _grad(gradient)
     out = np.empty((resolution, resolution, 4), np.float32)
-    lib().orc_lookup_table(_u8p(g), g.shape[0], mode, int(stereo), resolution, _fp(out))
+    lib().orc_lookup_table(_u8p(g), n, mode, int(stereo), resolution, _fp(out))
     return out
 
 

@@ -476,6 +476,13 @@ double orc_log_unmap(double f_min, double f_max, double zero_point, int p, int p
 /* ColorScheme  (colorscheme.rs)                                                              */
 /* ------------------------------------------------------------------------------------------ */
 
+static orc_gradient_fn g_gradient_fn = NULL;
+static void *g_gradient_user = NULL;
+void orc_set_gradient_fn(orc_gradient_fn fn, void *user) { g_gradient_fn = fn; g_gradient_user = user; }
+
+/* colour of the gradient at t: the table + index rule, or the continuous callback when gradient == NULL */
+static void gradient_eval(const uint8_t *gradient, int n_lut, int lut_mode, double t, uint8_t rgb[3]);
+
 int orc_lut_index(double t, int n_lut, int lut_mode)
 {
     /* [third-party] colorous 1.0.12 Gradient::eval_continuous for the 256-entry ramps
@@ -497,6 +504,13 @@ uint8_t orc_alpha_u8(float alpha)
     return (uint8_t)v;
 }
 
+static void gradient_eval(const uint8_t *gradient, int n_lut, int lut_mode, double t, uint8_t rgb[3])
+{
+    if (!gradient) { g_gradient_fn(t, rgb, g_gradient_user); return; }
+    int idx = orc_lut_index(t, n_lut, lut_mode);
+    rgb[0] = gradient[3 * idx + 0]; rgb[1] = gradient[3 * idx + 1]; rgb[2] = gradient[3 * idx + 2];
+}
+
 static float bounded_db(float min_db, float max_db, float l, float r)
 {
     /* colorscheme.rs:59-61 */
@@ -513,19 +527,17 @@ void orc_color_for(const uint8_t *gradient, int n_lut, int lut_mode, int stereo,
                    float l, float r, uint8_t rgb[3], float *alpha)
 {
     float bounded = bounded_db(min_db, max_db, l, r);
-    int idx;
     if (stereo) {
         /* :63-66: t = l as f64 / l1_norm(l, r) as f64 ; alpha = magnitude_bounded */
         volatile float l1 = fabsf(l) + fabsf(r);
         double t = (double)l / (double)l1;
-        idx = orc_lut_index(t, n_lut, lut_mode);
+        gradient_eval(gradient, n_lut, lut_mode, t, rgb);
         *alpha = bounded;
     } else {
         /* :67-70 */
-        idx = orc_lut_index((double)bounded, n_lut, lut_mode);
+        gradient_eval(gradient, n_lut, lut_mode, (double)bounded, rgb);
         *alpha = 1.0f;
     }
-    rgb[0] = gradient[3 * idx + 0]; rgb[1] = gradient[3 * idx + 1]; rgb[2] = gradient[3 * idx + 2];
 }
 
 void orc_render_column(const float *mags, size_t M, uint32_t sample_rate, int R, double f_min, double f_max,
@@ -555,10 +567,11 @@ void orc_lookup_table(const uint8_t *gradient, int n_lut, int lut_mode, int ster
             volatile float jf = (float)j / (float)(res - 1);
             volatile float pan = 1.0f - jf;
             float *o = table + 4 * ((size_t)i * (size_t)res + (size_t)j);
-            int idx = orc_lut_index(stereo ? (double)pan : (double)magnitude, n_lut, lut_mode);
-            o[0] = (float)gradient[3 * idx + 0] / 256.0f;
-            o[1] = (float)gradient[3 * idx + 1] / 256.0f;
-            o[2] = (float)gradient[3 * idx + 2] / 256.0f;
+            uint8_t c[3];
+            gradient_eval(gradient, n_lut, lut_mode, stereo ? (double)pan : (double)magnitude, c);
+            o[0] = (float)c[0] / 256.0f;
+            o[1] = (float)c[1] / 256.0f;
+            o[2] = (float)c[2] / 256.0f;
             o[3] = stereo ? magnitude : 1.0f;
         }
 }

@@ -92,6 +92,7 @@ SIGNATURES = [
     ("sgx_render_batch", C.c_int, [_ctx, _vp, _sz, _sz, _sz, _vp, C.POINTER(_sz)]),
     ("sgx_render_mags", C.c_int, [_ctx, _vp, _sz, _vp]),
     ("sgx_set_gradient", C.c_int, [_ctx, _vp, C.c_uint32, C.c_int]),
+    ("sgx_set_gradient_fn", C.c_int, [_ctx, _vp, _vp, C.c_int]),
     ("sgx_set_builtin_gradient", C.c_int, [_ctx, C.c_char_p]),
     ("sgx_builtin_gradient", C.c_int, [C.c_char_p, _vp]),
     ("sgx_lookup_table", C.c_int, [_ctx, C.c_uint32, _vp]),
@@ -101,6 +102,8 @@ SIGNATURES = [
     ("sgx_synth_white_noise", C.c_int, [_ctx, _vp, C.c_uint64, _sz, C.c_uint32, C.c_uint32]),
     ("sgx_checksum", C.c_int, [_ctx, _vp, _sz, C.c_uint64, C.POINTER(C.c_uint64)]),
 ]
+
+GRADIENT_FN = C.CFUNCTYPE(None, C.c_double, C.POINTER(C.c_uint8), C.c_void_p)
 
 _lib = None
 

@@ -64,7 +64,8 @@ const unsigned char *builtin_gradient(const char *name)
 
 int upload_palette(sgx_ctx *c)
 {
-    sgx::build_palette_thresholds(c->cfg.min_db, c->cfg.max_db, c->cfg.lut_index_mode, c->pal);
+    if (c->pal.segments) sgx::build_palette_segments(c->cfg.min_db, c->cfg.max_db, c->pal);
+    else sgx::build_palette_thresholds(c->cfg.min_db, c->cfg.max_db, c->cfg.lut_index_mode, c->pal);
     std::vector<uchar4> rgba(c->pal.n);
     for (uint32_t i = 0; i < c->pal.n; ++i)
         rgba[i] = make_uchar4(c->pal.rgb[3 * i], c->pal.rgb[3 * i + 1], c->pal.rgb[3 * i + 2], 255);
@@ -74,6 +75,7 @@ int upload_palette(sgx_ctx *c)
     SGX_HIP(c, upload(&c->d_lut_rgba, rgba.data(), rgba.size()));
     SGX_HIP(c, upload(&c->d_lut_thr, c->pal.lut_thr.data(), c->pal.lut_thr.size()));
     SGX_HIP(c, upload(&c->d_alpha_thr, c->pal.alpha_thr.data(), c->pal.alpha_thr.size()));
+    SGX_HIP(c, upload(&c->d_t_thr, c->pal.t_thr.data(), c->pal.t_thr.size()));
     return SGX_OK;
 }
 
@@ -237,7 +239,7 @@ void sgx_destroy(sgx_ctx *c)
     sgx::wg16384_destroy(c->d_fast_16k);
     c->d_fast_16k = nullptr;
     void *ptrs[] = {c->d_window, c->d_twiddle, c->d_rows, c->d_samples, c->d_lut_thr, c->d_alpha_thr,
-                    c->d_lut_rgba, c->d_ws_mags, c->d_one_in, c->d_one_out, c->d_cksum};
+                    c->d_lut_rgba, c->d_t_thr, c->d_ws_mags, c->d_one_in, c->d_one_out, c->d_cksum};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete c;
@@ -407,7 +409,25 @@ int sgx_set_gradient(sgx_ctx *c, const uint8_t *h_rgb, uint32_t n, int stereo)
     c->pal.rgb.assign(h_rgb, h_rgb + (size_t)n * 3);
     c->pal.n = n;
     c->pal.stereo = stereo ? 1 : 0;
+    c->pal.segments = false;
+    c->pal.fn = nullptr;
+    c->pal.t_thr.clear();
     return upload_palette(c);
+}
+
+int sgx_set_gradient_fn(sgx_ctx *c, sgx_gradient_fn eval, void *user, int stereo)
+{
+    if (!c) return SGX_ERR_INVALID_ARG;
+    if (!eval) return fail(c, SGX_ERR_INVALID_ARG, "sgx_set_gradient_fn: null callback");
+    c->pal.fn = eval;
+    c->pal.fn_user = user;
+    c->pal.stereo = stereo ? 1 : 0;
+    c->pal.segments = true;
+    int rc = upload_palette(c);
+    // the callback is only valid during this call (and sgx_lookup_table needs it again): keep the pointer,
+    // the caller owns its lifetime as documented
+    if (rc == SGX_OK && c->pal.n > 65536) return fail(c, SGX_ERR_INVALID_ARG, "sgx_set_gradient_fn: gradient has more than 65536 colour steps");
+    return rc;
 }
 
 int sgx_builtin_gradient(const char *name, uint8_t *h_rgb_out)
@@ -435,11 +455,18 @@ int sgx_lookup_table(sgx_ctx *c, uint32_t res, float *h_out)
         for (uint32_t j = 0; j < res; ++j) {
             const float magnitude = (float)i / (float)(res - 1);
             const float pan = 1.0f - ((float)j / (float)(res - 1));
-            const int idx = sgx::lut_index_host(c->pal.stereo ? (double)pan : (double)magnitude, c->pal.n, c->cfg.lut_index_mode);
+            const double tt = c->pal.stereo ? (double)pan : (double)magnitude;
+            uint8_t rgb[3];
+            if (c->pal.segments) {
+                c->pal.fn(tt, rgb, c->pal.fn_user);
+            } else {
+                const int idx = sgx::lut_index_host(tt, c->pal.n, c->cfg.lut_index_mode);
+                rgb[0] = c->pal.rgb[3 * idx]; rgb[1] = c->pal.rgb[3 * idx + 1]; rgb[2] = c->pal.rgb[3 * idx + 2];
+            }
             float *o = h_out + 4 * ((size_t)i * res + j);
-            o[0] = (float)c->pal.rgb[3 * idx + 0] / 256.0f;
-            o[1] = (float)c->pal.rgb[3 * idx + 1] / 256.0f;
-            o[2] = (float)c->pal.rgb[3 * idx + 2] / 256.0f;
+            o[0] = (float)rgb[0] / 256.0f;
+            o[1] = (float)rgb[1] / 256.0f;
+            o[2] = (float)rgb[2] / 256.0f;
             o[3] = c->pal.stereo ? magnitude : 1.0f;
         }
     return SGX_OK;

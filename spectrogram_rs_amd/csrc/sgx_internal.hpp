@@ -46,11 +46,19 @@ struct Palette {
     int stereo = 0;
     std::vector<float> lut_thr;     // [n-1]   smallest power whose LUT index is >= i+1 (mono)
     std::vector<float> alpha_thr;   // [255]   smallest power whose alpha byte is >= i+1 (stereo)
+    // continuous gradient given as a callback (sgx_set_gradient_fn): rgb[] then holds one colour per
+    // constant SEGMENT of the colour function instead of one per uniform LUT step
+    bool segments = false;
+    sgx_gradient_fn fn = nullptr;
+    void *fn_user = nullptr;
+    std::vector<double> t_thr;      // stereo + segments: smallest t (as double) at which segment i+1 starts
+    uint8_t nan_rgb[3] = {0, 0, 0}; // colour of t = NaN (l = r = 0 in the diverging branch)
 };
 
 void build_tables(uint32_t W, uint32_t R, uint32_t sample_rate_u32, double f_min, double f_max, uint32_t interp,
                   Tables &out);
 void build_palette_thresholds(float min_db, float max_db, uint32_t lut_mode, Palette &pal);
+void build_palette_segments(float min_db, float max_db, Palette &pal);
 int lut_index_host(double t, uint32_t n, uint32_t mode);
 uint8_t alpha_u8_host(float alpha);
 float bounded_db_host(float min_db, float max_db, float power);
@@ -75,6 +83,7 @@ struct sgx_ctx {
     float *d_lut_thr = nullptr;    // [n-1]
     float *d_alpha_thr = nullptr;  // [255]
     uchar4 *d_lut_rgba = nullptr;  // [n]
+    double *d_t_thr = nullptr;     // [n-1], segment palettes with a diverging scheme only
     void *d_fast = nullptr;        // tables of the wave-per-transform kernel (opaque here)
     void *d_fast_wg = nullptr;     // tables of the workgroup-per-transform kernel
     void *d_blu = nullptr;         // tables of the Bluestein (non-power-of-two) kernel

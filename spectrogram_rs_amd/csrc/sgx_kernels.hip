@@ -143,6 +143,9 @@ struct RenderParams {
     const uchar4 *lut_rgba;     // [n_lut]
     uint8_t *rgba;              // [n_columns][R][4]
     uint32_t M, R, n_lut, interp, stereo, lut_mode;
+    const double *t_thr;        // segment palettes, diverging branch: [n_lut - 1] switch points of the balance t
+    uint32_t segments;
+    uchar4 nan_rgba;            // colour of t = NaN
 };
 
 // number of thresholds <= v in a sorted table (NaN thresholds sort last and never match)
@@ -218,14 +221,28 @@ __global__ void __launch_bounds__(256) render_kernel(RenderParams p)
             // :63-66
             const float l1 = fabsf(l) + fabsf(r);
             const double t = (double)l / (double)l1;
-            double x = (p.lut_mode == SGX_LUT_ROUND_NM1) ? floor(t * (double)(p.n_lut - 1) + 0.5) : floor(t * (double)p.n_lut);
-            uint32_t idx = 0;
-            if (x > 0.0) idx = x >= (double)p.n_lut ? p.n_lut - 1 : (uint32_t)x;
-            px = p.lut_rgba[idx];
+            if (p.segments) {
+                if (t != t) {
+                    px = p.nan_rgba;
+                } else {
+                    uint32_t lo = 0, hi = p.n_lut - 1;  // number of switch points <= t
+                    while (lo < hi) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if (t >= p.t_thr[mid]) lo = mid + 1;
+                        else hi = mid;
+                    }
+                    px = p.lut_rgba[lo];
+                }
+            } else {
+                double x = (p.lut_mode == SGX_LUT_ROUND_NM1) ? floor(t * (double)(p.n_lut - 1) + 0.5) : floor(t * (double)p.n_lut);
+                uint32_t idx = 0;
+                if (x > 0.0) idx = x >= (double)p.n_lut ? p.n_lut - 1 : (uint32_t)x;
+                px = p.lut_rgba[idx];
+            }
             px.w = (unsigned char)count_reached(athr, 255, power);  // (alpha * 255.0) as u8, simple_spectrogram.rs:159
         } else {
             // :67-70; alpha = 1.0 -> 255
-            px = p.lut_rgba[count_reached(thr, p.n_lut - 1, power)];
+            px = (p.segments && power != power) ? p.nan_rgba : p.lut_rgba[count_reached(thr, p.n_lut - 1, power)];
             px.w = 255;
         }
         dst[p.R - 1 - py] = px;  // simple_spectrogram.rs:150
@@ -249,6 +266,9 @@ hipError_t launch_render(const sgx_ctx *c, const float *d_mags, size_t n_columns
     p.interp = c->cfg.interp;
     p.stereo = (uint32_t)c->pal.stereo;
     p.lut_mode = c->cfg.lut_index_mode;
+    p.t_thr = c->d_t_thr;
+    p.segments = c->pal.segments ? 1u : 0u;
+    p.nan_rgba = make_uchar4(c->pal.nan_rgb[0], c->pal.nan_rgb[1], c->pal.nan_rgb[2], 255);
     const size_t lds = (size_t)(c->M + 1) * sizeof(float2) + (size_t)(c->pal.n + 255) * sizeof(float);
     static thread_local size_t attr_set_for = 0;
     if (lds > 64 * 1024 && attr_set_for < lds) {

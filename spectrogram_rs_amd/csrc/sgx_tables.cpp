@@ -6,6 +6,7 @@
 // The arithmetic follows the reference's f32/f64 operation order (citations inline; file:line
 // in the reference repository).  This file must be compiled without FMA contraction
 // (-ffp-contract=off): every float operation below rounds exactly once, as rustc emits it.
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <limits>
@@ -204,6 +205,102 @@ void build_palette_thresholds(float min_db, float max_db, uint32_t lut_mode, Pal
     for (int a = 1; a <= 255; ++a)
         pal.alpha_thr[a - 1] =
             first_power_reaching(a, [&](float p) { return (int)alpha_u8_host(bounded_db_host(min_db, max_db, p)); });
+}
+
+
+namespace {
+
+inline bool same_rgb(const uint8_t a[3], const uint8_t b[3]) { return a[0] == b[0] && a[1] == b[1] && a[2] == b[2]; }
+inline float bits_f32(uint32_t b) { float v; std::memcpy(&v, &b, 4); return v; }
+inline uint32_t f32_bits(float v) { uint32_t b; std::memcpy(&b, &v, 4); return b; }
+
+}  // namespace
+
+void build_palette_segments(float min_db, float max_db, Palette &pal)
+{
+    // colour as a function of the power l^2 + r^2 (mono branch of color_for, colorscheme.rs:59-61,69):
+    // a step function of bytes.  Sample it on a grid that is finer than its steps, then bisect over
+    // float bit patterns inside every grid cell whose ends differ: the thresholds are the exact
+    // switch points of  eval(bounded_dB(power))  as the host evaluates it.
+    const int G = 8192;
+    auto color_at = [&](float power, uint8_t c[3]) { pal.fn((double)bounded_db_host(min_db, max_db, power), c, pal.fn_user); };
+    std::vector<uint32_t> grid;
+    grid.push_back(0u);
+    for (int g = 0; g <= G; ++g) {
+        const double t = -0.02 + 1.04 * (double)g / (double)G;
+        const double db = t * ((double)max_db - (double)min_db) + (double)min_db;
+        double pw = pow(10.0, db / 10.0) - 1e-7;
+        if (pw < 0.0) pw = 0.0;
+        grid.push_back(f32_bits((float)pw));
+    }
+    grid.push_back(0x7f800000u);  // +inf
+    std::sort(grid.begin(), grid.end());
+    grid.erase(std::unique(grid.begin(), grid.end()), grid.end());
+
+    pal.rgb.clear();
+    pal.lut_thr.clear();
+    uint8_t cur[3], cb[3], cm[3];
+    color_at(bits_f32(grid[0]), cur);
+    pal.rgb.insert(pal.rgb.end(), cur, cur + 3);
+    for (size_t i = 0; i + 1 < grid.size(); ++i) {
+        uint32_t lo = grid[i];
+        const uint32_t b = grid[i + 1];
+        color_at(bits_f32(b), cb);
+        while (!same_rgb(cur, cb)) {
+            uint32_t l = lo, h = b;  // colour(l) == cur, colour(h) != cur
+            while (h - l > 1) {
+                const uint32_t m = l + (h - l) / 2;
+                color_at(bits_f32(m), cm);
+                if (same_rgb(cm, cur)) l = m;
+                else h = m;
+            }
+            color_at(bits_f32(h), cur);
+            pal.lut_thr.push_back(bits_f32(h));
+            pal.rgb.insert(pal.rgb.end(), cur, cur + 3);
+            lo = h;
+            if (pal.rgb.size() / 3 > 60000) break;  // not a byte-valued gradient
+        }
+    }
+    pal.n = (uint32_t)(pal.rgb.size() / 3);
+    pal.fn(std::numeric_limits<double>::quiet_NaN(), pal.nan_rgb, pal.fn_user);
+
+    // alpha byte thresholds (diverging branch, simple_spectrogram.rs:159) -- as in the LUT mode
+    pal.alpha_thr.assign(255, 0.0f);
+    for (int a = 1; a <= 255; ++a)
+        pal.alpha_thr[a - 1] =
+            first_power_reaching(a, [&](float p) { return (int)alpha_u8_host(bounded_db_host(min_db, max_db, p)); });
+
+    // diverging branch: colour as a function of t = l / (|l| + |r|) in [-1, 1] (colorscheme.rs:65-66)
+    pal.t_thr.clear();
+    if (pal.stereo) {
+        std::vector<uint8_t> seg;
+        auto col_t = [&](double t, uint8_t c[3]) { pal.fn(t, c, pal.fn_user); };
+        col_t(-1.0, cur);
+        seg.insert(seg.end(), cur, cur + 3);
+        for (int g = 0; g < G; ++g) {
+            double lo = -1.0 + 2.0 * (double)g / (double)G;
+            const double b = -1.0 + 2.0 * (double)(g + 1) / (double)G;
+            col_t(b, cb);
+            while (!same_rgb(cur, cb)) {
+                double l = lo, h = b;
+                for (;;) {
+                    const double m = l + (h - l) * 0.5;
+                    if (!(m > l) || !(m < h)) break;  // adjacent doubles
+                    col_t(m, cm);
+                    if (same_rgb(cm, cur)) l = m;
+                    else h = m;
+                }
+                col_t(h, cur);
+                pal.t_thr.push_back(h);
+                seg.insert(seg.end(), cur, cur + 3);
+                lo = h;
+                if (seg.size() / 3 > 60000) break;
+            }
+        }
+        pal.rgb = seg;  // the diverging branch indexes colours by balance, not by power
+        pal.n = (uint32_t)(seg.size() / 3);
+        pal.lut_thr.assign(pal.n > 0 ? pal.n - 1 : 0, std::numeric_limits<float>::quiet_NaN());
+    }
 }
 
 }  // namespace sgx

@@ -423,7 +423,7 @@ bool wg4096_can_fuse_render(const sgx_ctx *c, const void *tables)
 {
     const auto *t = static_cast<const wg::WgTables *>(tables);
     // mono (sequential) colour schemes with a 256-entry ramp; diverging schemes take the two-kernel path
-    return t && t->fusable && c->pal.n == 256 && !c->pal.stereo;
+    return t && t->fusable && c->pal.n == 256 && !c->pal.stereo && !c->pal.segments;
 }
 
 namespace {

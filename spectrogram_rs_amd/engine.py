@@ -187,6 +187,15 @@ class SpectrogramEngine:
         rgb = np.ascontiguousarray(rgb, np.uint8).reshape(-1, 3)
         self._check(self._lib.sgx_set_gradient(self._ctx, rgb.ctypes.data_as(C.c_void_p), rgb.shape[0], int(stereo)))
 
+    def set_gradient_fn(self, fn, stereo: bool = False):
+        """Continuous gradient: `fn(t) -> (r, g, b)` stands in for colorous' eval_continuous(t).  It is
+        called on the host while the thresholds are built (and by lookup_table), never during a launch."""
+        def thunk(t, out, _user):
+            r, g, b = fn(t)
+            out[0], out[1], out[2] = int(r), int(g), int(b)
+        self._gradient_cb = _lib.GRADIENT_FN(thunk)  # keep alive: lookup_table calls it again
+        self._check(self._lib.sgx_set_gradient_fn(self._ctx, C.cast(self._gradient_cb, C.c_void_p), None, int(stereo)))
+
     def set_builtin_gradient(self, name: str):
         self._check(self._lib.sgx_set_builtin_gradient(self._ctx, name.encode()))
 

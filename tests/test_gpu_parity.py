@@ -434,6 +434,64 @@ def test_cpp_host_mirror_program(torch_cuda, mags_err, tmp_path, period, Wexp):
     assert mags_err(got, ref[:, 0]) <= (2.0 if Wexp == 2048 else 3.0)
 
 
+def _turbo(t):
+    # d3-scale-chromatic interpolateTurbo (the polynomial colorous::TURBO ports), clamped and rounded
+    t = 0.0 if t != t else max(0.0, min(1.0, t))
+    r = 34.61 + t * (1172.33 - t * (10793.56 - t * (33300.12 - t * (38394.49 - t * 14825.05))))
+    g = 23.31 + t * (557.33 + t * (1225.33 - t * (3574.96 - t * (1073.77 + t * 707.56))))
+    b = 27.2 + t * (3211.1 - t * (15327.97 - t * (27814.0 - t * (22569.18 - t * 6838.66))))
+    return tuple(int(max(0, min(255, round(v)))) for v in (r, g, b))
+
+
+def _diverging(t):
+    # a three-stop diverging ramp (blue - white - red), linear in RGB, rounded: non-monotone per channel
+    t = 0.0 if t != t else max(0.0, min(1.0, t))
+    lo, mid, hi = (33, 102, 172), (247, 247, 247), (178, 24, 43)
+    a, b, u = (lo, mid, t * 2) if t < 0.5 else (mid, hi, t * 2 - 1)
+    return tuple(int(round(a[i] + (b[i] - a[i]) * u)) for i in range(3))
+
+
+def test_continuous_gradients_through_a_callback(torch_cuda):
+    # ColorScheme::new_mono / new_stereo with ANY colorous gradient: the colour function arrives as a
+    # callback; its byte switch points become thresholds; bytes equal the oracle calling the same function
+    torch = torch_cuda
+    pcm = oracle.white_noise(2 * (W + 15 * H), seed=77).reshape(-1, 2) * np.array([1.0, 0.4], np.float32)
+    mags = oracle.stream_process(pcm, 2, W, H)[:, 0]
+    mags = (mags * np.logspace(-4, 1.5, 16, dtype=np.float32)[:, None, None]).astype(np.float32)
+    mags[5] = 0.0
+    dev = to_dev(torch, mags)
+    eng = engine(window_samples=W, hop_samples=H, channels=2)
+    try:
+        for fn, stereo in ((_turbo, False), (_diverging, True), (_turbo, True)):
+            eng.set_gradient_fn(fn, stereo=stereo)
+            oracle.set_gradient_fn(fn)
+            got = eng.render_mags(dev).cpu().numpy()
+            ref = oracle.render_columns(mags, SR, None, stereo=stereo)
+            assert np.array_equal(got, ref), (fn.__name__, stereo)
+            assert len(np.unique(ref[..., :3].reshape(-1, 3), axis=0)) > 150
+            assert np.array_equal(eng.lookup_table(32), oracle.lookup_table(None, 32, stereo=stereo))
+        # end to end from PCM as well (two-kernel route for callback gradients)
+        eng.set_gradient_fn(_turbo)
+        oracle.set_gradient_fn(_turbo)
+        x = to_dev(torch, pcm * np.float32(0.05))
+        rg = eng.render_batch(x).cpu().numpy()[:, 0]
+        own = oracle.render_columns(eng.stft_batch(x).cpu().numpy()[:, 0], SR, None)
+        assert np.array_equal(rg, own)
+        # the ColorScheme mirror routes callables the same way (Turbo = the d3 polynomial)
+        from spectrogram_rs_amd import ColorScheme, default_color_schemes
+        turbo = [c for c in default_color_schemes() if c.name == "Turbo"][0]
+        turbo.apply(eng)
+        oracle.set_gradient_fn(turbo.gradient_fn)
+        assert np.array_equal(eng.render_mags(dev).cpu().numpy(), oracle.render_columns(mags, SR, None))
+        assert turbo.foreground() == _turbo(1.0) and turbo.background() == _turbo(0.0)
+        # a table set afterwards replaces the callback
+        eng.set_builtin_gradient("viridis")
+        g = np.load(os.path.join(os.path.dirname(__file__), "golden", "gradients.npz"))["viridis"]
+        assert np.array_equal(eng.render_mags(dev).cpu().numpy(), oracle.render_columns(mags, SR, g))
+    finally:
+        oracle.set_gradient_fn(None)
+
+
 def test_lookup_table_and_widget_ring(torch_cuda, gradients):
     torch = torch_cuda
     from spectrogram_rs_amd import ColorScheme, RingBuffer, SimpleSpectrogram
