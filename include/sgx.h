@@ -177,6 +177,14 @@ SGX_API int sgx_render_batch(sgx_ctx *ctx, const float *d_pcm, size_t n_samples,
  *   d_mags [n_columns][M][2] -> d_rgba [n_columns][R][4]. */
 SGX_API int sgx_render_mags(sgx_ctx *ctx, const float *d_mags, size_t n_columns, uint8_t *d_rgba);
 
+/* FrequencySample::magnitude_in(f0..f1) (src/fourier/mod.rs:17-21; interpolated_frequency_sample.rs:60-75)
+ * for n_ranges arbitrary frequency ranges and every column: the mean of the interpolated (l, r) samples,
+ * no colour.  h_ranges [n_ranges][2] = (f0, f1) in Hz on the host; d_out [n_columns][n_ranges][2] float.
+ * This is what SpectrumAnalyzer::push_frequencies consumes (spectrum_analyzer.rs:48-61: 128 log-spaced
+ * bands).  The per-range tables are built on the host and cached until the range set changes. */
+SGX_API int sgx_magnitude_in(sgx_ctx *ctx, const float *d_mags, size_t n_columns, const float *h_ranges,
+                             uint32_t n_ranges, float *d_out);
+
 /* ---- ColorScheme ---------------------------------------------------------------------------- */
 
 /* ColorScheme::new_mono(gradient, name) / new_stereo(gradient, background, name)

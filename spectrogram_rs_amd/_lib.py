@@ -91,6 +91,7 @@ SIGNATURES = [
     ("sgx_process_one", C.c_int, [_ctx, _vp, _sz, _vp]),
     ("sgx_render_batch", C.c_int, [_ctx, _vp, _sz, _sz, _sz, _vp, C.POINTER(_sz)]),
     ("sgx_render_mags", C.c_int, [_ctx, _vp, _sz, _vp]),
+    ("sgx_magnitude_in", C.c_int, [_ctx, _vp, _sz, _vp, C.c_uint32, _vp]),
     ("sgx_set_gradient", C.c_int, [_ctx, _vp, C.c_uint32, C.c_int]),
     ("sgx_set_gradient_fn", C.c_int, [_ctx, _vp, _vp, C.c_int]),
     ("sgx_set_builtin_gradient", C.c_int, [_ctx, C.c_char_p]),

@@ -239,7 +239,7 @@ void sgx_destroy(sgx_ctx *c)
     sgx::wg16384_destroy(c->d_fast_16k);
     c->d_fast_16k = nullptr;
     void *ptrs[] = {c->d_window, c->d_twiddle, c->d_rows, c->d_samples, c->d_lut_thr, c->d_alpha_thr,
-                    c->d_lut_rgba, c->d_t_thr, c->d_ws_mags, c->d_one_in, c->d_one_out, c->d_cksum};
+                    c->d_lut_rgba, c->d_t_thr, c->d_band_rows, c->d_band_samples, c->d_ws_mags, c->d_one_in, c->d_one_out, c->d_cksum};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete c;
@@ -399,6 +399,29 @@ int sgx_render_batch(sgx_ctx *c, const float *d_pcm, size_t n_samples, size_t fi
         if (e != hipSuccess) return fail_hip(c, e, "sgx_render_batch: render launch");
     }
     if (n_out) *n_out = n;
+    return SGX_OK;
+}
+
+int sgx_magnitude_in(sgx_ctx *c, const float *d_mags, size_t n_columns, const float *h_ranges, uint32_t n_ranges, float *d_out)
+{
+    if (!c) return SGX_ERR_INVALID_ARG;
+    if (n_columns == 0 || n_ranges == 0) return SGX_OK;
+    if (!d_mags || !h_ranges || !d_out) return fail(c, SGX_ERR_INVALID_ARG, "sgx_magnitude_in: null buffer");
+    SGX_HIP(c, hipSetDevice(c->device));
+    const std::vector<float> key(h_ranges, h_ranges + (size_t)n_ranges * 2);
+    if (key != c->bands_key || !c->d_band_rows) {
+        std::vector<float> f0(n_ranges), f1(n_ranges);
+        for (uint32_t i = 0; i < n_ranges; ++i) { f0[i] = h_ranges[2 * i]; f1[i] = h_ranges[2 * i + 1]; }
+        std::vector<sgx::RowEntry> rows;
+        std::vector<sgx::SampleEntry> samples;
+        sgx::build_range_tables(c->W, c->sr_u32, c->cfg.interp, f0.data(), f1.data(), n_ranges, rows, samples);
+        SGX_HIP(c, hipStreamSynchronize(c->stream));  // the previous range set may still be in use
+        SGX_HIP(c, upload(&c->d_band_rows, rows.data(), rows.size()));
+        SGX_HIP(c, upload(&c->d_band_samples, samples.data(), samples.size()));
+        c->bands_key = key;
+    }
+    hipError_t e = sgx::launch_magnitude_in(c, d_mags, n_columns, c->d_band_rows, c->d_band_samples, n_ranges, d_out);
+    if (e != hipSuccess) return fail_hip(c, e, "sgx_magnitude_in: kernel launch");
     return SGX_OK;
 }
 

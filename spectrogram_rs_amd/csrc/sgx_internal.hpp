@@ -57,6 +57,8 @@ struct Palette {
 
 void build_tables(uint32_t W, uint32_t R, uint32_t sample_rate_u32, double f_min, double f_max, uint32_t interp,
                   Tables &out);
+void build_range_tables(uint32_t W, uint32_t sample_rate_u32, uint32_t interp, const float *range_f0, const float *range_f1,
+                        uint32_t n_ranges, std::vector<RowEntry> &rows, std::vector<SampleEntry> &samples);
 void build_palette_thresholds(float min_db, float max_db, uint32_t lut_mode, Palette &pal);
 void build_palette_segments(float min_db, float max_db, Palette &pal);
 int lut_index_host(double t, uint32_t n, uint32_t mode);
@@ -94,6 +96,10 @@ struct sgx_ctx {
     size_t ws_frames = 0;
     float *d_one_in = nullptr, *d_one_out = nullptr;
     unsigned long long *d_cksum = nullptr;
+    // cached tables of the last sgx_magnitude_in range set
+    std::vector<float> bands_key;
+    sgx::RowEntry *d_band_rows = nullptr;
+    sgx::SampleEntry *d_band_samples = nullptr;
 
     std::string err;
 };
@@ -133,6 +139,8 @@ hipError_t launch_stft_wg4096_f16(const sgx_ctx *c, const void *tables, const fl
                                   size_t first_frame, size_t n_frames, size_t total_frames, void *d_mags_f16);
 hipError_t launch_to_half(const sgx_ctx *c, const float *d_in, void *d_out, size_t n_pairs);
 hipError_t launch_render(const sgx_ctx *c, const float *d_mags, size_t n_columns, uint8_t *d_rgba);
+hipError_t launch_magnitude_in(const sgx_ctx *c, const float *d_mags, size_t n_columns, const RowEntry *d_rows,
+                               const SampleEntry *d_samples, uint32_t n_ranges, float *d_out);
 hipError_t launch_white_noise(const sgx_ctx *c, float *d_out, uint64_t first, size_t n, uint32_t channels, uint32_t seed);
 hipError_t launch_checksum(const sgx_ctx *c, const uint32_t *d_words, size_t n_words, uint64_t base_word,
                            unsigned long long *d_acc);

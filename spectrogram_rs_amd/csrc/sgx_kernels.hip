@@ -293,6 +293,100 @@ hipError_t launch_render(const sgx_ctx *c, const float *d_mags, size_t n_columns
 }
 
 // ------------------------------------------------------------------------------------------------
+// FrequencySample::magnitude_in over arbitrary ranges (src/fourier/mod.rs:17-21): the pixel stage
+// without the colour -- what SpectrumAnalyzer::push_frequencies consumes (spectrum_analyzer.rs:60-61)
+// ------------------------------------------------------------------------------------------------
+
+struct BandsParams {
+    const float *mags;
+    const RowEntry *rows;
+    const SampleEntry *samples;
+    float *out;  // [n_columns][n_ranges][2]
+    uint32_t M, n_ranges, interp;
+};
+
+__global__ void __launch_bounds__(256) magnitude_in_kernel(BandsParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2 *m = reinterpret_cast<float2 *>(smem_raw);
+    const uint32_t tid = threadIdx.x, nt = blockDim.x;
+    const size_t col = blockIdx.x;
+    const float2 *src = reinterpret_cast<const float2 *>(p.mags) + col * p.M;
+    for (uint32_t i = tid; i < p.M; i += nt) m[i] = src[i];
+    __syncthreads();
+    const int32_t last = (int32_t)p.M - 1;
+    float2 *dst = reinterpret_cast<float2 *>(p.out) + col * p.n_ranges;
+    for (uint32_t b = tid; b < p.n_ranges; b += nt) {
+        const RowEntry row = p.rows[b];
+        float sl = 0.0f, sr = 0.0f;
+        for (uint32_t i = 0; i < row.count; ++i) {
+            const SampleEntry se = p.samples[row.first + i];
+            float vl, vr;
+            if (p.interp == SGX_INTERP_COSINE) {
+                const float2 a = m[se.i0], bb = m[se.i1];
+                vl = a.x * se.w1 + bb.x * se.w2;
+                vr = a.y * se.w1 + bb.y * se.w2;
+            } else {
+                const int32_t x1 = se.i0;
+                const int32_t x0 = x1 > 0 ? x1 - 1 : 0;
+                const int32_t x2 = x1 + 1 < last ? x1 + 1 : last;
+                const int32_t x3 = x1 + 2 < last ? x1 + 2 : last;
+                const float2 y0 = m[x0], y1 = m[x1], y2 = m[x2], y3 = m[x3];
+                const float mu = se.w0, mu2 = se.w1, mu3 = se.w2;
+                {
+                    const float a0 = ((y3.x - y2.x) - y0.x) + y1.x;
+                    const float a1 = (y0.x - y1.x) - a0;
+                    const float a2 = y2.x - y0.x;
+                    vl = ((a0 * mu3) + (a1 * mu2)) + ((a2 * mu) + y1.x);
+                }
+                {
+                    const float a0 = ((y3.y - y2.y) - y0.y) + y1.y;
+                    const float a1 = (y0.y - y1.y) - a0;
+                    const float a2 = y2.y - y0.y;
+                    vr = ((a0 * mu3) + (a1 * mu2)) + ((a2 * mu) + y1.y);
+                }
+            }
+            sl = sl + vl;
+            sr = sr + vr;
+        }
+        dst[b] = make_float2(sl / row.count_f, sr / row.count_f);
+    }
+}
+
+hipError_t launch_magnitude_in(const sgx_ctx *c, const float *d_mags, size_t n_columns, const RowEntry *d_rows,
+                               const SampleEntry *d_samples, uint32_t n_ranges, float *d_out)
+{
+    if (n_columns == 0 || n_ranges == 0) return hipSuccess;
+    BandsParams p;
+    p.mags = d_mags;
+    p.rows = d_rows;
+    p.samples = d_samples;
+    p.out = d_out;
+    p.M = c->M;
+    p.n_ranges = n_ranges;
+    p.interp = c->cfg.interp;
+    const size_t lds = (size_t)(c->M + 1) * sizeof(float2);
+    static thread_local size_t attr_set_for = 0;
+    if (lds > 64 * 1024 && attr_set_for < lds) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(magnitude_in_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set_for = lds;
+    }
+    const size_t max_chunk = 1u << 30;
+    for (size_t done = 0; done < n_columns; done += max_chunk) {
+        const size_t chunk = n_columns - done < max_chunk ? n_columns - done : max_chunk;
+        BandsParams q = p;
+        q.mags = d_mags + done * (size_t)c->M * 2;
+        q.out = d_out + done * (size_t)n_ranges * 2;
+        hipLaunchKernelGGL(magnitude_in_kernel, dim3((unsigned)chunk), dim3(256), lds, c->stream, q);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+// ------------------------------------------------------------------------------------------------
 // f32 -> f16 magnitudes (only for STFT kernels that have no native half store)
 // ------------------------------------------------------------------------------------------------
 

@@ -42,7 +42,7 @@ inline float index_of(float f, float period, uint32_t M)
 
 void build_tables(uint32_t W, uint32_t R, uint32_t sr, double f_min, double f_max, uint32_t interp, Tables &out)
 {
-    const uint32_t P = 2 * W, M = W - 1;
+    const uint32_t P = 2 * W;
 
     // fft.rs:61 -- 0.5 * (1.0 - ((TAU * i as f32) / (W as f32)).cos()), all f32, product first.
     out.window.resize(W);
@@ -82,22 +82,33 @@ void build_tables(uint32_t W, uint32_t R, uint32_t sr, double f_min, double f_ma
     }
 
     // interpolated_frequency_sample.rs:60-75 for every row, :79-105 for the weights.
-    out.rows.resize(R);
-    out.samples.clear();
+    std::vector<float> f0(R), f1(R);
+    for (uint32_t py = 0; py < R; ++py) { f0[py] = out.edges[py]; f1[py] = out.edges[py + 1]; }
+    build_range_tables(W, sr, interp, f0.data(), f1.data(), R, out.rows, out.samples);
+}
+
+void build_range_tables(uint32_t W, uint32_t sr, uint32_t interp, const float *range_f0, const float *range_f1, uint32_t n_ranges,
+                        std::vector<RowEntry> &rows, std::vector<SampleEntry> &samples)
+{
+    // FrequencySample::magnitude_in(f0..f1) (interpolated_frequency_sample.rs:60-75) for each range:
+    // sample count, lin_space positions, fractional indices and interpolation weights (:79-105)
+    const uint32_t M = W - 1;
+    rows.resize(n_ranges);
+    samples.clear();
     const float period = period_of(M, sr);
     const float pi = 3.14159265358979323846264338327950288f;
-    for (uint32_t py = 0; py < R; ++py) {
-        const float f0 = out.edges[py], f1 = out.edges[py + 1];
+    for (uint32_t py = 0; py < n_ranges; ++py) {
+        const float f0 = range_f0[py], f1 = range_f1[py];
         const float i0 = index_of(f0, period, M), i1 = index_of(f1, period, M);
         float d = i1 - i0;
         int64_t n = f32_as_index(floorf(d));
         if (n < 1) n = 1;
         RowEntry re;
-        re.first = (uint32_t)out.samples.size();
+        re.first = (uint32_t)samples.size();
         re.count = (uint32_t)n;
         re.count_f = (float)n;
         re.pad = 0;
-        out.rows[py] = re;
+        rows[py] = re;
         // iter_num_tools lin_space over the half-open range: step = (end - start) / n,
         // x_i = start + i * step
         const float span = f1 - f0;
@@ -132,7 +143,7 @@ void build_tables(uint32_t W, uint32_t R, uint32_t sr, double f_min, double f_ma
                 se.w1 = mu2;
                 se.w2 = mu3;
             }
-            out.samples.push_back(se);
+            samples.push_back(se);
         }
     }
 }

@@ -182,6 +182,20 @@ class SpectrogramEngine:
             self._check(self._lib.sgx_render_mags(self._ctx, self._dev_f32(mags), n, C.c_void_p(out.data_ptr())))
         return out
 
+    def magnitude_in(self, mags, ranges: np.ndarray, out=None):
+        """FrequencySample::magnitude_in for every column and every (f0, f1) range:
+        mags [columns][M][2] -> [columns][n_ranges][2] float32."""
+        import torch
+
+        ranges = np.ascontiguousarray(ranges, np.float32).reshape(-1, 2)
+        n = mags.numel() // (self.M * 2)
+        if out is None:
+            out = torch.empty((n, ranges.shape[0], 2), dtype=torch.float32, device=mags.device)
+        if n and ranges.shape[0]:
+            self._check(self._lib.sgx_magnitude_in(self._ctx, self._dev_f32(mags), n, ranges.ctypes.data_as(C.c_void_p),
+                                                   ranges.shape[0], C.c_void_p(out.data_ptr())))
+        return out
+
     # ---- colour scheme ---------------------------------------------------------------------
     def set_gradient(self, rgb: np.ndarray, stereo: bool = False):
         rgb = np.ascontiguousarray(rgb, np.uint8).reshape(-1, 3)

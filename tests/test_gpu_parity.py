@@ -492,6 +492,27 @@ def test_continuous_gradients_through_a_callback(torch_cuda):
         oracle.set_gradient_fn(None)
 
 
+@pytest.mark.parametrize("interp", [0, 1])
+def test_magnitude_in_over_spectrum_analyzer_bands(torch_cuda, interp):
+    # FrequencySample::magnitude_in (the pixel-stage boundary, src/fourier/mod.rs:17-21) over the 128 log-spaced
+    # bands of SpectrumAnalyzer::push_frequencies (spectrum_analyzer.rs:20-61), bit-exact vs the oracle
+    torch = torch_cuda
+    start, end, nb = np.float32(32.0), np.float32(24000.0), 129
+    ls, le = np.float32(np.log10(start)), np.float32(np.log10(end))
+    step = np.float32((le - ls) / np.float32(nb))
+    edges = np.array([np.float32(10.0) ** np.float32(ls + step * np.float32(i)) for i in range(nb + 1)], np.float32)
+    ranges = np.stack([edges[:-1], edges[1:]], 1)[:128]
+    ranges = np.concatenate([ranges, np.array([[0.0, 5.0], [23990.0, 24000.0], [100.0, 100.0], [5000.0, 4000.0]], np.float32)])
+    eng = engine(window_samples=W, hop_samples=H, channels=2, interp=interp)
+    mags = oracle.stream_process(oracle.white_noise(2 * (W + 5 * H), seed=12), 2, W, H)[:, 0]
+    got = eng.magnitude_in(to_dev(torch, mags), ranges).cpu().numpy()
+    ref = np.stack([[oracle.magnitude_in(m, SR, float(a), float(b), interp) for a, b in ranges] for m in mags])
+    assert got.shape == ref.shape == (6, 132, 2) and np.array_equal(got, ref)
+    # a different range set replaces the cached tables
+    got2 = eng.magnitude_in(to_dev(torch, mags), ranges[:7]).cpu().numpy()
+    assert np.array_equal(got2, ref[:, :7])
+
+
 def test_lookup_table_and_widget_ring(torch_cuda, gradients):
     torch = torch_cuda
     from spectrogram_rs_amd import ColorScheme, RingBuffer, SimpleSpectrogram
