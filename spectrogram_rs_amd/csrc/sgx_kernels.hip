@@ -107,12 +107,10 @@ hipError_t launch_stft_generic(const sgx_ctx *c, const float *d_pcm, uint32_t ch
     p.half_scale = 0.5f;
     p.scale = 2.0f / (float)c->W;
     const size_t lds = (size_t)c->P * sizeof(float2);
-    static thread_local size_t attr_set_for = 0;
-    if (lds > 64 * 1024 && attr_set_for < lds) {
+    if (lds > 64 * 1024) {  // per launch: the attribute is per device, and a process may hold contexts on several
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(stft_generic_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        attr_set_for = lds;
     }
     // gridDim.x is limited to 2^31-1; frames are chunked far below that by the caller
     const size_t max_chunk = 1u << 30;
@@ -270,12 +268,10 @@ hipError_t launch_render(const sgx_ctx *c, const float *d_mags, size_t n_columns
     p.segments = c->pal.segments ? 1u : 0u;
     p.nan_rgba = make_uchar4(c->pal.nan_rgb[0], c->pal.nan_rgb[1], c->pal.nan_rgb[2], 255);
     const size_t lds = (size_t)(c->M + 1) * sizeof(float2) + (size_t)(c->pal.n + 255) * sizeof(float);
-    static thread_local size_t attr_set_for = 0;
-    if (lds > 64 * 1024 && attr_set_for < lds) {
+    if (lds > 64 * 1024) {  // per launch: the attribute is per device, and a process may hold contexts on several
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(render_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        attr_set_for = lds;
     }
     const size_t max_chunk = 1u << 30;
     size_t done = 0;
@@ -366,12 +362,10 @@ hipError_t launch_magnitude_in(const sgx_ctx *c, const float *d_mags, size_t n_c
     p.n_ranges = n_ranges;
     p.interp = c->cfg.interp;
     const size_t lds = (size_t)(c->M + 1) * sizeof(float2);
-    static thread_local size_t attr_set_for = 0;
-    if (lds > 64 * 1024 && attr_set_for < lds) {
+    if (lds > 64 * 1024) {  // per launch: the attribute is per device, and a process may hold contexts on several
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(magnitude_in_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        attr_set_for = lds;
     }
     const size_t max_chunk = 1u << 30;
     for (size_t done = 0; done < n_columns; done += max_chunk) {

@@ -276,77 +276,12 @@ __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
                 }
             }
             lds_barrier();
-            const int last = kM - 1;
             for (int c_i = 0; c_i < (MONO ? 2 : 1); ++c_i) {
                 if (MONO && !(c_i ? have_second : have_first)) continue;
                 const float *mc = MONO ? (c_i ? m1 : m0) : m0;
                 uchar4 *dst = reinterpret_cast<uchar4 *>(p.rgba) + ((size_t)(c_i ? f1 : f0) * p.pairs + p.pair) * (size_t)p.R;
-                for (uint32_t py = tid; py < p.R; py += 256) {
-                    const uint32_t re = p.rows[py];
-                    const uint32_t first = re & 0xffffu, cnt = re >> 16;
-                    float sl = 0.0f, sr = 0.0f;  // Complex::sum starts at zero
-                    for (uint32_t i = 0; i < cnt; ++i) {
-                        const PackedSample se = p.samples[first + i];
-                        float vl, vr = 0.0f;
-                        if (p.interp == SGX_INTERP_COSINE) {
-                            // interpolated_frequency_sample.rs:79-86
-                            const int lo = se.i0, hi = lo + 1 < last ? lo + 1 : last;
-                            const float w1 = 1.0f - se.w;
-                            if (MONO) {
-                                vl = mc[lo] * w1 + mc[hi] * se.w;
-                            } else {
-                                const float2 a = reinterpret_cast<const float2 *>(mc)[lo], b = reinterpret_cast<const float2 *>(mc)[hi];
-                                vl = a.x * w1 + b.x * se.w;
-                                vr = a.y * w1 + b.y * se.w;
-                            }
-                        } else {
-                            // :89-105
-                            const int x1 = se.i0;
-                            const int x0 = x1 > 0 ? x1 - 1 : 0;
-                            const int x2 = x1 + 1 < last ? x1 + 1 : last;
-                            const int x3 = x1 + 2 < last ? x1 + 2 : last;
-                            const float mu = se.w, mu2 = mu * mu, mu3 = mu * mu2;
-                            if (MONO) {
-                                const float y0 = mc[x0], y1 = mc[x1], y2 = mc[x2], y3 = mc[x3];
-                                const float a0 = ((y3 - y2) - y0) + y1;
-                                const float a1 = (y0 - y1) - a0;
-                                const float a2 = y2 - y0;
-                                vl = ((a0 * mu3) + (a1 * mu2)) + ((a2 * mu) + y1);
-                            } else {
-                                const float2 *m2 = reinterpret_cast<const float2 *>(mc);
-                                const float2 y0 = m2[x0], y1 = m2[x1], y2 = m2[x2], y3 = m2[x3];
-                                {
-                                    const float a0 = ((y3.x - y2.x) - y0.x) + y1.x;
-                                    const float a1 = (y0.x - y1.x) - a0;
-                                    const float a2 = y2.x - y0.x;
-                                    vl = ((a0 * mu3) + (a1 * mu2)) + ((a2 * mu) + y1.x);
-                                }
-                                {
-                                    const float a0 = ((y3.y - y2.y) - y0.y) + y1.y;
-                                    const float a1 = (y0.y - y1.y) - a0;
-                                    const float a2 = y2.y - y0.y;
-                                    vr = ((a0 * mu3) + (a1 * mu2)) + ((a2 * mu) + y1.y);
-                                }
-                            }
-                        }
-                        sl = sl + vl;
-                        if (!MONO) sr = sr + vr;
-                    }
-                    float l = sl, r = sr;
-                    if (cnt > 1) {  // x / 1.0 == x: only rows that average several samples divide (:72)
-                        const float nf = (float)cnt;
-                        l = sl / nf;
-                        if (!MONO) r = sr / nf;
-                    }
-                    if (MONO) r = l;  // mono -> (s, s): both channels carry the same magnitude
-                    // colorscheme.rs:59-61 as a threshold count; the log2 only seeds the search
-                    const float power = (l * l) + (r * r);
-                    int idx = (int)floorf(fmaf(__builtin_amdgcn_logf(power + 1e-7f), p.guess_a, p.guess_b));
-                    idx = idx < 0 ? 0 : (idx > 255 ? 255 : idx);
-                    while (idx < 255 && power >= thr[idx]) ++idx;
-                    while (idx > 0 && !(power >= thr[idx - 1])) --idx;
-                    dst[p.R - 1 - py] = lut[idx];  // simple_spectrogram.rs:150; alpha = 1.0 -> 255
-                }
+                if (p.interp == SGX_INTERP_COSINE) render_column<MONO, true>(p, mc, dst, thr, lut, tid);
+                else render_column<MONO, false>(p, mc, dst, thr, lut, tid);
             }
         }
     }
@@ -379,10 +314,16 @@ hipError_t wg4096_init(sgx_ctx *c, void **out)
     std::vector<uint32_t> rows(c->tab.rows.size());
     std::vector<PackedSample> samples(c->tab.samples.size());
     bool fusable = c->tab.samples.size() < 65536;
+    const int32_t last = (int32_t)c->M - 1;
     for (size_t i = 0; i < rows.size(); ++i) {
         const auto &r = c->tab.rows[i];
-        if (r.count >= 65536) fusable = false;
-        rows[i] = (r.first & 0xffffu) | (r.count << 16);
+        if (r.count >= 32768) fusable = false;
+        bool interior = true;  // no tap of this row is clamped at either end of the spectrum
+        for (uint32_t k = 0; k < r.count; ++k) {
+            const int32_t x1 = c->tab.samples[r.first + k].i0;
+            if (c->cfg.interp == SGX_INTERP_COSINE ? (x1 + 1 > last) : (x1 < 1 || x1 + 2 > last)) interior = false;
+        }
+        rows[i] = (r.first & 0xffffu) | ((r.count & 0x7fffu) << 16) | (interior ? 0x80000000u : 0u);
     }
     for (size_t i = 0; i < samples.size(); ++i) {
         const auto &se = c->tab.samples[i];

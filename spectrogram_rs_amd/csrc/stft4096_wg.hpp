@@ -85,6 +85,100 @@ __device__ __forceinline__ void store_row(char *rowm8, int col, const float (&va
             *reinterpret_cast<float2 *>(rowm8 + 2048 * q3 + lane_off) = DUP ? make_float2(va[q3], va[q3]) : make_float2(va[q3], vb[q3]);
 }
 
+// ---- fused pixel column: magnitude_in -> color_for -> put_pixel (simple_spectrogram.rs:141-161) ---------------
+// `mc` is one column of magnitudes in LDS: MONO a scalar per bin (l = r), else (l, r) pairs.  Row word:
+// first sample | count << 16 | interior << 31, where `interior` says that no tap of the row touches the
+// ends of the spectrum, so the taps are the contiguous bins x1-1 .. x1+2 (cubic) / lo, lo+1 (cosine) and
+// the saturating index arithmetic of interpolated_frequency_sample.rs:89-105 can be skipped.
+template <bool MONO, bool COSINE, bool INTERIOR>
+__device__ __forceinline__ void interp_sample(const float *mc, const PackedSample se, int last, float &vl, float &vr)
+{
+    vr = 0.0f;
+    if (COSINE) {
+        // :79-86  data[low] * (1 - o') + data[high] * o'
+        const int lo = se.i0, hi = INTERIOR ? lo + 1 : (lo + 1 < last ? lo + 1 : last);
+        const float w1 = 1.0f - se.w;
+        if (MONO) {
+            vl = mc[lo] * w1 + mc[hi] * se.w;
+        } else {
+            const float2 a = reinterpret_cast<const float2 *>(mc)[lo], b = reinterpret_cast<const float2 *>(mc)[hi];
+            vl = a.x * w1 + b.x * se.w;
+            vr = a.y * w1 + b.y * se.w;
+        }
+    } else {
+        // :89-105
+        const int x1 = se.i0;
+        const int x0 = INTERIOR ? x1 - 1 : (x1 > 0 ? x1 - 1 : 0);
+        const int x2 = INTERIOR ? x1 + 1 : (x1 + 1 < last ? x1 + 1 : last);
+        const int x3 = INTERIOR ? x1 + 2 : (x1 + 2 < last ? x1 + 2 : last);
+        const float mu = se.w, mu2 = mu * mu, mu3 = mu * mu2;
+        if (MONO) {
+            const float y0 = mc[x0], y1 = mc[x1], y2 = mc[x2], y3 = mc[x3];
+            const float a0 = ((y3 - y2) - y0) + y1;
+            const float a1 = (y0 - y1) - a0;
+            const float a2 = y2 - y0;
+            vl = ((a0 * mu3) + (a1 * mu2)) + ((a2 * mu) + y1);
+        } else {
+            const float2 *m2 = reinterpret_cast<const float2 *>(mc);
+            const float2 y0 = m2[x0], y1 = m2[x1], y2 = m2[x2], y3 = m2[x3];
+            {
+                const float a0 = ((y3.x - y2.x) - y0.x) + y1.x;
+                const float a1 = (y0.x - y1.x) - a0;
+                const float a2 = y2.x - y0.x;
+                vl = ((a0 * mu3) + (a1 * mu2)) + ((a2 * mu) + y1.x);
+            }
+            {
+                const float a0 = ((y3.y - y2.y) - y0.y) + y1.y;
+                const float a1 = (y0.y - y1.y) - a0;
+                const float a2 = y2.y - y0.y;
+                vr = ((a0 * mu3) + (a1 * mu2)) + ((a2 * mu) + y1.y);
+            }
+        }
+    }
+}
+
+// (Tried: dealing rows to the four waves round-robin to even out the sample counts, which grow with the
+// row -- the strided pixel stores cost more than the balance gains: 145 -> 133 M frames/s.)
+template <bool MONO, bool COSINE>
+__device__ __forceinline__ void render_column(const Params &p, const float *mc, uchar4 *dst, const float *thr, const uchar4 *lut, int tid)
+{
+    const int last = kM - 1;
+    for (uint32_t py = tid; py < p.R; py += 256) {
+        const uint32_t re = p.rows[py];
+        const uint32_t first = re & 0xffffu, cnt = (re >> 16) & 0x7fffu;
+        float sl = 0.0f, sr = 0.0f;  // Complex::sum starts at zero
+        if (re >> 31) {
+            for (uint32_t i = 0; i < cnt; ++i) {
+                float vl, vr;
+                interp_sample<MONO, COSINE, true>(mc, p.samples[first + i], last, vl, vr);
+                sl = sl + vl;
+                if (!MONO) sr = sr + vr;
+            }
+        } else {
+            for (uint32_t i = 0; i < cnt; ++i) {
+                float vl, vr;
+                interp_sample<MONO, COSINE, false>(mc, p.samples[first + i], last, vl, vr);
+                sl = sl + vl;
+                if (!MONO) sr = sr + vr;
+            }
+        }
+        float l = sl, r = sr;
+        if (cnt > 1) {  // x / 1.0 == x: only rows that average several samples divide (:72)
+            const float nf = (float)cnt;
+            l = sl / nf;
+            if (!MONO) r = sr / nf;
+        }
+        if (MONO) r = l;  // mono -> (s, s): both channels carry the same magnitude
+        // colorscheme.rs:59-61 as a threshold count; the log2 only seeds the search
+        const float power = (l * l) + (r * r);
+        int idx = (int)floorf(fmaf(__builtin_amdgcn_logf(power + 1e-7f), p.guess_a, p.guess_b));
+        idx = idx < 0 ? 0 : (idx > 255 ? 255 : idx);
+        while (idx < 255 && power >= thr[idx]) ++idx;
+        while (idx > 0 && !(power >= thr[idx - 1])) --idx;
+        dst[p.R - 1 - py] = lut[idx];  // simple_spectrogram.rs:150; alpha = 1.0 -> 255
+    }
+}
+
 // the same row as IEEE half pairs (round to nearest even): bin k at byte 4 k of rowm4
 template <bool DUP>
 __device__ __forceinline__ void store_row_f16(char *rowm4, int col, const float (&va)[8], const float (&vb)[8])

@@ -86,7 +86,7 @@ class FastFourierTransform(AudioTransform):
         self._device = device
         self._force_generic = force_generic
         self._engines = {}
-        self._engine(0)  # "planning" happens at construction, as FFTW's does (fft.rs:20-24)
+        self._per_frame = self._engine(1)  # "planning" happens at construction, as FFTW's does (fft.rs:20-24)
 
     # engines are cached per hop: the wrapper's `stride` is a public, mutable field
     def _engine(self, hop: int) -> SpectrogramEngine:
@@ -120,7 +120,7 @@ class FastFourierTransform(AudioTransform):
             lr = np.asarray(taken, np.float32).reshape(-1, 2)
         if lr.shape[0] < W:
             return None  # fft.rs:72
-        return self._engine(next(iter(self._engines))).process_one(lr)
+        return self._per_frame.process_one(lr)
 
     def process_stream(self, lr: np.ndarray, hop: int) -> np.ndarray:
         """All complete frames of an (l, r) buffer in one launch: [frames][M][2]."""
