@@ -27,7 +27,11 @@ extern "C" {
                               max_frames: usize, d_mags_f16: *mut c_void, n_out: *mut usize) -> c_int;   // F16F16 ring rows
     pub fn sgx_render_batch(ctx: *mut SgxCtx, d_pcm: *const f32, n_samples: usize, first_frame: usize,
                             max_frames: usize, d_rgba: *mut u8, n_out: *mut usize) -> c_int;
+    pub fn sgx_magnitude_in(ctx: *mut SgxCtx, d_mags: *const f32, n_columns: usize, h_ranges: *const f32,
+                            n_ranges: u32, d_out: *mut f32) -> c_int;              // FrequencySample::magnitude_in
     pub fn sgx_set_gradient(ctx: *mut SgxCtx, h_rgb: *const u8, n: u32, stereo: c_int) -> c_int;
+    pub fn sgx_set_gradient_fn(ctx: *mut SgxCtx, eval: extern "C" fn(f64, *mut u8, *mut c_void), user: *mut c_void,
+                               stereo: c_int) -> c_int;
     pub fn sgx_lookup_table(ctx: *mut SgxCtx, resolution: u32, h_out: *mut f32) -> c_int;
     pub fn sgx_sync(ctx: *mut SgxCtx) -> c_int;
 }

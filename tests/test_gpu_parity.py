@@ -229,6 +229,53 @@ def test_full_size_properties(torch_cuda, mags_err):
     assert (eng.checksum(lo) + eng.checksum(hi, base_word=words_lo)) % (1 << 64) == a
 
 
+def test_stream_longer_than_2_to_32_samples(torch_cuda, mags_err):
+    # config 5 streams hold 25.6 G samples: every index on the path is 64-bit.  A 17 GB mono stream whose last
+    # frames start beyond sample 2^32 (where the noise generator also mixes in the high word)
+    torch = torch_cuda
+    eng = engine(window_samples=W, hop_samples=H, channels=1, gradient="viridis")
+    n = (1 << 32) + 70_000
+    if torch.cuda.mem_get_info()[0] < 30 * (1 << 30):
+        pytest.skip("needs 30 GB of free HBM")
+    pcm = eng.white_noise(n)
+    total = eng.num_frames(n)
+    assert total == (n - W) // H + 1
+    first = total - 6
+    assert first * H > (1 << 32)
+    got = eng.stft_batch(pcm, first_frame=first).cpu().numpy()
+    rg = eng.render_batch(pcm, first_frame=first).cpu().numpy()
+    del pcm
+    host = oracle.white_noise(5 * H + W, first=first * H)
+    assert not np.array_equal(host[:64], oracle.white_noise(64, first=first * H - (1 << 32)))  # not a 32-bit wrap
+    ref = oracle.stream_process(host, 1, W, H)
+    assert got.shape == ref.shape == (6, 1, M, 2) and mags_err(got, ref) <= 2.0
+    own = oracle.render_columns(got[:, 0], SR, np.load(os.path.join(os.path.dirname(__file__), "golden", "gradients.npz"))["viridis"])
+    assert np.array_equal(rg[:, 0], own)
+
+
+def test_pixel_path_properties_at_scale(torch_cuda):
+    # 131 072 frames through the fused kernel: equal to the two-kernel path on sampled columns, deterministic,
+    # and independent of how the frame range is split (what rank sharding relies on)
+    torch = torch_cuda
+    F = 131_072
+    fused = engine(window_samples=W, hop_samples=H, channels=1, interp=1, gradient="viridis")
+    split = engine(window_samples=W, hop_samples=H, channels=1, interp=1, gradient="viridis", fused_render=False)
+    pcm = fused.white_noise((F - 1) * H + W) * 0.1
+    a = fused.render_batch(pcm)
+    assert a.shape == (F, 1, R, 4) and int(a[..., 3].min()) == 255
+    ck = fused.checksum(a)
+    assert fused.checksum(fused.render_batch(pcm)) == ck
+    for first, cnt in ((0, 3000), (50_001, 777), (F - 5, 5)):
+        assert torch.equal(split.render_batch(pcm, first_frame=first, max_frames=cnt), a[first:first + cnt])
+    parts = [fused.render_batch(pcm, first_frame=f0, max_frames=c) for f0, c in ((0, 40_000), (40_000, 50_001), (90_001, F - 90_001))]
+    words = 0
+    total = 0
+    for t in parts:
+        total = (total + fused.checksum(t, base_word=words)) % (1 << 64)
+        words += t.numel() // 4
+    assert total == ck
+
+
 # ---- the pixel path --------------------------------------------------------------------------------
 
 @pytest.mark.parametrize("interp", [0, 1])
