@@ -13,7 +13,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "liboracle.so")
+_SO = os.environ.get("ORACLE_SO") or os.path.join(_HERE, "liboracle.so")  # ORACLE_SO: sanitizer build (oracle/Makefile)
 
 F32, F64 = 0, 1
 INTERP_CUBIC, INTERP_COSINE = 0, 1
