@@ -185,6 +185,50 @@ SGX_API int sgx_render_mags(sgx_ctx *ctx, const float *d_mags, size_t n_columns,
 SGX_API int sgx_magnitude_in(sgx_ctx *ctx, const float *d_mags, size_t n_columns, const float *h_ranges,
                              uint32_t n_ranges, float *d_out);
 
+/* SpectrumAnalyzer::push_frequencies (spectrum_analyzer.rs:46-68) for ONE column of magnitudes
+ * d_column [M][2] on the device: the n_bars (the widget has 128) adjacent bands of
+ * log_space(32, max(sample_rate / 2, 22050), n_bars + 1, 10) (:20-36,52-58; f32 logf / powf on the host),
+ * magnitude_in of each band on the device, then on the host level = (10 log10f(hypotf(l, r) + 1e-7) + 70) / 60
+ * as f64 and h_levels[i] = max(level, h_levels[i] * 0.99) (:61-66: the bars decay by 1 % per pushed
+ * column; a fresh widget starts every bar at 0.3, :92).  h_levels [n_bars] double, in/out.  Synchronous. */
+SGX_API int sgx_spectrum_levels(sgx_ctx *ctx, const float *d_column, uint32_t n_bars, double *h_levels);
+
+/* ---- live capture: the ring between the audio callback and the GUI tick -------------------- */
+
+/* The reference's producer is the cpal input callback pushing (l, r) pairs into a 4096-entry
+ * ringbuf::HeapRb (audio_input_list_model.rs:30,63-72); its consumer is the GTK tick running the
+ * hop loop over that ring (audio_transform.rs:34-42 from gpu_spectrogram.rs:255-262 /
+ * simple_spectrogram.rs:136-139).  sgx_live keeps the CONSUMED side of that ring on the device:
+ * a push lands in a pinned host ring; a tick sends only the samples that arrived since the last
+ * tick (one async copy, two when the ring wraps), runs every complete frame through one launch
+ * of the context's transform (context channels must be 2: the ring holds (l, r) pairs), returns
+ * the results to the host and keeps the W - H overlap resident.  One producer thread and one
+ * consumer thread may run concurrently (lock-free single-producer / single-consumer, as HeapRb). */
+typedef struct sgx_live sgx_live;
+
+#define SGX_LIVE_MAGS 0     /* float [frames][M][2]: what AudioStreamTransform::process yields        */
+#define SGX_LIVE_MAGS_F16 1 /* half  [frames][M][2]: rows of the F16F16 ring (gpu_spectrogram.rs:268) */
+#define SGX_LIVE_RGBA 2     /* uint8 [frames][R][4]: columns of SimpleSpectrogram::snapshot           */
+
+#define SGX_LIVE_REFERENCE_SKIP 1u /* also skip H samples on the terminating short read, exactly as
+                                      audio_transform.rs:37-41 does (it drops up to H samples per tick);
+                                      default: frames are t*H exact */
+
+/* capacity_pairs: ring size in (l, r) pairs (the reference: 4096); must hold at least one window */
+SGX_API int sgx_live_create(sgx_ctx *ctx, size_t capacity_pairs, uint32_t flags, sgx_live **out);
+SGX_API void sgx_live_destroy(sgx_live *live);
+/* The cpal callback (audio_input_list_model.rs:63-75): h_samples holds n_values floats, interleaved by
+ * `channels`.  1 channel -> (s, s) pairs, 2 -> (l, r) pairs, anything else -> SGX_ERR_UNSUPPORTED (the
+ * reference prints "N-channel input not supported!").  Pairs that do not fit are dropped (push_iter).
+ * Returns the number of pairs accepted, or a negative sgx_status.  Producer thread. */
+SGX_API long long sgx_live_push(sgx_live *live, const float *h_samples, size_t n_values, uint32_t channels);
+/* HeapRb::occupied_len: pairs pushed and not yet skipped */
+SGX_API size_t sgx_live_occupied(const sgx_live *live);
+/* One GUI tick (audio_transform.rs:34-42): every complete frame of the ring, at most max_frames, in the
+ * format `what`, into the HOST buffer h_out; the ring advances by H per frame.  *n_frames may be 0 (not
+ * an error).  Synchronous: returns when h_out is filled.  Consumer thread. */
+SGX_API int sgx_live_tick(sgx_live *live, int what, void *h_out, size_t max_frames, size_t *n_frames);
+
 /* ---- ColorScheme ---------------------------------------------------------------------------- */
 
 /* ColorScheme::new_mono(gradient, name) / new_stereo(gradient, background, name)

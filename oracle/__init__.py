@@ -79,6 +79,10 @@ def lib():
         L.orc_lookup_table.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int, fp]
         L.orc_set_gradient_fn.restype = None
         L.orc_set_gradient_fn.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_log_space.restype = C.c_float
+        L.orc_log_space.argtypes = [C.c_float, C.c_float, C.c_size_t, C.c_float, C.c_size_t]
+        L.orc_spectrum_levels.restype = None
+        L.orc_spectrum_levels.argtypes = [fp, C.c_size_t, C.c_uint32, C.c_int, C.c_size_t, dp]
         L.orc_lowbias32.restype = C.c_uint32
         L.orc_lowbias32.argtypes = [C.c_uint32]
         L.orc_white_noise.restype = None
@@ -210,6 +214,19 @@ def magnitude_in(data: np.ndarray, sample_rate: int, f0: float, f1: float, inter
 
 def num_samples_in(M: int, sample_rate: int, f0: float, f1: float) -> int:
     return int(lib().orc_num_samples_in(M, sample_rate, f0, f1))
+
+
+def log_space(start: float, end: float, n: int, base: float, i: int) -> float:
+    return float(lib().orc_log_space(start, end, n, base, i))
+
+
+def spectrum_levels(mags: np.ndarray, sample_rate: int, levels: np.ndarray, interp: int = INTERP_CUBIC) -> np.ndarray:
+    """SpectrumAnalyzer::push_frequencies: `levels` (float64) is updated in place and returned."""
+    data = _f32c(mags).reshape(-1, 2)
+    assert levels.dtype == np.float64 and levels.flags.c_contiguous
+    lib().orc_spectrum_levels(_fp(data), data.shape[0], sample_rate, interp, levels.size,
+                              levels.ctypes.data_as(C.POINTER(C.c_double)))
+    return levels
 
 
 # ---- LogCoordf64 ---------------------------------------------------------------------------

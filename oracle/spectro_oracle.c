@@ -577,6 +577,42 @@ void orc_lookup_table(const uint8_t *gradient, int n_lut, int lut_mode, int ster
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* SpectrumAnalyzer  (widgets/spectrum_analyzer.rs)                                           */
+/* ------------------------------------------------------------------------------------------ */
+
+float orc_log_space(float start, float end, size_t n, float base, size_t i)
+{
+    /* :20-36 -- f32::log(base) is ln(x) / ln(base); the iterator never stops (the `if i > n` is a no-op) */
+    volatile float ls = logf(start) / logf(base);
+    volatile float le = logf(end) / logf(base);
+    volatile float span = le - ls;
+    volatile float step = span / (float)n;
+    volatile float off = step * (float)i;
+    volatile float lin = ls + off;
+    return powf(base, lin);
+}
+
+void orc_spectrum_levels(const float *mags, size_t M, uint32_t sample_rate, int interp, size_t n_bars, double *levels)
+{
+    /* push_frequencies, :46-68 */
+    const float min = -70.0f, max = -10.0f;
+    volatile float half = (float)sample_rate / 2.0f;       /* frequencies().end, interpolated_frequency_sample.rs:56-58 */
+    const float end = half > 22050.0f ? half : 22050.0f;   /* .max(22050.0) */
+    for (size_t i = 0; i < n_bars; ++i) {
+        const float f0 = orc_log_space(32.0f, end, n_bars + 1, 10.0f, i);
+        const float f1 = orc_log_space(32.0f, end, n_bars + 1, 10.0f, i + 1);
+        float lr[2];
+        orc_magnitude_in(mags, M, sample_rate, f0, f1, interp, lr);
+        volatile float magnitude = hypotf(lr[0], lr[1]);    /* c32::new(l, r).norm() */
+        volatile float biased = magnitude + 1e-7f;
+        volatile float db = 10.0f * log10f(biased);
+        volatile float num = db - min;
+        volatile float t = num / (max - min);
+        levels[i] = fmax((double)t, levels[i] * 0.99);      /* f64::max ignores a NaN operand, as fmax */
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* synthetic inputs -- not reference code                                         */
 /* ------------------------------------------------------------------------------------------ */
 

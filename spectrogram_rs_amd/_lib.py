@@ -25,6 +25,8 @@ FLAG_WAVE_KERNEL = 2
 FLAG_NO_FUSED_RENDER = 4
 FLAG_PACKED_KERNEL = 8
 FLAG_INDEPENDENT_FRAMES = 16
+LIVE_MAGS, LIVE_MAGS_F16, LIVE_RGBA = 0, 1, 2
+LIVE_REFERENCE_SKIP = 1
 
 
 class SgxError(RuntimeError):
@@ -92,6 +94,12 @@ SIGNATURES = [
     ("sgx_render_batch", C.c_int, [_ctx, _vp, _sz, _sz, _sz, _vp, C.POINTER(_sz)]),
     ("sgx_render_mags", C.c_int, [_ctx, _vp, _sz, _vp]),
     ("sgx_magnitude_in", C.c_int, [_ctx, _vp, _sz, _vp, C.c_uint32, _vp]),
+    ("sgx_spectrum_levels", C.c_int, [_ctx, _vp, C.c_uint32, _vp]),
+    ("sgx_live_create", C.c_int, [_ctx, _sz, C.c_uint32, C.POINTER(_vp)]),
+    ("sgx_live_destroy", None, [_vp]),
+    ("sgx_live_push", C.c_longlong, [_vp, _vp, _sz, C.c_uint32]),
+    ("sgx_live_occupied", _sz, [_vp]),
+    ("sgx_live_tick", C.c_int, [_vp, C.c_int, _vp, _sz, C.POINTER(_sz)]),
     ("sgx_set_gradient", C.c_int, [_ctx, _vp, C.c_uint32, C.c_int]),
     ("sgx_set_gradient_fn", C.c_int, [_ctx, _vp, _vp, C.c_int]),
     ("sgx_set_builtin_gradient", C.c_int, [_ctx, C.c_char_p]),

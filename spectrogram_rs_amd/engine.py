@@ -196,6 +196,20 @@ class SpectrogramEngine:
                                                    ranges.shape[0], C.c_void_p(out.data_ptr())))
         return out
 
+    def spectrum_levels(self, column, levels: np.ndarray) -> np.ndarray:
+        """SpectrumAnalyzer::push_frequencies (spectrum_analyzer.rs:46-68) for one column [M][2] on the device;
+        `levels` (float64, one per bar) is updated in place and returned."""
+        assert levels.dtype == np.float64 and levels.flags.c_contiguous
+        assert column.numel() == self.M * 2
+        self._check(self._lib.sgx_spectrum_levels(self._ctx, self._dev_f32(column), levels.size,
+                                                  levels.ctypes.data_as(C.c_void_p)))
+        return levels
+
+    # ---- live capture ----------------------------------------------------------------------
+    def live(self, capacity: int = 4096, reference_skip: bool = False) -> "LiveRing":
+        """The ring between the audio callback and the GUI tick, consumed side resident on the device."""
+        return LiveRing(self, capacity, reference_skip)
+
     # ---- colour scheme ---------------------------------------------------------------------
     def set_gradient(self, rgb: np.ndarray, stereo: bool = False):
         rgb = np.ascontiguousarray(rgb, np.uint8).reshape(-1, 3)
@@ -248,6 +262,61 @@ class SpectrogramEngine:
         v = C.c_uint64(0)
         self._check(self._lib.sgx_checksum(self._ctx, C.c_void_p(t.data_ptr()), nbytes, base_word, C.byref(v)))
         return int(v.value)
+
+
+class LiveRing:
+    """sgx_live: ringbuf::HeapRb<(f32, f32)> (audio_input_list_model.rs:30) whose consumer is the hop loop of
+    AudioStreamTransform::process (audio_transform.rs:34-42), run on the GPU once per tick."""
+
+    _FORMATS = {"mags": (_lib.LIVE_MAGS, np.float32), "mags_f16": (_lib.LIVE_MAGS_F16, np.float16),
+                "rgba": (_lib.LIVE_RGBA, np.uint8)}
+
+    def __init__(self, engine: SpectrogramEngine, capacity: int = 4096, reference_skip: bool = False):
+        self.engine = engine
+        self.capacity = int(capacity)
+        self._lib = engine._lib
+        self._h = C.c_void_p()
+        engine._check(self._lib.sgx_live_create(engine._ctx, self.capacity,
+                                                _lib.LIVE_REFERENCE_SKIP if reference_skip else 0, C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.sgx_live_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def push(self, data, channels: int) -> int:
+        """The input callback (audio_input_list_model.rs:63-75): interleaved float32 `data`; returns the pairs
+        accepted (overflow is dropped).  Raises SgxError(SGX_ERR_UNSUPPORTED) for more than two channels."""
+        data = np.ascontiguousarray(data, np.float32).reshape(-1)
+        n = int(self._lib.sgx_live_push(self._h, data.ctypes.data_as(C.c_void_p), data.size, channels))
+        if n < 0:
+            raise SgxError(n, f"{channels}-channel input not supported!" if n == _lib.SGX_ERR_UNSUPPORTED else "sgx_live_push")
+        return n
+
+    def occupied_len(self) -> int:
+        return int(self._lib.sgx_live_occupied(self._h))
+
+    def __len__(self) -> int:
+        return self.occupied_len()
+
+    def tick(self, what: str = "mags", max_frames: Optional[int] = None) -> np.ndarray:
+        """One GUI tick: every complete frame of the ring as a host array
+        ("mags": [frames][M][2] f32, "mags_f16": the same in half, "rgba": [frames][R][4] u8)."""
+        code, dtype = self._FORMATS[what]
+        e = self.engine
+        if max_frames is None:
+            max_frames = e.num_frames(self.capacity)
+        shape = (max_frames, e.R, 4) if what == "rgba" else (max_frames, e.M, 2)
+        out = np.empty(shape, dtype)
+        got = C.c_size_t(0)
+        e._check(self._lib.sgx_live_tick(self._h, code, out.ctypes.data_as(C.c_void_p), max_frames, C.byref(got)))
+        return out[:got.value]
 
 
 def builtin_gradient(name: str) -> np.ndarray:

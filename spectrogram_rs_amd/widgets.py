@@ -5,6 +5,8 @@ pixel columns (simple_spectrogram.rs:34-35,89-94,164).  `snapshot()` here does w
 of the reference's `snapshot` does (:120-165): drain the ring through the transform, turn every
 frame into one pixel column and advance `offset`.  Drawing the two sub-pixbufs (:181-209) is GTK
 and out of scope; `scrolled()` returns the same image they would compose.
+
+SpectrumAnalyzer mirrors src/widgets/spectrum_analyzer.rs: 128 level bars over log-spaced bands.
 """
 from __future__ import annotations
 
@@ -21,7 +23,10 @@ TEXTURE_HEIGHT = 1024  # simple_spectrogram.rs:35
 
 
 class SimpleSpectrogram:
-    def __init__(self, sample_stream: RingBuffer, *, sample_rate: int = 48000, period: float = 0.05,
+    """`sample_stream` is the host RingBuffer mirror, or None: the widget then owns a device-resident LiveRing
+    (engine.live(), filled through `push`), so that a tick moves only the new samples to the GPU."""
+
+    def __init__(self, sample_stream: Optional[RingBuffer], *, sample_rate: int = 48000, period: float = 0.05,
                  window_samples: int = 0, device: Optional[int] = None, interp: int = 0,
                  width: int = TEXTURE_WIDTH, height: int = TEXTURE_HEIGHT):
         import torch
@@ -46,6 +51,13 @@ class SimpleSpectrogram:
         self.engine = SpectrogramEngine(float(sr), hop_samples=max(hop, 1), channels=2, rows=self.height,
                                         interp=self._interp, device=self._device, **kw)
         self.palette.apply(self.engine)
+        # the reference's ring outlives the transform; the device-resident one is rebuilt with it (samples in
+        # flight at a sample-rate change are dropped)
+        self.live = self.engine.live(max(4096, 2 * self.engine.W), reference_skip=True) if self.input_stream is None else None
+
+    def push(self, data, channels: int) -> int:
+        """the input callback (audio_input_list_model.rs:63-75), LiveRing mode only"""
+        return self.live.push(data, channels)
 
     def set_palette(self, palette: ColorScheme) -> None:
         self.palette = palette
@@ -56,6 +68,15 @@ class SimpleSpectrogram:
         import torch
 
         eng = self.engine
+        if self.live is not None:
+            cols = torch.from_numpy(self.live.tick("rgba")).to(eng.device)  # [frames][R][4]
+            frames = cols.shape[0]
+            if frames:
+                px = (self.offset + torch.arange(frames, device=eng.device)) % self.width
+                keep = slice(max(frames - self.width, 0), frames)
+                self.buffer[:, px[keep], :] = cols[keep].permute(1, 0, 2)
+                self.offset = (self.offset + frames) % self.width
+            return frames
         n = len(self.input_stream)
         frames = eng.num_frames(n)
         if frames:
@@ -75,3 +96,15 @@ class SimpleSpectrogram:
         import torch
 
         return torch.cat([self.buffer[:, self.offset:], self.buffer[:, :self.offset]], dim=1)
+
+
+class SpectrumAnalyzer:
+    """spectrum_analyzer.rs:38-68: `level_bars` LevelBar values (a fresh bar holds 0.3, :92); push_frequencies
+    takes one frame of magnitudes ([M][2] on the engine's device) and raises / decays every bar."""
+
+    def __init__(self, engine: SpectrogramEngine, n_bars: int = 128):
+        self.engine = engine
+        self.level_bars = np.full(n_bars, 0.3, np.float64)
+
+    def push_frequencies(self, frequency_sample) -> np.ndarray:
+        return self.engine.spectrum_levels(frequency_sample, self.level_bars)

@@ -267,3 +267,24 @@ def test_render_column_layout_and_golden(gold, gradients):
     col = oracle.render_column(mags, SR, v)
     lit = np.nonzero((col[:, :3] != v[0]).any(axis=1))[0]
     assert len(lit) and lit.min() > R // 2
+
+
+def test_spectrum_analyzer_bands_and_levels():
+    # log_space(32, end, 129, 10) (spectrum_analyzer.rs:20-36): geometric, first edge 32 Hz, edge 129 = end
+    edges = np.array([oracle.log_space(32.0, 24000.0, 129, 10.0, i) for i in range(130)])
+    assert edges[0] == pytest.approx(32.0, rel=1e-6) and edges[129] == pytest.approx(24000.0, rel=1e-5)
+    ratio = edges[1:] / edges[:-1]
+    assert np.allclose(ratio, (24000.0 / 32.0) ** (1 / 129), rtol=1e-5)
+    # a flat spectrum (l = r = c): magnitude_in of every band is c, so every bar shows
+    # (10 log10(sqrt(2) c + 1e-7) + 70) / 60 (:60-62); bars start at 0.3 (:92)
+    c = 0.01
+    mags = np.full((M, 2), c, np.float32)
+    levels = np.full(128, 0.3)
+    oracle.spectrum_levels(mags, SR, levels)
+    want = (10 * math.log10(math.sqrt(2) * c + 1e-7) + 70) / 60
+    assert np.allclose(levels, want, atol=2e-6) and want > 0.3
+    # a quieter frame: the bars decay by 1 % per push instead of dropping (:64)
+    oracle.spectrum_levels(mags * np.float32(1e-3), SR, levels)
+    assert np.allclose(levels, want * 0.99, atol=2e-6)
+    # below 44.1 kHz the last edge stays at 22050 Hz (.max(22050.0), :54)
+    assert oracle.log_space(32.0, max(8000 / 2, 22050.0), 129, 10.0, 129) == pytest.approx(22050.0, rel=1e-5)

@@ -48,7 +48,7 @@ def main():
             print(f"render_mags only: median {med:.3f} ms -> {F / med / 1e3:.1f} M columns/s", flush=True)
 
 
-if __name__ == "__main__" and "--extra" not in sys.argv:
+if __name__ == "__main__" and "--extra" not in sys.argv and "--live" not in sys.argv:
     main()
 
 
@@ -92,3 +92,32 @@ def f16(frames=1_000_000):
 
 if __name__ == "__main__" and "--extra" in sys.argv:
     f16()
+
+
+def live_ticks(ticks=600):
+    """the reference's real-time operating point: 60 GUI ticks/s, 800 new stereo samples per tick, 0.05 s window,
+    hop 93 -- host buffer in, host buffer out, per-tick wall time (PCIe both ways included)"""
+    import time
+
+    import numpy as np
+
+    eng = SpectrogramEngine(48000.0, period=0.05, stride=2.0 / 1024, channels=2, gradient="magma")
+    rng = np.random.default_rng(0)
+    chunk = rng.uniform(-1, 1, (800, 2)).astype(np.float32)
+    for what in ("mags", "mags_f16", "rgba"):
+        ring = eng.live(4096)
+        ring.push(rng.uniform(-1, 1, (2400, 2)).astype(np.float32), 2)
+        ring.tick(what)
+        times, frames = [], 0
+        for _ in range(ticks):
+            ring.push(chunk, 2)
+            t0 = time.perf_counter()
+            frames += len(ring.tick(what, max_frames=32))
+            times.append(time.perf_counter() - t0)
+        t = np.array(times[20:]) * 1e6
+        print(f"live tick [{what}] W={eng.W} H={eng.H}: {frames / ticks:.1f} frames/tick, median {np.median(t):.0f} us, "
+              f"p99 {np.percentile(t, 99):.0f} us per tick (the tick period at 60 Hz is 16667 us)", flush=True)
+
+
+if __name__ == "__main__" and "--live" in sys.argv:
+    live_ticks()
