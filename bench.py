@@ -146,13 +146,17 @@ def main():
             # whole image -- 1e8 columns would be 410 GB, more than one GPU's HBM
             root_seen[0] += int(piece.shape[0])
 
+        def render(c0, cn):
+            eng.render_batch(pcm, first_frame=c0, max_frames=cn, out=rgba[c0:c0 + cn])
+
         def pixel_pass():
-            for c0, cn in chunks(Fp, chunk):
-                eng.render_batch(pcm, first_frame=c0, max_frames=cn, out=rgba[c0:c0 + cn])
-            if world > 1:
-                # the one exchange step of the path: finished pixel columns to rank 0 (RCCL over xGMI),
-                # world-1 point-to-point flows, chunked
-                gather_columns(rgba[:, 0], counts, dst=0, chunk=chunk, consume=consume)
+            if world == 1:
+                for c0, cn in chunks(Fp, chunk):
+                    render(c0, cn)
+            else:
+                # the one exchange step of the path: finished pixel columns to rank 0 (RCCL over xGMI), world-1
+                # concurrent point-to-point flows per chunk; chunk i's transfer overlaps chunk i+1's kernel
+                gather_columns(rgba[:, 0], counts, dst=0, chunk=chunk, consume=consume, produce=render)
 
         pixel_pass()
         torch.cuda.synchronize()

@@ -39,16 +39,52 @@ def chunks(n: int, chunk: int) -> Iterator[Tuple[int, int]]:
         yield c0, min(chunk, n - c0)
 
 
+def _post_round(mine, n_per_rank: List[int], dst: int, staged: bool, like, group):
+    """Post one round of the gather without waiting: the root posts one receive per contributing rank, every other
+    rank one send, as ONE batch (RCCL: one grouped launch, world - 1 concurrent point-to-point flows, one per
+    xGMI link into the root).  Returns (pieces, requests); pieces[r] is None where rank r sends nothing."""
+    import torch
+    import torch.distributed as dist
+
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    pieces, ops = [None] * world, []
+    if rank == dst:
+        for r in range(world):
+            if n_per_rank[r] == 0:
+                continue
+            if r == dst:
+                pieces[r] = mine
+                continue
+            pieces[r] = torch.empty((n_per_rank[r],) + tuple(like.shape[1:]), dtype=like.dtype,
+                                    device="cpu" if staged else like.device)
+            ops.append(dist.P2POp(dist.irecv, pieces[r], r, group))
+    elif n_per_rank[rank] > 0:
+        ops.append(dist.P2POp(dist.isend, mine.cpu() if staged else mine.contiguous(), dst, group))
+    return pieces, (dist.batch_isend_irecv(ops) if ops else [])
+
+
+def _finish_round(pieces, reqs, staged: bool, device):
+    for q in reqs:
+        q.wait()  # RCCL: orders the current stream after the transfer; gloo: blocks the host
+    if staged:
+        pieces = [None if p is None else (p if p.device == device else p.to(device)) for p in pieces]
+    return pieces
+
+
 def gather_columns(local, counts: List[int], dst: int = 0, chunk: int = 65536,
-                   consume: Optional[Callable] = None, group=None):
+                   consume: Optional[Callable] = None, group=None, produce: Optional[Callable] = None):
     """Gather pixel columns [n_local][...] from every rank to `dst`, in chunks of at most `chunk`
     columns per rank so that the root never holds more than world * chunk columns at once (1e8
     columns are 410 GB: more than one GPU's HBM).  `counts[r]` is rank r's column count (known from
     frame_range).  On the root, `consume(global_first_column, tensor)` is called for every piece in
     stream order per rank; without `consume` the pieces are concatenated and returned (small runs).
 
+    `produce(c0, n)`, if given, is called before round i's columns local[c0:c0+n] are sent: the caller
+    renders them there.  Round i's transfer is posted and round i+1 is produced before round i is
+    waited for, so on MI355X the xGMI transfer of one chunk overlaps the kernel of the next.
+
     Traffic shape on MI355X: world - 1 independent point-to-point flows into the root, one per
-    xGMI link -- per-link bound, no ring, no reduction."""
+    xGMI link, posted as one batch per round -- per-link bound, no ring, no reduction."""
     import torch
     import torch.distributed as dist
 
@@ -60,28 +96,28 @@ def gather_columns(local, counts: List[int], dst: int = 0, chunk: int = 65536,
     starts = [sum(counts[:r]) for r in range(world)]
     rounds = max((c + chunk - 1) // chunk for c in counts) if counts else 0
     kept = [[] for _ in range(world)]
-    for i in range(rounds):
+
+    def post(i):
         c0 = i * chunk
-        mine = local[c0:c0 + chunk]
-        if rank == dst:
-            for r in range(world):
-                n_r = max(min(chunk, counts[r] - c0), 0)
-                if n_r == 0:
-                    continue
-                if r == dst:
-                    piece = mine
-                else:
-                    piece = torch.empty((n_r,) + tuple(local.shape[1:]), dtype=local.dtype,
-                                        device="cpu" if staged else local.device)
-                    dist.recv(piece, src=r, group=group)
-                    if staged:
-                        piece = piece.to(local.device)
-                if consume is not None:
-                    consume(starts[r] + c0, piece)
-                else:
-                    kept[r].append(piece.clone() if r == dst else piece)
-        elif mine.shape[0] > 0:
-            dist.send(mine.cpu() if staged else mine.contiguous(), dst=dst, group=group)
+        n_per_rank = [max(min(chunk, counts[r] - c0), 0) for r in range(world)]
+        if produce is not None and n_per_rank[rank] > 0:
+            produce(c0, n_per_rank[rank])
+        return c0, _post_round(local[c0:c0 + chunk], n_per_rank, dst, staged, local, group)
+
+    pending = post(0) if rounds else None
+    for i in range(rounds):
+        c0, (pieces, reqs) = pending
+        pending = post(i + 1) if i + 1 < rounds else None
+        pieces = _finish_round(pieces, reqs, staged, local.device)
+        if rank != dst:
+            continue
+        for r in range(world):
+            if pieces[r] is None:
+                continue
+            if consume is not None:
+                consume(starts[r] + c0, pieces[r])
+            else:
+                kept[r].append(pieces[r].clone() if r == dst else pieces[r])
     if rank == dst and consume is None:
         flat = [p for r in range(world) for p in kept[r]]
         return torch.cat(flat) if flat else local[:0]

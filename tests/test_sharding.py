@@ -43,7 +43,7 @@ def _worker(rank, world, port, total_frames, out_path):
     import torch.distributed as dist
 
     import oracle
-    from spectrogram_rs_amd.sharding import frame_range, gather_columns, sample_range
+    from spectrogram_rs_amd.sharding import chunks, frame_range, gather_columns, sample_range
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -62,10 +62,20 @@ def _worker(rank, world, port, total_frames, out_path):
     # (b) streaming gather: the root only ever sees one piece at a time
     seen = {}
     gather_columns(cols, counts, dst=0, chunk=4, consume=lambda g0, t: seen.__setitem__(g0, t.clone()))
+    # (c) pipelined gather: the columns of a round are produced (rendered) only when that round is posted, one
+    #     round ahead of the round being waited for
+    lazy, calls = torch.zeros_like(cols), []
+
+    def produce(c0, n_cols):
+        calls.append((c0, n_cols))
+        lazy[c0:c0 + n_cols] = cols[c0:c0 + n_cols]
+
+    img2 = gather_columns(lazy, counts, dst=0, chunk=3, produce=produce)
+    assert calls == list(chunks(count, 3))
     if rank == 0:
         assert img.shape[0] == total_frames
         pieces = torch.cat([seen[k] for k in sorted(seen)])
-        assert torch.equal(pieces, img)
+        assert torch.equal(pieces, img) and torch.equal(img2, img)
         np.save(out_path, img.numpy())
     dist.barrier()
     dist.destroy_process_group()
