@@ -69,16 +69,20 @@ __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
 
     // per-thread constants, kept in registers for the life of the (persistent) workgroup
 #ifndef SGX_WIN_RELOAD
+    // the output scale (hypot / 2) * (2 / W) = 2^-11 rides on the window: a power of two commutes with every
+    // rounding below (products, sums, the square root of a sum of squares), so the bits are the same and the
+    // 16 multiplies per thread after the square roots are gone
+    const float inv_w = 1.0f / (float)kW;
+    static_assert((kW & (kW - 1)) == 0, "the scale must be a power of two to move it");
     float win[8];
 #pragma unroll
-    for (int a = 0; a < 8; ++a) win[a] = p.window[tid + 256 * a];
+    for (int a = 0; a < 8; ++a) win[a] = p.window[tid + 256 * a] * inv_w;
 #endif
     float2 tw1[16];
 #pragma unroll
     for (int q = 1; q < 16; ++q) tw1[q] = p.tw1[q * 256 + tid];
 
     const int q1_2 = tid >> 4, t0_2 = tid & 15;                 // pass-2 role
-    const float inv_w = 1.0f / (float)kW;                       // (hypot / 2) * (2 / W)
     __syncthreads();
 
     const unsigned long long job_begin = (unsigned long long)blockIdx.x * p.jobs_per_block;
@@ -149,7 +153,7 @@ __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
         // the Hann factors are re-read (L1-resident 8 KB table) instead of pinning 8 VGPRs
         float win[8];
 #pragma unroll
-        for (int a = 0; a < 8; ++a) win[a] = p.window[tid + 256 * a];
+        for (int a = 0; a < 8; ++a) win[a] = p.window[tid + 256 * a] * (1.0f / (float)kW);
 #endif
         // local (output) frame indices; for mono f0 may be -1 (the pair's first frame precedes the range)
         const long long f0 = MONO ? (long long)(2 * (p.pair_base + job)) - (long long)p.first_frame : (long long)job;
@@ -234,31 +238,30 @@ __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
             const float ar = xr[pos], ai = xi[pos];
             const float pr = ar + b.x, pi = ai - b.y;   // a + conj(b) = 2 L^
             const float qr = ar - b.x, qi = ai + b.y;   // a - conj(b) = 2i R^
-            ml[q3] = __builtin_amdgcn_sqrtf(fmaf(pr, pr, pi * pi)) * inv_w;
-            mr[q3] = __builtin_amdgcn_sqrtf(fmaf(qr, qr, qi * qi)) * inv_w;
+            ml[q3] = __builtin_amdgcn_sqrtf(fmaf(pr, pr, pi * pi));  // already scaled by 1 / W (see `win`)
+            mr[q3] = __builtin_amdgcn_sqrtf(fmaf(qr, qr, qi * qi));
         }
 
         if (!RENDER) {
             // ---- store [F][pairs][M][2]: uniform row base (SGPR) + one 32-bit lane offset
             if (p.out_f16) {
                 char *base = reinterpret_cast<char *>(p.mags);
-                char *row0 = base + ((size_t)(have_first ? f0 : 0) * p.pairs + p.pair) * (size_t)kM * 4 - 4;
+                const long long row0 = (long long)(((size_t)(have_first ? f0 : 0) * p.pairs + p.pair) * (size_t)kM * 4) - 4;
                 if (MONO) {
-                    if (have_first) store_row_f16<true>(row0, col, ml, ml);
-                    if (have_second) store_row_f16<true>(base + (f1 * p.pairs + p.pair) * (size_t)kM * 4 - 4, col, mr, mr);
+                    if (have_first) store_row_f16<true>(base, row0, col, ml, ml);
+                    if (have_second) store_row_f16<true>(base, (long long)((f1 * p.pairs + p.pair) * (size_t)kM * 4) - 4, col, mr, mr);
                 } else {
-                    store_row_f16<false>(row0, col, ml, mr);
+                    store_row_f16<false>(base, row0, col, ml, mr);
                 }
             } else {
-                char *row0 = reinterpret_cast<char *>(p.mags + (((size_t)(have_first ? f0 : 0) * p.pairs + p.pair) * (size_t)kM) * 2) - 8;
+                // byte offset of bin k = 0 of the row (bin k lives 8 k bytes on; k = 0 is never stored)
+                char *base = reinterpret_cast<char *>(p.mags);
+                const long long row0 = (long long)((((size_t)(have_first ? f0 : 0) * p.pairs + p.pair) * (size_t)kM) * 8) - 8;
                 if (MONO) {
-                    if (have_first) store_row<true>(row0, col, ml, ml);
-                    if (have_second) {
-                        char *row1 = reinterpret_cast<char *>(p.mags + ((f1 * p.pairs + p.pair) * (size_t)kM) * 2) - 8;
-                        store_row<true>(row1, col, mr, mr);
-                    }
+                    if (have_first) store_row<true>(base, row0, col, ml, ml);
+                    if (have_second) store_row<true>(base, (long long)(((f1 * p.pairs + p.pair) * (size_t)kM) * 8) - 8, col, mr, mr);
                 } else {
-                    store_row<false>(row0, col, ml, mr);
+                    store_row<false>(base, row0, col, ml, mr);
                 }
             }
         } else {

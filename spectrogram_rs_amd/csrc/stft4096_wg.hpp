@@ -75,14 +75,30 @@ __device__ __forceinline__ void lds_barrier()
 
 // one row of [M][2] floats; rowm8 = row base - 8 bytes (bin k lives at byte 8 k of rowm8): a uniform
 // (SGPR) row base plus one 32-bit lane offset, immediate offsets per segment
-template <bool DUP>  // DUP: mono, the row holds (m, m); else (va, vb) = (left, right)
-__device__ __forceinline__ void store_row(char *rowm8, int col, const float (&va)[8], const float (&vb)[8])
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+// A raw buffer descriptor over one output row: base = the row's bin-0 address (uniform), no stride, no bounds
+// in the way (2 GB window).  Stores through it take an SGPR descriptor + one 32-bit lane offset + a scalar
+// segment offset + an immediate: no per-lane 64-bit address arithmetic at all.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t row_rsrc(char *mags, long long row_byte)
 {
-    const uint32_t lane_off = (uint32_t)col * 8u;
+    const uint32_t olo = __builtin_amdgcn_readfirstlane((uint32_t)row_byte);
+    const uint32_t ohi = __builtin_amdgcn_readfirstlane((uint32_t)((unsigned long long)row_byte >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc(mags + (long long)(((unsigned long long)ohi << 32) | olo), 0, 0x7fffffff, 0x00020000);
+}
+
+// one row of [M][2] floats; row_byte = byte offset of the row's (absent) bin 0, bin k lives 8 k bytes on
+template <bool DUP>  // DUP: mono, the row holds (m, m); else (va, vb) = (left, right)
+__device__ __forceinline__ void store_row(char *mags, long long row_byte, int col, const float (&va)[8], const float (&vb)[8])
+{
+    const __amdgpu_buffer_rsrc_t r = row_rsrc(mags, row_byte);
+    const int lane_off = col * 8;
 #pragma unroll
     for (int q3 = 0; q3 < 8; ++q3)
-        if (q3 > 0 || col != 0)  // k = 0 (DC) is not part of the output (fft.rs:81)
-            *reinterpret_cast<float2 *>(rowm8 + 2048 * q3 + lane_off) = DUP ? make_float2(va[q3], va[q3]) : make_float2(va[q3], vb[q3]);
+        if (q3 > 0 || col != 0) {  // k = 0 (DC) is not part of the output (fft.rs:81)
+            const u32x2 d = {__float_as_uint(va[q3]), __float_as_uint(DUP ? va[q3] : vb[q3])};
+            __builtin_amdgcn_raw_buffer_store_b64(d, r, lane_off + 2048 * (q3 & 1), 4096 * (q3 >> 1), 0);
+        }
 }
 
 // ---- fused pixel column: magnitude_in -> color_for -> put_pixel (simple_spectrogram.rs:141-161) ---------------
@@ -181,14 +197,15 @@ __device__ __forceinline__ void render_column(const Params &p, const float *mc, 
 
 // the same row as IEEE half pairs (round to nearest even): bin k at byte 4 k of rowm4
 template <bool DUP>
-__device__ __forceinline__ void store_row_f16(char *rowm4, int col, const float (&va)[8], const float (&vb)[8])
+__device__ __forceinline__ void store_row_f16(char *mags, long long row_byte, int col, const float (&va)[8], const float (&vb)[8])
 {
-    const uint32_t lane_off = (uint32_t)col * 4u;
+    const __amdgpu_buffer_rsrc_t r = row_rsrc(mags, row_byte);
+    const int lane_off = col * 4;
 #pragma unroll
     for (int q3 = 0; q3 < 8; ++q3)
         if (q3 > 0 || col != 0) {
             const __half2 h = __floats2half2_rn(va[q3], DUP ? va[q3] : vb[q3]);
-            *reinterpret_cast<__half2 *>(rowm4 + 1024 * q3 + lane_off) = h;
+            __builtin_amdgcn_raw_buffer_store_b32(*reinterpret_cast<const uint32_t *>(&h), r, lane_off + 1024 * (q3 & 3), 4096 * (q3 >> 2), 0);
         }
 }
 

@@ -227,23 +227,22 @@ __global__ void __launch_bounds__(256, 4) stft4096_wgp_kernel(Params p)
             // ---- store [F][pairs][M][2]: uniform row base (SGPR) + one 32-bit lane offset
             if (p.out_f16) {
                 char *base = reinterpret_cast<char *>(p.mags);
-                char *row0 = base + ((size_t)(have_first ? f0 : 0) * p.pairs + p.pair) * (size_t)kM * 4 - 4;
+                const long long row0 = (long long)(((size_t)(have_first ? f0 : 0) * p.pairs + p.pair) * (size_t)kM * 4) - 4;
                 if (MONO) {
-                    if (have_first) store_row_f16<true>(row0, col, ml, ml);
-                    if (have_second) store_row_f16<true>(base + (f1 * p.pairs + p.pair) * (size_t)kM * 4 - 4, col, mr, mr);
+                    if (have_first) store_row_f16<true>(base, row0, col, ml, ml);
+                    if (have_second) store_row_f16<true>(base, (long long)((f1 * p.pairs + p.pair) * (size_t)kM * 4) - 4, col, mr, mr);
                 } else {
-                    store_row_f16<false>(row0, col, ml, mr);
+                    store_row_f16<false>(base, row0, col, ml, mr);
                 }
             } else {
-                char *row0 = reinterpret_cast<char *>(p.mags + (((size_t)(have_first ? f0 : 0) * p.pairs + p.pair) * (size_t)kM) * 2) - 8;
+                // byte offset of bin k = 0 of the row (bin k lives 8 k bytes on; k = 0 is never stored)
+                char *base = reinterpret_cast<char *>(p.mags);
+                const long long row0 = (long long)((((size_t)(have_first ? f0 : 0) * p.pairs + p.pair) * (size_t)kM) * 8) - 8;
                 if (MONO) {
-                    if (have_first) store_row<true>(row0, col, ml, ml);
-                    if (have_second) {
-                        char *row1 = reinterpret_cast<char *>(p.mags + ((f1 * p.pairs + p.pair) * (size_t)kM) * 2) - 8;
-                        store_row<true>(row1, col, mr, mr);
-                    }
+                    if (have_first) store_row<true>(base, row0, col, ml, ml);
+                    if (have_second) store_row<true>(base, (long long)(((f1 * p.pairs + p.pair) * (size_t)kM) * 8) - 8, col, mr, mr);
                 } else {
-                    store_row<false>(row0, col, ml, mr);
+                    store_row<false>(base, row0, col, ml, mr);
                 }
             }
         } else {
