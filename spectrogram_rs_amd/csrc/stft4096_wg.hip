@@ -93,6 +93,9 @@ __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
     // its FFT passes, i.e. BEFORE j's magnitude stores.  vmcnt retires in issue order, so a load
     // issued after 16-32 stores would have to wait for all of them to reach memory first.
     float sa[(MONO && PAIRING == kPairAdjacentRow) ? 9 : 8], sb[8];
+    float ld0 = 0.0f, ld1 = 0.0f;   // sliding window: the two rows requested for the next transform
+    bool pending = false;
+    uint32_t issued_since = 0;      // vector-memory instructions this wave issued after requesting ld0 / ld1
     auto fetch = [&](unsigned long long job, bool sequential) {
         if (MONO) {
             // frames are paired by their GLOBAL index (2q, 2q+1), so the bytes do not depend on where a
@@ -106,14 +109,24 @@ __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
                 // (two frames on) re-uses rows 2..8 of this one: slide the register window and
                 // load only the two new rows -- every sample is fetched once per workgroup
                 if (kSlideWindow && sequential) {
-#pragma unroll
-                    for (int a = 0; a < 7; ++a) sa[a] = sa[a + 2];
-                    sa[7] = s0[tid + 256 * 7];
+                    // Only REQUEST the two new rows here.  They land in two pending registers and are rotated
+                    // into the window at the top of the next iteration, AFTER this transform's stores have been
+                    // issued: the wait for them is then `vmcnt(stores issued since)`, which the older loads
+                    // satisfy while the stores are still in flight.  The compiler cannot express that wait (at
+                    // the loop header it merges the entry path and falls back to vmcnt(0), i.e. it drains the
+                    // store stream once per transform), so the two loads and their wait are written by hand.
+                    const float *r7 = s0 + 256 * 7;
+                    const float *r8 = second ? r7 + 256 : r7;  // no partner frame: any valid address, the value is unused
+                    asm volatile("global_load_dword %0, %2, %3\n\tglobal_load_dword %1, %2, %4"
+                                 : "=&v"(ld0), "=&v"(ld1)
+                                 : "v"(tid * 4), "s"(r7), "s"(r8)
+                                 : "memory");
+                    pending = true;
                 } else {
 #pragma unroll
                     for (int a = 0; a < 8; ++a) sa[a] = s0[tid + 256 * a];
+                    sa[8] = second ? s0[tid + 256 * 8] : 0.0f;
                 }
-                sa[8] = second ? s0[tid + 256 * 8] : 0.0f;
             } else {
                 const float *s1 = second ? p.pcm + fb * p.H : s0;
 #pragma unroll
@@ -145,8 +158,24 @@ __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
         }
     };
     if (job_begin < job_end) fetch(job_begin, false);
+    if (MONO && PAIRING == kPairAdjacentRow && kSlideWindow) {
+        // the first window is waited for HERE, so that the loop header carries no pending load of the entry path
+        asm volatile("" ::"v"(sa[0]), "v"(sa[1]), "v"(sa[2]), "v"(sa[3]), "v"(sa[4]), "v"(sa[5]), "v"(sa[6]), "v"(sa[7]),
+                     "v"(sa[(MONO && PAIRING == kPairAdjacentRow) ? 8 : 7]));
+    }
 
     for (unsigned long long job = job_begin; job < job_end; ++job) {
+        if (MONO && PAIRING == kPairAdjacentRow && kSlideWindow && pending) {
+            // this transform = the previous one moved on by two rows.  vmcnt counts in issue order: the two row
+            // loads are complete once no more than `issued_since` younger instructions are outstanding.
+            if (issued_since >= 14) asm volatile("s_waitcnt vmcnt(14)" : "+v"(ld0), "+v"(ld1));
+            else if (issued_since >= 7) asm volatile("s_waitcnt vmcnt(7)" : "+v"(ld0), "+v"(ld1));
+            else asm volatile("s_waitcnt vmcnt(0)" : "+v"(ld0), "+v"(ld1));
+#pragma unroll
+            for (int a = 0; a < 7; ++a) sa[a] = sa[a + 2];
+            sa[7] = ld0;
+            sa[(MONO && PAIRING == kPairAdjacentRow) ? 8 : 7] = ld1;
+        }
         // ---- Hann (fft.rs:53-63) on the prefetched samples
         float er[8], ei[8];
 #ifdef SGX_WIN_RELOAD
@@ -242,6 +271,10 @@ __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
             mr[q3] = __builtin_amdgcn_sqrtf(fmaf(qr, qr, qi * qi));
         }
 
+        // every stored row is 8 store instructions in every wave (the lane of bin 0 is masked, not skipped; the
+        // wait below assumes 7, one to spare); the fused pixel path issues table loads and pixel stores of its
+        // own: counted as "unknown" = 0
+        issued_since = RENDER ? 0u : 7u * ((have_first ? 1u : 0u) + ((MONO && have_second) ? 1u : 0u));
         if (!RENDER) {
             // ---- store [F][pairs][M][2]: uniform row base (SGPR) + one 32-bit lane offset
             if (p.out_f16) {

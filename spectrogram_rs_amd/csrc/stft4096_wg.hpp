@@ -1,6 +1,9 @@
 // stft4096_wg.hpp -- declarations shared by the two workgroup-per-transform kernels
 // (stft4096_wg.hip: scalar codelets; stft4096_wgp.hip: packed (re, im) codelets).
 #pragma once
+#ifndef SGX_ABL_NSTORE
+#define SGX_ABL_NSTORE 8  // ablation builds only: store this many of the 8 row segments
+#endif
 #include <hip/hip_fp16.h>
 
 #include "sgx_internal.hpp"
@@ -95,7 +98,7 @@ __device__ __forceinline__ void store_row(char *mags, long long row_byte, int co
     const int lane_off = col * 8;
 #pragma unroll
     for (int q3 = 0; q3 < 8; ++q3)
-        if (q3 > 0 || col != 0) {  // k = 0 (DC) is not part of the output (fft.rs:81)
+        if ((q3 > 0 || col != 0) && q3 < SGX_ABL_NSTORE) {  // k = 0 (DC) is not part of the output (fft.rs:81)
             const u32x2 d = {__float_as_uint(va[q3]), __float_as_uint(DUP ? va[q3] : vb[q3])};
             __builtin_amdgcn_raw_buffer_store_b64(d, r, lane_off + 2048 * (q3 & 1), 4096 * (q3 >> 1), 0);
         }
