@@ -300,25 +300,22 @@ __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
         } else {
             // ---- fused pixel column(s): magnitude_in -> color_for -> put_pixel
             //      (simple_spectrogram.rs:141-161), magnitudes staged in LDS only
-            float *m0 = reinterpret_cast<float *>(buf);   // MONO: column of frame f0 ; else interleaved (l, r)
-            float *m1 = m0 + 2048;                        // MONO: column of frame f0 + 1
+            float2 *m2 = reinterpret_cast<float2 *>(buf);  // [bin - 1]: (l, r), or for mono (frame f0, frame f0 + 1)
+            float2 *vbuf = m2 + 2048;                       // [sample]: the interpolated pair
             lds_barrier();  // partner reads done: the buffer can be overwritten
 #pragma unroll
             for (int q3 = 0; q3 < 8; ++q3) {
                 const int k = col + 256 * q3;
-                if (k >= 1) {
-                    if (MONO) { m0[k - 1] = ml[q3]; m1[k - 1] = mr[q3]; }
-                    else reinterpret_cast<float2 *>(m0)[k - 1] = make_float2(ml[q3], mr[q3]);
-                }
+                if (k >= 1) m2[k - 1] = make_float2(ml[q3], mr[q3]);
             }
             lds_barrier();
-            for (int c_i = 0; c_i < (MONO ? 2 : 1); ++c_i) {
-                if (MONO && !(c_i ? have_second : have_first)) continue;
-                const float *mc = MONO ? (c_i ? m1 : m0) : m0;
-                uchar4 *dst = reinterpret_cast<uchar4 *>(p.rgba) + ((size_t)(c_i ? f1 : f0) * p.pairs + p.pair) * (size_t)p.R;
-                if (p.interp == SGX_INTERP_COSINE) render_column<MONO, true>(p, mc, dst, thr, lut, tid);
-                else render_column<MONO, false>(p, mc, dst, thr, lut, tid);
-            }
+            if (p.interp == SGX_INTERP_COSINE) sample_pass<true>(p, m2, vbuf, tid);
+            else sample_pass<false>(p, m2, vbuf, tid);
+            lds_barrier();
+            uchar4 *rgba = reinterpret_cast<uchar4 *>(p.rgba);
+            uchar4 *dst_a = rgba + ((size_t)(have_first ? f0 : 0) * p.pairs + p.pair) * (size_t)p.R;
+            uchar4 *dst_b = rgba + ((size_t)f1 * p.pairs + p.pair) * (size_t)p.R;
+            row_pass<MONO>(p, vbuf, dst_a, dst_b, have_first, have_second, thr, lut, tid);
         }
     }
 }
@@ -349,24 +346,24 @@ hipError_t wg4096_init(sgx_ctx *c, void **out)
     // mu^2, mu^3 and 1 - o' with the same single-rounded operations the host table holds)
     std::vector<uint32_t> rows(c->tab.rows.size());
     std::vector<PackedSample> samples(c->tab.samples.size());
-    bool fusable = c->tab.samples.size() < 65536;
+    // the interpolated samples of a column sit in LDS behind the column itself
+    bool fusable = c->tab.samples.size() <= (size_t)kMaxFusedSamples;
     const int32_t last = (int32_t)c->M - 1;
     for (size_t i = 0; i < rows.size(); ++i) {
         const auto &r = c->tab.rows[i];
-        if (r.count >= 32768) fusable = false;
-        bool interior = true;  // no tap of this row is clamped at either end of the spectrum
-        for (uint32_t k = 0; k < r.count; ++k) {
-            const int32_t x1 = c->tab.samples[r.first + k].i0;
-            if (c->cfg.interp == SGX_INTERP_COSINE ? (x1 + 1 > last) : (x1 < 1 || x1 + 2 > last)) interior = false;
-        }
-        rows[i] = (r.first & 0xffffu) | ((r.count & 0x7fffu) << 16) | (interior ? 0x80000000u : 0u);
+        if (r.count >= 65536 || r.first >= 65536) fusable = false;
+        rows[i] = (r.first & 0xffffu) | ((r.count & 0xffffu) << 16);
     }
     for (size_t i = 0; i < samples.size(); ++i) {
         const auto &se = c->tab.samples[i];
-        samples[i].i0 = se.i0;
+        const int32_t x1 = se.i0;
+        // interior: no tap of this sample is clamped at either end of the spectrum
+        const bool interior = c->cfg.interp == SGX_INTERP_COSINE ? !(x1 + 1 > last) : !(x1 < 1 || x1 + 2 > last);
+        samples[i].i0 = interior ? x1 : ~x1;
         samples[i].w = c->cfg.interp == SGX_INTERP_COSINE ? se.w2 : se.w0;
     }
     t->fusable = fusable;
+    t->n_samples = (uint32_t)samples.size();
 
     auto up = [](auto **dst, const auto &v) {
         hipError_t e = hipMalloc(reinterpret_cast<void **>(dst), v.size() * sizeof(v[0]));
@@ -434,6 +431,7 @@ hipError_t launch_wg(const sgx_ctx *c, const void *tables, const float *d_pcm, u
         if (RENDER) {
             p.rows = t->d_rows;
             p.samples = t->d_samples;
+            p.n_samples = t->n_samples;
             p.lut_thr = c->d_lut_thr;
             p.lut_rgba = c->d_lut_rgba;
             p.rgba = d_rgba;

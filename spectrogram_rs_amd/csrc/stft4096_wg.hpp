@@ -42,6 +42,7 @@ struct Params {
     // fused pixel path (RENDER): magnitudes never leave LDS
     const uint32_t *rows;      // [R]  first | count << 16
     const PackedSample *samples;
+    uint32_t n_samples;        // samples per column (sum of the rows' counts)
     const float *lut_thr;      // [255]
     const uchar4 *lut_rgba;    // [256]
     uint8_t *rgba;             // [F][pairs][R][4]
@@ -63,6 +64,7 @@ struct WgTables {
     float2 *d_tw2 = nullptr;
     uint32_t *d_rows = nullptr;        // packed row table for the fused pixel path
     PackedSample *d_samples = nullptr;
+    uint32_t n_samples = 0;
     bool fusable = false;
 };
 
@@ -105,96 +107,105 @@ __device__ __forceinline__ void store_row(char *mags, long long row_byte, int co
 }
 
 // ---- fused pixel column: magnitude_in -> color_for -> put_pixel (simple_spectrogram.rs:141-161) ---------------
-// `mc` is one column of magnitudes in LDS: MONO a scalar per bin (l = r), else (l, r) pairs.  Row word:
-// first sample | count << 16 | interior << 31, where `interior` says that no tap of the row touches the
-// ends of the spectrum, so the taps are the contiguous bins x1-1 .. x1+2 (cubic) / lo, lo+1 (cosine) and
-// the saturating index arithmetic of interpolated_frequency_sample.rs:89-105 can be skipped.
-template <bool MONO, bool COSINE, bool INTERIOR>
-__device__ __forceinline__ void interp_sample(const float *mc, const PackedSample se, int last, float &vl, float &vr)
+// Two passes over LDS, both balanced whatever the rows' sample counts (a row of the log axis averages 1 sample
+// at the bottom and 11 at the top: one thread per ROW leaves the wave that owns the top rows with twice the work
+// of the others, and walks the sample table in a dependent loop of L1 loads):
+//   sample pass  one thread per magnitude_in SAMPLE (2 173 per column at 48 kHz / 1024 rows): coalesced table
+//                read, interpolation of BOTH channels (stereo) or BOTH mono columns of the transform -- the
+//                column lives in LDS as float2 per bin either way -- result to LDS
+//   row pass     one thread per row: sum of its samples in lin_space order (Complex::sum), the divide, dB
+//                thresholds, LUT, pixel store (coalesced: consecutive lanes, consecutive image rows)
+// Sample word: i0 >= 0: no tap touches the ends of the spectrum (taps are contiguous bins, the saturating index
+// arithmetic of interpolated_frequency_sample.rs:89-105 is skipped); i0 < 0: ~i0 is the index, taps are clamped.
+constexpr int kMaxFusedSamples = (kBufComplex - 2048);  // float2 per sample behind the 2048-bin column (2304)
+
+template <bool COSINE, bool INTERIOR>
+__device__ __forceinline__ float2 interp_sample2(const float2 *m2, int i0, float w, int last)
 {
-    vr = 0.0f;
+    float2 v;
     if (COSINE) {
         // :79-86  data[low] * (1 - o') + data[high] * o'
-        const int lo = se.i0, hi = INTERIOR ? lo + 1 : (lo + 1 < last ? lo + 1 : last);
-        const float w1 = 1.0f - se.w;
-        if (MONO) {
-            vl = mc[lo] * w1 + mc[hi] * se.w;
-        } else {
-            const float2 a = reinterpret_cast<const float2 *>(mc)[lo], b = reinterpret_cast<const float2 *>(mc)[hi];
-            vl = a.x * w1 + b.x * se.w;
-            vr = a.y * w1 + b.y * se.w;
-        }
+        const int lo = i0, hi = INTERIOR ? lo + 1 : (lo + 1 < last ? lo + 1 : last);
+        const float w1 = 1.0f - w;
+        const float2 a = m2[lo], b = m2[hi];
+        v.x = a.x * w1 + b.x * w;
+        v.y = a.y * w1 + b.y * w;
     } else {
         // :89-105
-        const int x1 = se.i0;
+        const int x1 = i0;
         const int x0 = INTERIOR ? x1 - 1 : (x1 > 0 ? x1 - 1 : 0);
         const int x2 = INTERIOR ? x1 + 1 : (x1 + 1 < last ? x1 + 1 : last);
         const int x3 = INTERIOR ? x1 + 2 : (x1 + 2 < last ? x1 + 2 : last);
-        const float mu = se.w, mu2 = mu * mu, mu3 = mu * mu2;
-        if (MONO) {
-            const float y0 = mc[x0], y1 = mc[x1], y2 = mc[x2], y3 = mc[x3];
-            const float a0 = ((y3 - y2) - y0) + y1;
-            const float a1 = (y0 - y1) - a0;
-            const float a2 = y2 - y0;
-            vl = ((a0 * mu3) + (a1 * mu2)) + ((a2 * mu) + y1);
-        } else {
-            const float2 *m2 = reinterpret_cast<const float2 *>(mc);
-            const float2 y0 = m2[x0], y1 = m2[x1], y2 = m2[x2], y3 = m2[x3];
-            {
-                const float a0 = ((y3.x - y2.x) - y0.x) + y1.x;
-                const float a1 = (y0.x - y1.x) - a0;
-                const float a2 = y2.x - y0.x;
-                vl = ((a0 * mu3) + (a1 * mu2)) + ((a2 * mu) + y1.x);
-            }
-            {
-                const float a0 = ((y3.y - y2.y) - y0.y) + y1.y;
-                const float a1 = (y0.y - y1.y) - a0;
-                const float a2 = y2.y - y0.y;
-                vr = ((a0 * mu3) + (a1 * mu2)) + ((a2 * mu) + y1.y);
-            }
+        const float mu = w, mu2 = mu * mu, mu3 = mu * mu2;
+        const float2 y0 = m2[x0], y1 = m2[x1], y2 = m2[x2], y3 = m2[x3];
+        {
+            const float a0 = ((y3.x - y2.x) - y0.x) + y1.x;
+            const float a1 = (y0.x - y1.x) - a0;
+            const float a2 = y2.x - y0.x;
+            v.x = ((a0 * mu3) + (a1 * mu2)) + ((a2 * mu) + y1.x);
         }
+        {
+            const float a0 = ((y3.y - y2.y) - y0.y) + y1.y;
+            const float a1 = (y0.y - y1.y) - a0;
+            const float a2 = y2.y - y0.y;
+            v.y = ((a0 * mu3) + (a1 * mu2)) + ((a2 * mu) + y1.y);
+        }
+    }
+    return v;
+}
+
+template <bool COSINE>
+__device__ __forceinline__ void sample_pass(const Params &p, const float2 *m2, float2 *vbuf, int tid)
+{
+    const int last = kM - 1;
+    for (uint32_t s = tid; s < p.n_samples; s += 256) {
+        const PackedSample se = p.samples[s];
+        vbuf[s] = se.i0 >= 0 ? interp_sample2<COSINE, true>(m2, se.i0, se.w, last)
+                             : interp_sample2<COSINE, false>(m2, ~se.i0, se.w, last);
     }
 }
 
-// (Tried: dealing rows to the four waves round-robin to even out the sample counts, which grow with the
-// row -- the strided pixel stores cost more than the balance gains: 145 -> 133 M frames/s.)
-template <bool MONO, bool COSINE>
-__device__ __forceinline__ void render_column(const Params &p, const float *mc, uchar4 *dst, const float *thr, const uchar4 *lut, int tid)
+// colorscheme.rs:59-61 as a threshold count; the log2 only seeds the search
+__device__ __forceinline__ uchar4 pixel_for(const Params &p, float l, float r, const float *thr, const uchar4 *lut)
 {
-    const int last = kM - 1;
+    const float power = (l * l) + (r * r);
+    int idx = (int)floorf(fmaf(__builtin_amdgcn_logf(power + 1e-7f), p.guess_a, p.guess_b));
+    idx = idx < 0 ? 0 : (idx > 255 ? 255 : idx);
+    while (idx < 255 && power >= thr[idx]) ++idx;
+    while (idx > 0 && !(power >= thr[idx - 1])) --idx;
+    return lut[idx];  // alpha = 1.0 -> 255
+}
+
+// MONO: .x / .y of a sample are the two columns (frames) of the transform, each a (s, s) pixel; else one (l, r) pixel.
+// (Tried, same-device A/B: the thread's sample-table words and row words requested before the two barriers and the
+// loops unrolled (9 samples, 4 rows side by side, thresholds read four at a time): 182 -> 131 M frames/s -- these
+// kernels sit at the 128-VGPR cap of four waves per SIMD and every extra live value becomes scratch traffic.)
+template <bool MONO>
+__device__ __forceinline__ void row_pass(const Params &p, const float2 *vbuf, uchar4 *dst_a, uchar4 *dst_b, bool have_a, bool have_b,
+                                         const float *thr, const uchar4 *lut, int tid)
+{
     for (uint32_t py = tid; py < p.R; py += 256) {
         const uint32_t re = p.rows[py];
-        const uint32_t first = re & 0xffffu, cnt = (re >> 16) & 0x7fffu;
+        const uint32_t first = re & 0xffffu, cnt = re >> 16;
         float sl = 0.0f, sr = 0.0f;  // Complex::sum starts at zero
-        if (re >> 31) {
-            for (uint32_t i = 0; i < cnt; ++i) {
-                float vl, vr;
-                interp_sample<MONO, COSINE, true>(mc, p.samples[first + i], last, vl, vr);
-                sl = sl + vl;
-                if (!MONO) sr = sr + vr;
-            }
-        } else {
-            for (uint32_t i = 0; i < cnt; ++i) {
-                float vl, vr;
-                interp_sample<MONO, COSINE, false>(mc, p.samples[first + i], last, vl, vr);
-                sl = sl + vl;
-                if (!MONO) sr = sr + vr;
-            }
+        for (uint32_t i = 0; i < cnt; ++i) {
+            const float2 v = vbuf[first + i];
+            sl = sl + v.x;
+            sr = sr + v.y;
         }
         float l = sl, r = sr;
         if (cnt > 1) {  // x / 1.0 == x: only rows that average several samples divide (:72)
             const float nf = (float)cnt;
             l = sl / nf;
-            if (!MONO) r = sr / nf;
+            r = sr / nf;
         }
-        if (MONO) r = l;  // mono -> (s, s): both channels carry the same magnitude
-        // colorscheme.rs:59-61 as a threshold count; the log2 only seeds the search
-        const float power = (l * l) + (r * r);
-        int idx = (int)floorf(fmaf(__builtin_amdgcn_logf(power + 1e-7f), p.guess_a, p.guess_b));
-        idx = idx < 0 ? 0 : (idx > 255 ? 255 : idx);
-        while (idx < 255 && power >= thr[idx]) ++idx;
-        while (idx > 0 && !(power >= thr[idx - 1])) --idx;
-        dst[p.R - 1 - py] = lut[idx];  // simple_spectrogram.rs:150; alpha = 1.0 -> 255
+        const uint32_t y = p.R - 1 - py;  // simple_spectrogram.rs:150
+        if (MONO) {  // mono -> (s, s): both channels carry the same magnitude
+            if (have_a) dst_a[y] = pixel_for(p, l, l, thr, lut);
+            if (have_b) dst_b[y] = pixel_for(p, r, r, thr, lut);
+        } else {
+            dst_a[y] = pixel_for(p, l, r, thr, lut);
+        }
     }
 }
 

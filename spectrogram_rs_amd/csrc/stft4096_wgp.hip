@@ -248,25 +248,22 @@ __global__ void __launch_bounds__(256, 4) stft4096_wgp_kernel(Params p)
         } else {
             // ---- fused pixel column(s): magnitude_in -> color_for -> put_pixel
             //      (simple_spectrogram.rs:141-161), magnitudes staged in LDS only
-            float *m0 = reinterpret_cast<float *>(buf);   // MONO: column of frame f0 ; else interleaved (l, r)
-            float *m1 = m0 + 2048;                        // MONO: column of frame f0 + 1
+            float2 *m2 = reinterpret_cast<float2 *>(buf);  // [bin - 1]: (l, r), or for mono (frame f0, frame f0 + 1)
+            float2 *vbuf = m2 + 2048;                       // [sample]: the interpolated pair
             lds_barrier();  // partner reads done: the buffer can be overwritten
 #pragma unroll
             for (int q3 = 0; q3 < 8; ++q3) {
                 const int k = col + 256 * q3;
-                if (k >= 1) {
-                    if (MONO) { m0[k - 1] = ml[q3]; m1[k - 1] = mr[q3]; }
-                    else reinterpret_cast<float2 *>(m0)[k - 1] = make_float2(ml[q3], mr[q3]);
-                }
+                if (k >= 1) m2[k - 1] = make_float2(ml[q3], mr[q3]);
             }
             lds_barrier();
-            for (int c_i = 0; c_i < (MONO ? 2 : 1); ++c_i) {
-                if (MONO && !(c_i ? have_second : have_first)) continue;
-                const float *mc = MONO ? (c_i ? m1 : m0) : m0;
-                uchar4 *dst = reinterpret_cast<uchar4 *>(p.rgba) + ((size_t)(c_i ? f1 : f0) * p.pairs + p.pair) * (size_t)p.R;
-                if (p.interp == SGX_INTERP_COSINE) render_column<MONO, true>(p, mc, dst, thr, lut, tid);
-                else render_column<MONO, false>(p, mc, dst, thr, lut, tid);
-            }
+            if (p.interp == SGX_INTERP_COSINE) sample_pass<true>(p, m2, vbuf, tid);
+            else sample_pass<false>(p, m2, vbuf, tid);
+            lds_barrier();
+            uchar4 *rgba = reinterpret_cast<uchar4 *>(p.rgba);
+            uchar4 *dst_a = rgba + ((size_t)(have_first ? f0 : 0) * p.pairs + p.pair) * (size_t)p.R;
+            uchar4 *dst_b = rgba + ((size_t)f1 * p.pairs + p.pair) * (size_t)p.R;
+            row_pass<MONO>(p, vbuf, dst_a, dst_b, have_first, have_second, thr, lut, tid);
         }
     }
 }
@@ -305,6 +302,7 @@ hipError_t launch_wgp(const sgx_ctx *c, const void *tables, const float *d_pcm, 
         if (RENDER) {
             p.rows = t->d_rows;
             p.samples = t->d_samples;
+            p.n_samples = t->n_samples;
             p.lut_thr = c->d_lut_thr;
             p.lut_rgba = c->d_lut_rgba;
             p.rgba = d_rgba;
