@@ -214,7 +214,8 @@ typedef struct sgx_live sgx_live;
                                       audio_transform.rs:37-41 does (it drops up to H samples per tick);
                                       default: frames are t*H exact */
 
-/* capacity_pairs: ring size in (l, r) pairs (the reference: 4096); must hold at least one window */
+/* capacity_pairs: ring size in (l, r) pairs (the reference: 4096); must hold at least one window.
+ * A ring belongs to its context: destroy it before sgx_destroy(ctx). */
 SGX_API int sgx_live_create(sgx_ctx *ctx, size_t capacity_pairs, uint32_t flags, sgx_live **out);
 SGX_API void sgx_live_destroy(sgx_live *live);
 /* The cpal callback (audio_input_list_model.rs:63-75): h_samples holds n_values floats, interleaved by

@@ -239,7 +239,7 @@ void sgx_destroy(sgx_ctx *c)
     sgx::wg16384_destroy(c->d_fast_16k);
     c->d_fast_16k = nullptr;
     void *ptrs[] = {c->d_window, c->d_twiddle, c->d_rows, c->d_samples, c->d_lut_thr, c->d_alpha_thr,
-                    c->d_lut_rgba, c->d_t_thr, c->d_band_rows, c->d_band_samples, c->d_ws_mags, c->d_one_in, c->d_one_out, c->d_cksum};
+                    c->d_lut_rgba, c->d_t_thr, c->d_band_rows, c->d_band_samples, c->d_levels, c->d_ws_mags, c->d_one_in, c->d_one_out, c->d_cksum};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete c;

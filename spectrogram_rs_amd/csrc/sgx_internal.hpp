@@ -100,6 +100,8 @@ struct sgx_ctx {
     std::vector<float> bands_key;
     sgx::RowEntry *d_band_rows = nullptr;
     sgx::SampleEntry *d_band_samples = nullptr;
+    float *d_levels = nullptr;  // sgx_spectrum_levels: the bands' (l, r) means, grown on demand
+    uint32_t levels_cap = 0;
 
     std::string err;
 };

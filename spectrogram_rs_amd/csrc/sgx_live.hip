@@ -226,24 +226,25 @@ int sgx_spectrum_levels(sgx_ctx *c, const float *d_column, uint32_t n_bars, doub
         prev = next;
     }
     hipError_t e = hipSetDevice(c->device);
-    float *d_bands = nullptr;
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_bands), (size_t)n_bars * 2 * sizeof(float));
+    if (e == hipSuccess && n_bars > c->levels_cap) {
+        e = hipStreamSynchronize(c->stream);
+        if (c->d_levels) { (void)hipFree(c->d_levels); c->d_levels = nullptr; c->levels_cap = 0; }
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->d_levels), (size_t)n_bars * 2 * sizeof(float));
+        if (e == hipSuccess) c->levels_cap = n_bars;
+    }
     if (e != hipSuccess) {
         c->err = std::string("sgx_spectrum_levels: ") + hipGetErrorString(e);
         return SGX_ERR_HIP;
     }
-    int rc = sgx_magnitude_in(c, d_column, 1, ranges.data(), n_bars, d_bands);
-    std::vector<float> lr((size_t)n_bars * 2);
-    if (rc == SGX_OK) {
-        e = hipMemcpyAsync(lr.data(), d_bands, lr.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        if (e != hipSuccess) {
-            c->err = std::string("sgx_spectrum_levels: ") + hipGetErrorString(e);
-            rc = SGX_ERR_HIP;
-        }
-    }
-    (void)hipFree(d_bands);
+    int rc = sgx_magnitude_in(c, d_column, 1, ranges.data(), n_bars, c->d_levels);
     if (rc != SGX_OK) return rc;
+    std::vector<float> lr((size_t)n_bars * 2);
+    e = hipMemcpyAsync(lr.data(), c->d_levels, lr.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) {
+        c->err = std::string("sgx_spectrum_levels: ") + hipGetErrorString(e);
+        return SGX_ERR_HIP;
+    }
     const float min_db = -70.0f, max_db = -10.0f;  // locals of push_frequencies (:47-48), not the colour scheme's
     for (uint32_t i = 0; i < n_bars; ++i) {
         float m = hypotf(lr[2 * i], lr[2 * i + 1]);          // c32::new(l, r).norm()   :60
