@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=1_000_000, help="frames per GPU per step (config 2: 1e6)")
     ap.add_argument("--pixel-frames", type=int, default=262_144, help="frames per GPU for the pixel-path leg (0 = skip)")
+    ap.add_argument("--pixel-timeout", type=float, default=300.0, help="seconds after which a stalled pixel-path leg is given up")
     ap.add_argument("--cpu-frames", type=int, default=262_144, help="frames of the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--generic", action="store_true", help="force the generic power-of-two kernel")
     return ap.parse_args()
@@ -132,9 +133,47 @@ def main():
     elapsed, kernel_ms = float(t[0]), float(t[1])
     checksum = eng.checksum(mags[:4096])
 
-    # ---- pixel path leg (config 3 / config 5 shape), not the headline value -----------------------
-    pixel = None
-    if args.pixel_frames > 0:
+    def build_line(pixel, cpu):
+        total_frames = world * F * args.steps
+        value = total_frames / elapsed
+        achieved = F * ALGO_BYTES_STFT / (kernel_ms * 1e-3) / 1e9
+        traffic = load_traffic()
+        line = {
+            "metric": "STFT frames/sec (4096-pt, hop 256)",
+            "value": value,
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"configs[1]: batched 4096-pt Hann STFT, hop 256, {F} frames/GPU of counter-based white-noise mono PCM resident in HBM",
+                "window": W, "fft_length": 2 * W, "hop": H, "channels": 1, "frames_per_gpu": F,
+                "kernel": KERNEL_NAMES[eng.info.stft_kernel][0],
+                "sharding": "contiguous frame ranges per rank, no data-path collective" if world > 1 else "single GPU",
+            },
+            "achieved_GBps_algorithmic": value * ALGO_BYTES_STFT / 1e9,
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": ((traffic or {}).get("stft_bytes_per_frame") or 0) * F or None,
+                "kernel": KERNEL_NAMES[eng.info.stft_kernel][1],
+                "launch_ms": kernel_ms, "bytes_per_frame": ALGO_BYTES_STFT, "frames_per_launch": F,
+            },
+            "cpu_baseline": cpu,
+            "pixel_path": pixel,
+            "checksum_first_4096_frames": checksum,
+        }
+        return line
+
+    def pixel_leg():
+        if args.pixel_frames <= 0:
+            return None
         Fp = min(args.pixel_frames, F)
         chunk = min(65_536, Fp)
         rgba = torch.empty((Fp, 1, R, 4), dtype=torch.uint8, device=eng.device)
@@ -178,7 +217,33 @@ def main():
             "algorithmic_GBps": fps * ALGO_BYTES_PIXEL / 1e9,
             "gathered": world > 1,
         }
+        return pixel
 
+    # ---- pixel path leg (config 3 / config 5 shape), not the headline value -----------------------
+    # The headline number above is already final.  The leg below contains the one collective exchange of the
+    # path; if it fails or stalls on some rank (a collective cannot be interrupted from Python), a watchdog
+    # still prints the JSON line -- with the failure recorded in "pixel_path" -- and ends the process.
+    pixel = None
+    import threading
+
+    def on_stall():
+        if rank == 0:
+            print(json.dumps(build_line({"error": f"pixel-path leg did not finish within {args.pixel_timeout} s"}, None)), flush=True)
+        os._exit(0)
+
+    watchdog = threading.Timer(args.pixel_timeout, on_stall)
+    watchdog.daemon = True
+    if args.pixel_frames > 0:
+        watchdog.start()
+    try:
+        pixel = pixel_leg()
+    except Exception as e:  # noqa: BLE001 -- reported in the line, the headline stands
+        pixel = {"error": f"{type(e).__name__}: {e}"}
+        if world > 1:      # the other ranks may be waiting in the exchange: nothing collective from here on
+            if rank == 0:
+                print(json.dumps(build_line(pixel, None)), flush=True)
+            os._exit(0)
+    watchdog.cancel()
     # ---- CPU baseline: the oracle on this host's cores (rank 0, N = 1 only) ------------------------
     cpu = None
     if rank == 0 and world == 1 and args.cpu_frames > 0:
@@ -213,42 +278,7 @@ def main():
         }
 
     if rank == 0:
-        total_frames = world * F * args.steps
-        value = total_frames / elapsed
-        achieved = F * ALGO_BYTES_STFT / (kernel_ms * 1e-3) / 1e9
-        traffic = load_traffic()
-        line = {
-            "metric": "STFT frames/sec (4096-pt, hop 256)",
-            "value": value,
-            "unit": "frames/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic",
-            "config": {
-                "workload": f"configs[1]: batched 4096-pt Hann STFT, hop 256, {F} frames/GPU of counter-based white-noise mono PCM resident in HBM",
-                "window": W, "fft_length": 2 * W, "hop": H, "channels": 1, "frames_per_gpu": F,
-                "kernel": KERNEL_NAMES[eng.info.stft_kernel][0],
-                "sharding": "contiguous frame ranges per rank, no data-path collective" if world > 1 else "single GPU",
-            },
-            "achieved_GBps_algorithmic": value * ALGO_BYTES_STFT / 1e9,
-            "roofline": {
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": ((traffic or {}).get("stft_bytes_per_frame") or 0) * F or None,
-                "kernel": KERNEL_NAMES[eng.info.stft_kernel][1],
-                "launch_ms": kernel_ms, "bytes_per_frame": ALGO_BYTES_STFT, "frames_per_launch": F,
-            },
-            "cpu_baseline": cpu,
-            "pixel_path": pixel,
-            "checksum_first_4096_frames": checksum,
-        }
-        print(json.dumps(line), flush=True)
+        print(json.dumps(build_line(pixel, cpu)), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
