@@ -158,6 +158,43 @@ __device__ __forceinline__ uint32_t count_reached(const float *thr, uint32_t n, 
     return lo;
 }
 
+// ColorScheme::color_for((l, r)) (colorscheme.rs:55-71) as threshold counts; `thr` / `athr` are the LDS copies
+__device__ __forceinline__ uchar4 color_for(const RenderParams &p, const float *thr, const float *athr, float l, float r)
+{
+    // colorscheme.rs:59: norm_sqr = l*l + r*r, then the dB ramp as a threshold count
+    const float power = (l * l) + (r * r);
+    uchar4 px;
+    if (p.stereo) {
+        // :63-66
+        const float l1 = fabsf(l) + fabsf(r);
+        const double t = (double)l / (double)l1;
+        if (p.segments) {
+            if (t != t) {
+                px = p.nan_rgba;
+            } else {
+                uint32_t lo = 0, hi = p.n_lut - 1;  // number of switch points <= t
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (t >= p.t_thr[mid]) lo = mid + 1;
+                    else hi = mid;
+                }
+                px = p.lut_rgba[lo];
+            }
+        } else {
+            double x = (p.lut_mode == SGX_LUT_ROUND_NM1) ? floor(t * (double)(p.n_lut - 1) + 0.5) : floor(t * (double)p.n_lut);
+            uint32_t idx = 0;
+            if (x > 0.0) idx = x >= (double)p.n_lut ? p.n_lut - 1 : (uint32_t)x;
+            px = p.lut_rgba[idx];
+        }
+        px.w = (unsigned char)count_reached(athr, 255, power);  // (alpha * 255.0) as u8, simple_spectrogram.rs:159
+    } else {
+        // :67-70; alpha = 1.0 -> 255
+        px = (p.segments && power != power) ? p.nan_rgba : p.lut_rgba[count_reached(thr, p.n_lut - 1, power)];
+        px.w = 255;
+    }
+    return px;
+}
+
 // Replaces the body of `for py in 0..buffer.height()` (simple_spectrogram.rs:141-161).
 __global__ void __launch_bounds__(256) render_kernel(RenderParams p)
 {
@@ -212,38 +249,92 @@ __global__ void __launch_bounds__(256) render_kernel(RenderParams p)
         }
         const float l = sl / row.count_f, r = sr / row.count_f;  // :72
 
-        // colorscheme.rs:59: norm_sqr = l*l + r*r, then the dB ramp as a threshold count
-        const float power = (l * l) + (r * r);
-        uchar4 px;
-        if (p.stereo) {
-            // :63-66
-            const float l1 = fabsf(l) + fabsf(r);
-            const double t = (double)l / (double)l1;
-            if (p.segments) {
-                if (t != t) {
-                    px = p.nan_rgba;
-                } else {
-                    uint32_t lo = 0, hi = p.n_lut - 1;  // number of switch points <= t
-                    while (lo < hi) {
-                        const uint32_t mid = (lo + hi) >> 1;
-                        if (t >= p.t_thr[mid]) lo = mid + 1;
-                        else hi = mid;
-                    }
-                    px = p.lut_rgba[lo];
-                }
-            } else {
-                double x = (p.lut_mode == SGX_LUT_ROUND_NM1) ? floor(t * (double)(p.n_lut - 1) + 0.5) : floor(t * (double)p.n_lut);
-                uint32_t idx = 0;
-                if (x > 0.0) idx = x >= (double)p.n_lut ? p.n_lut - 1 : (uint32_t)x;
-                px = p.lut_rgba[idx];
-            }
-            px.w = (unsigned char)count_reached(athr, 255, power);  // (alpha * 255.0) as u8, simple_spectrogram.rs:159
-        } else {
-            // :67-70; alpha = 1.0 -> 255
-            px = (p.segments && power != power) ? p.nan_rgba : p.lut_rgba[count_reached(thr, p.n_lut - 1, power)];
-            px.w = 255;
-        }
+        const uchar4 px = color_for(p, thr, athr, l, r);
         dst[p.R - 1 - py] = px;  // simple_spectrogram.rs:150
+    }
+}
+
+// The same column in two balanced passes over LDS (see stft4096_wg.hpp: one thread per magnitude_in SAMPLE,
+// then one thread per row), by persistent workgroups that keep the threshold tables in LDS and request the
+// next column's magnitudes while the current one is rendered.  Used whenever the column, its interpolated
+// samples and the tables fit in LDS; render_kernel above is the general fallback.
+__global__ void __launch_bounds__(256) render_two_pass_kernel(RenderParams p, unsigned long long n_columns, uint32_t n_samples)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2 *m = reinterpret_cast<float2 *>(smem_raw);                 // [M]
+    float2 *vbuf = m + p.M + 1;                                       // [n_samples]
+    float *thr = reinterpret_cast<float *>(vbuf + n_samples);         // [n_lut - 1]
+    float *athr = thr + p.n_lut;                                      // [255]
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t i = tid; i + 1 < p.n_lut; i += 256) thr[i] = p.lut_thr[i];
+    for (uint32_t i = tid; i < 255; i += 256) athr[i] = p.alpha_thr[i];
+
+    constexpr int kPre = 8;  // bins per thread held in registers for the next column (M <= 2048 here)
+    const int32_t last = (int32_t)p.M - 1;
+    float2 nxt[kPre];
+    auto request = [&](unsigned long long col) {
+        const float2 *src = reinterpret_cast<const float2 *>(p.mags) + col * p.M;
+#pragma unroll
+        for (int j = 0; j < kPre; ++j) {
+            const uint32_t i = tid + 256u * j;
+            nxt[j] = i < p.M ? src[i] : make_float2(0.0f, 0.0f);
+        }
+    };
+    unsigned long long col = blockIdx.x;
+    if (col < n_columns) request(col);
+    for (; col < n_columns; col += gridDim.x) {
+        __syncthreads();  // the previous column's row pass is done with m / vbuf
+#pragma unroll
+        for (int j = 0; j < kPre; ++j) {
+            const uint32_t i = tid + 256u * j;
+            if (i < p.M) m[i] = nxt[j];
+        }
+        if (col + gridDim.x < n_columns) request(col + gridDim.x);
+        __syncthreads();
+        // ---- sample pass (interpolated_frequency_sample.rs:79-105)
+        for (uint32_t sidx = tid; sidx < n_samples; sidx += 256) {
+            const SampleEntry se = p.samples[sidx];
+            float2 v;
+            if (p.interp == SGX_INTERP_COSINE) {
+                const float2 a = m[se.i0], b = m[se.i1];
+                v.x = a.x * se.w1 + b.x * se.w2;
+                v.y = a.y * se.w1 + b.y * se.w2;
+            } else {
+                const int32_t x1 = se.i0;
+                const int32_t x0 = x1 > 0 ? x1 - 1 : 0;
+                const int32_t x2 = x1 + 1 < last ? x1 + 1 : last;
+                const int32_t x3 = x1 + 2 < last ? x1 + 2 : last;
+                const float2 y0 = m[x0], y1 = m[x1], y2 = m[x2], y3 = m[x3];
+                const float mu = se.w0, mu2 = se.w1, mu3 = se.w2;
+                {
+                    const float a0 = ((y3.x - y2.x) - y0.x) + y1.x;
+                    const float a1 = (y0.x - y1.x) - a0;
+                    const float a2 = y2.x - y0.x;
+                    v.x = ((a0 * mu3) + (a1 * mu2)) + ((a2 * mu) + y1.x);
+                }
+                {
+                    const float a0 = ((y3.y - y2.y) - y0.y) + y1.y;
+                    const float a1 = (y0.y - y1.y) - a0;
+                    const float a2 = y2.y - y0.y;
+                    v.y = ((a0 * mu3) + (a1 * mu2)) + ((a2 * mu) + y1.y);
+                }
+            }
+            vbuf[sidx] = v;
+        }
+        __syncthreads();
+        // ---- row pass (:60-75 the mean; colorscheme.rs:55-71; simple_spectrogram.rs:150-160)
+        uchar4 *dst = reinterpret_cast<uchar4 *>(p.rgba) + col * p.R;
+        for (uint32_t py = tid; py < p.R; py += 256) {
+            const RowEntry row = p.rows[py];
+            float sl = 0.0f, sr = 0.0f;  // Complex::sum starts at zero
+            for (uint32_t i = 0; i < row.count; ++i) {
+                const float2 v = vbuf[row.first + i];
+                sl = sl + v.x;
+                sr = sr + v.y;
+            }
+            const float l = sl / row.count_f, r = sr / row.count_f;  // :72
+            dst[p.R - 1 - py] = color_for(p, thr, athr, l, r);
+        }
     }
 }
 
@@ -267,6 +358,19 @@ hipError_t launch_render(const sgx_ctx *c, const float *d_mags, size_t n_columns
     p.t_thr = c->d_t_thr;
     p.segments = c->pal.segments ? 1u : 0u;
     p.nan_rgba = make_uchar4(c->pal.nan_rgb[0], c->pal.nan_rgb[1], c->pal.nan_rgb[2], 255);
+    const size_t n_samples = c->tab.samples.size();
+    const size_t lds2 = (size_t)(c->M + 1 + n_samples) * sizeof(float2) + (size_t)(c->pal.n + 255) * sizeof(float);
+    if (c->M <= 2048 && lds2 <= 64 * 1024) {
+        // persistent two-pass form: workgroups sized to the LDS image, each walks columns blockIdx.x, + grid, ...
+        int n_cu = 256;
+        (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device);
+        const size_t per_cu = (160 * 1024) / lds2 < 8 ? (160 * 1024) / lds2 : 8;
+        size_t blocks = (size_t)n_cu * (per_cu ? per_cu : 1);
+        if (blocks > n_columns) blocks = n_columns;
+        hipLaunchKernelGGL(render_two_pass_kernel, dim3((unsigned)blocks), dim3(256), lds2, c->stream, p,
+                           (unsigned long long)n_columns, (uint32_t)n_samples);
+        return hipGetLastError();
+    }
     const size_t lds = (size_t)(c->M + 1) * sizeof(float2) + (size_t)(c->pal.n + 255) * sizeof(float);
     if (lds > 64 * 1024) {  // per launch: the attribute is per device, and a process may hold contexts on several
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(render_kernel),

@@ -296,6 +296,24 @@ def test_render_stage_is_bit_exact_given_identical_magnitudes(torch_cuda, gradie
     assert len(np.unique(ref[..., :3].reshape(-1, 3), axis=0)) > 200
 
 
+@pytest.mark.parametrize("Wt,cols", [(2048, 700), (4096, 9), (512, 300)])
+def test_render_stage_kernels_agree_with_the_oracle(torch_cuda, gradients, Wt, cols):
+    # the standalone pixel stage has two kernels: the persistent two-pass one (column, samples and tables fit in
+    # LDS; W <= 2048) and the general one (here W = 4096).  `cols` > workgroups in flight makes the persistent
+    # workgroups walk several columns each.
+    torch = torch_cuda
+    eng = engine(window_samples=Wt, hop_samples=64, channels=2, gradient="magma")
+    rng = np.random.default_rng(Wt)
+    mags = (np.abs(rng.standard_normal((cols, Wt - 1, 2))) * np.logspace(-5, 0, cols)[:, None, None]).astype(np.float32)
+    got = eng.render_mags(to_dev(torch, mags)).cpu().numpy()
+    pick = np.unique(np.linspace(0, cols - 1, 12).astype(int))
+    ref = oracle.render_columns(mags[pick], SR, gradients["magma"])
+    assert got.shape == (cols, R, 4) and np.array_equal(got[pick], ref)
+    # every column, against the same kernel run column by column (persistence must not leak state)
+    one = np.stack([eng.render_mags(to_dev(torch, mags[i:i + 1])).cpu().numpy()[0] for i in (0, cols // 2, cols - 1)])
+    assert np.array_equal(one, got[[0, cols // 2, cols - 1]])
+
+
 def test_render_golden_columns(torch_cuda, gold):
     torch = torch_cuda
     g = gold("rgba_columns.npz")
