@@ -292,8 +292,12 @@ __global__ void __launch_bounds__(256) render_two_pass_kernel(RenderParams p, un
         if (col + gridDim.x < n_columns) request(col + gridDim.x);
         __syncthreads();
         // ---- sample pass (interpolated_frequency_sample.rs:79-105)
-        for (uint32_t sidx = tid; sidx < n_samples; sidx += 256) {
-            const SampleEntry se = p.samples[sidx];
+        uint32_t sidx = tid;
+        SampleEntry se_cur = p.samples[sidx < n_samples ? sidx : 0];
+        while (sidx < n_samples) {
+            // the next step's table entry is requested before this step's gathers (one L1 latency overlapped)
+            const SampleEntry se = se_cur;
+            se_cur = p.samples[sidx + 256 < n_samples ? sidx + 256 : 0];
             float2 v;
             if (p.interp == SGX_INTERP_COSINE) {
                 const float2 a = m[se.i0], b = m[se.i1];
@@ -320,6 +324,7 @@ __global__ void __launch_bounds__(256) render_two_pass_kernel(RenderParams p, un
                 }
             }
             vbuf[sidx] = v;
+            sidx += 256;
         }
         __syncthreads();
         // ---- row pass (:60-75 the mean; colorscheme.rs:55-71; simple_spectrogram.rs:150-160)

@@ -62,9 +62,13 @@ __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
 
     const int tid = threadIdx.x;
     tw2[tid] = p.tw2[tid];
+    uint32_t row_words[4] = {0u, 0u, 0u, 0u};  // RENDER: the table words of this thread's rows tid + 256 i
     if (RENDER) {
         thr[tid] = tid < 255 ? p.lut_thr[tid] : __builtin_nanf("");
         lut[tid] = p.lut_rgba[tid];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if ((uint32_t)tid + 256u * i < p.R) row_words[i] = p.rows[tid + 256 * i];
     }
 
     // per-thread constants, kept in registers for the life of the (persistent) workgroup
@@ -315,7 +319,7 @@ __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
             uchar4 *rgba = reinterpret_cast<uchar4 *>(p.rgba);
             uchar4 *dst_a = rgba + ((size_t)(have_first ? f0 : 0) * p.pairs + p.pair) * (size_t)p.R;
             uchar4 *dst_b = rgba + ((size_t)f1 * p.pairs + p.pair) * (size_t)p.R;
-            row_pass<MONO>(p, vbuf, dst_a, dst_b, have_first, have_second, thr, lut, tid);
+            row_pass<MONO>(p, row_words, vbuf, dst_a, dst_b, have_first, have_second, thr, lut, tid);
         }
     }
 }
@@ -347,7 +351,7 @@ hipError_t wg4096_init(sgx_ctx *c, void **out)
     std::vector<uint32_t> rows(c->tab.rows.size());
     std::vector<PackedSample> samples(c->tab.samples.size());
     // the interpolated samples of a column sit in LDS behind the column itself
-    bool fusable = c->tab.samples.size() <= (size_t)kMaxFusedSamples;
+    bool fusable = c->tab.samples.size() <= (size_t)kMaxFusedSamples && c->tab.rows.size() <= 1024;
     const int32_t last = (int32_t)c->M - 1;
     for (size_t i = 0; i < rows.size(); ++i) {
         const auto &r = c->tab.rows[i];

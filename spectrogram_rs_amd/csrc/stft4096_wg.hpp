@@ -158,10 +158,17 @@ template <bool COSINE>
 __device__ __forceinline__ void sample_pass(const Params &p, const float2 *m2, float2 *vbuf, int tid)
 {
     const int last = kM - 1;
-    for (uint32_t s = tid; s < p.n_samples; s += 256) {
-        const PackedSample se = p.samples[s];
+    // the table word of the next step is requested before this step's gathers: one L1 latency per step is
+    // overlapped instead of exposed (two registers; deeper unrolling costs more registers than these kernels have)
+    uint32_t s = tid;
+    PackedSample se = p.samples[s < p.n_samples ? s : 0];
+    while (s < p.n_samples) {
+        const uint32_t s_next = s + 256;
+        const PackedSample se_next = p.samples[s_next < p.n_samples ? s_next : 0];
         vbuf[s] = se.i0 >= 0 ? interp_sample2<COSINE, true>(m2, se.i0, se.w, last)
                              : interp_sample2<COSINE, false>(m2, ~se.i0, se.w, last);
+        se = se_next;
+        s = s_next;
     }
 }
 
@@ -181,11 +188,13 @@ __device__ __forceinline__ uchar4 pixel_for(const Params &p, float l, float r, c
 // loops unrolled (9 samples, 4 rows side by side, thresholds read four at a time): 182 -> 131 M frames/s -- these
 // kernels sit at the 128-VGPR cap of four waves per SIMD and every extra live value becomes scratch traffic.)
 template <bool MONO>
-__device__ __forceinline__ void row_pass(const Params &p, const float2 *vbuf, uchar4 *dst_a, uchar4 *dst_b, bool have_a, bool have_b,
-                                         const float *thr, const uchar4 *lut, int tid)
+__device__ __forceinline__ void row_pass(const Params &p, const uint32_t (&row_words)[4], const float2 *vbuf, uchar4 *dst_a, uchar4 *dst_b,
+                                         bool have_a, bool have_b, const float *thr, const uchar4 *lut, int tid)
 {
-    for (uint32_t py = tid; py < p.R; py += 256) {
-        const uint32_t re = p.rows[py];
+    int i_row = 0;
+    for (uint32_t py = tid; py < p.R; py += 256, ++i_row) {
+        // a thread renders the same rows (tid + 256 i) of every column: their table words stay in registers (R <= 1024)
+        const uint32_t re = i_row == 0 ? row_words[0] : i_row == 1 ? row_words[1] : i_row == 2 ? row_words[2] : row_words[3];
         const uint32_t first = re & 0xffffu, cnt = re >> 16;
         float sl = 0.0f, sr = 0.0f;  // Complex::sum starts at zero
         for (uint32_t i = 0; i < cnt; ++i) {
