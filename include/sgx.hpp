@@ -6,6 +6,7 @@
 //   fourier::FastFourierTransform      src/fourier/fft.rs:11-99
 //   fourier::AudioStreamTransform<T>   src/fourier/audio_transform.rs:14-43    (hop loop over a ring)
 //   RingBuffer                         ringbuf::HeapRb<(f32, f32)> as used at src/devices/audio_input_list_model.rs:30,63-72
+//   LiveRing                           the same ring, consumed side on the device (sgx_live_*)
 //
 // Host buffers in, host buffers out (the per-frame `process` of the trait works on host pairs); the
 // batched `process` of AudioStreamTransform moves every complete frame of the ring through ONE
@@ -165,6 +166,49 @@ public:
 private:
     std::size_t capacity_;
     std::deque<StereoMagnitude> data_;
+};
+
+// The same ring with its consumed side resident on the device (sgx_live_*): the capture callback pushes
+// host samples (audio_input_list_model.rs:63-75), one tick() per GUI frame returns every complete frame
+// (audio_transform.rs:34-42) and moves only the new samples to the GPU.
+class LiveRing {
+public:
+    // reference_skip: also drop H samples on the terminating short read, exactly as audio_transform.rs:37-41
+    LiveRing(FastFourierTransform &transform, std::size_t capacity = 4096, bool reference_skip = false)
+        : transform_(transform)
+    {
+        const int rc = sgx_live_create(transform.ctx(), capacity, reference_skip ? SGX_LIVE_REFERENCE_SKIP : 0u, &live_);
+        if (rc != SGX_OK) throw Error(rc, sgx_last_error(transform.ctx()));
+    }
+    LiveRing(const LiveRing &) = delete;
+    LiveRing &operator=(const LiveRing &) = delete;
+    ~LiveRing() { sgx_live_destroy(live_); }
+
+    // interleaved samples of a 1- or 2-channel callback; returns the pairs accepted (overflow is dropped)
+    std::size_t push(const float *data, std::size_t n_values, unsigned channels)
+    {
+        const long long rc = sgx_live_push(live_, data, n_values, channels);
+        if (rc < 0) throw Error((int)rc, std::to_string(channels) + "-channel input not supported!");
+        return (std::size_t)rc;
+    }
+    std::size_t occupied_len() const { return sgx_live_occupied(live_); }
+
+    std::vector<AudioTransform::Output> tick(std::size_t max_frames = 64)
+    {
+        const std::size_t m = transform_.num_output_frequencies();
+        std::vector<float> flat(max_frames * m * 2);
+        std::size_t got = 0;
+        const int rc = sgx_live_tick(live_, SGX_LIVE_MAGS, flat.data(), max_frames, &got);
+        if (rc != SGX_OK) throw Error(rc, sgx_last_error(transform_.ctx()));
+        std::vector<AudioTransform::Output> out(got, AudioTransform::Output(m));
+        for (std::size_t f = 0; f < got; ++f)
+            for (std::size_t j = 0; j < m; ++j) out[f][j] = {flat[(f * m + j) * 2], flat[(f * m + j) * 2 + 1]};
+        return out;
+    }
+
+private:
+    FastFourierTransform &transform_;
+    sgx_live *live_ = nullptr;
 };
 
 // audio_transform.rs:14-43; the three members are public and assignable, as in the reference

@@ -36,6 +36,21 @@ int main(int argc, char **argv)
         auto one = fft.process(lr.data(), n);
         if (!one || *one != frames.at(0)) { fprintf(stderr, "process() != batched frame 0\n"); return 4; }
         if (fft.process(lr.data(), fft.num_input_samples() - 1)) { fprintf(stderr, "short input must be None\n"); return 5; }
+        // the device-resident ring: the same samples pushed in callback-sized pieces with a tick after each must
+        // yield the same frames, in order (t * H framing across ticks)
+        {
+            LiveRing live(fft, 1 << 16);
+            std::vector<AudioTransform::Output> got;
+            for (size_t i = 0; i < n; i += 480) {
+                const size_t m = n - i < 480 ? n - i : 480;
+                if (live.push(reinterpret_cast<const float *>(lr.data() + i), 2 * m, 2) != m) return 6;
+                for (auto &fr : live.tick()) got.push_back(std::move(fr));
+            }
+            if (got != frames) { fprintf(stderr, "LiveRing frames != batched frames (%zu vs %zu)\n", got.size(), frames.size()); return 7; }
+            bool refused = false;
+            try { live.push(reinterpret_cast<const float *>(lr.data()), 6, 3); } catch (const Error &) { refused = true; }
+            if (!refused) return 8;
+        }
         FILE *f = fopen(argv[1], "wb");
         const uint64_t hdr[4] = {frames.size(), fft.num_output_frequencies(), stream.stride_samples(), ring.occupied_len()};
         fwrite(hdr, sizeof(hdr), 1, f);
