@@ -1,0 +1,73 @@
+"""Seeded sweep over the configuration space: random window / hop / channel count / stream length / axis / dB range
+/ interpolation / LUT rule, every draw checked against the CPU oracle (magnitudes within the stated tolerance,
+pixel bytes bit-exact on identical magnitudes) and against the library's own invariants (one-kernel == two-kernel
+pixel path, any sub-range == the same frames of the full run).  Run with -m gpu on an MI355X."""
+import numpy as np
+import pytest
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def draw(rng):
+    kind = rng.choice(["pow2", "pow2", "odd"])
+    if kind == "pow2":
+        W = int(2 ** rng.integers(2, 13))               # 4 .. 4096 (2W = the power-of-two kernels)
+    else:
+        W = int(rng.integers(5, 5400))                  # chirp-z kernel: any length with 3W - 1 <= 16384
+        if W & (W - 1) == 0:
+            W += 1
+    H = int(rng.integers(1, max(2, W + W // 2)))        # hops above W (gaps between frames) included
+    channels = int(rng.choice([1, 2, 2, 4]))
+    frames = int(rng.integers(0, 40))
+    n = 0 if frames == 0 else (frames - 1) * H + W + int(rng.integers(0, H))   # ragged tail
+    if rng.random() < 0.1:
+        n = int(rng.integers(0, W))                     # shorter than one window
+    sr = int(rng.choice([8000, 22050, 44100, 48000, 96000]))
+    f_lo = float(rng.uniform(1.0, 200.0))
+    f_hi = float(rng.uniform(f_lo * 2, sr * rng.uniform(0.3, 0.7)))
+    lo_db = float(rng.uniform(-120.0, -40.0))
+    return dict(W=W, H=H, channels=channels, n=n, sr=sr, rows=int(rng.integers(1, 1400)), f_min=f_lo, f_max=f_hi,
+                min_db=lo_db, max_db=float(lo_db + rng.uniform(10.0, 90.0)), interp=int(rng.integers(0, 2)),
+                lut=int(rng.integers(0, 2)), amp=float(10.0 ** rng.uniform(-4, 0.3)), grad=str(rng.choice(["viridis", "magma", "inferno", "plasma"])),
+                diverging=bool(rng.random() < 0.3))
+
+
+@pytest.mark.parametrize("seed", range(160))
+def test_random_configuration(seed, mags_err, gradients):
+    import torch
+    from spectrogram_rs_amd import SpectrogramEngine
+    rng = np.random.default_rng(1000 + seed)
+    c = draw(rng)
+    W, H, ch, n = c["W"], c["H"], c["channels"], c["n"]
+    kw = dict(window_samples=W, hop_samples=H, channels=ch, rows=c["rows"], f_min=c["f_min"], f_max=c["f_max"],
+              min_db=c["min_db"], max_db=c["max_db"], interp=c["interp"], lut_index_mode=c["lut"], gradient=c["grad"])
+    eng = SpectrogramEngine(float(c["sr"]), **kw)
+    if c["diverging"]:   # colour from the left / right balance, alpha from the level (colorscheme.rs:63-66)
+        eng.set_gradient(gradients[c["grad"]], stereo=True)
+    pcm = (oracle.white_noise(n * ch, seed=seed) * np.float32(c["amp"])).astype(np.float32)
+    dev = torch.from_numpy(pcm).cuda()
+    total = oracle.num_frames(n, W, H)
+    assert eng.num_frames(n) == total
+    got = eng.stft_batch(dev).cpu().numpy()
+    ref = oracle.stream_process(pcm, ch, W, H, threads=8)
+    assert got.shape == ref.shape == (total, max(ch // 2, 1), W - 1, 2)
+    if total == 0:
+        assert eng.render_batch(dev).shape[0] == 0
+        return
+    # float32 against float32: each within the tolerance of the exact transform (three roundings more for chirp-z)
+    assert mags_err(got, ref) <= (3.0 if eng.info.stft_kernel == 4 else 2.0), c
+    # any sub-range writes the bytes of the full run
+    first = int(rng.integers(0, total))
+    count = int(rng.integers(1, total - first + 1))
+    assert np.array_equal(eng.stft_batch(dev, first_frame=first, max_frames=count).cpu().numpy(), got[first:first + count]), c
+    # pixels: bit-exact against the oracle on the engine's own magnitudes; PCM -> pixels in one call gives the same bytes
+    if W >= 8:
+        cols = eng.render_mags(torch.from_numpy(got).cuda().reshape(-1)).cpu().numpy()
+        pick = np.unique(rng.integers(0, cols.shape[0], 4))
+        want = oracle.render_columns(got.reshape(-1, W - 1, 2)[pick], c["sr"], gradients[c["grad"]], R=c["rows"], f_min=c["f_min"],
+                                     f_max=c["f_max"], interp=c["interp"], min_db=c["min_db"], max_db=c["max_db"], mode=c["lut"],
+                                     stereo=c["diverging"])
+        assert np.array_equal(cols[pick], want), c
+        assert np.array_equal(eng.render_batch(dev).cpu().numpy().reshape(cols.shape), cols), c
