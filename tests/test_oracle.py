@@ -288,3 +288,21 @@ def test_spectrum_analyzer_bands_and_levels():
     assert np.allclose(levels, want * 0.99, atol=2e-6)
     # below 44.1 kHz the last edge stays at 22050 Hz (.max(22050.0), :54)
     assert oracle.log_space(32.0, max(8000 / 2, 22050.0), 129, 10.0, 129) == pytest.approx(22050.0, rel=1e-5)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_oracle_fft_on_random_lengths_against_numpy(seed, mags_err):
+    # the oracle's own mixed-radix FFT (it has to serve the application's 4800-point transform as well as the
+    # power-of-two configs) against numpy's float64 FFT of the same windowed, padded frame, for lengths with small and
+    # large prime factors alike
+    rng = np.random.default_rng(seed)
+    Wt = int(rng.choice([int(rng.integers(2, 300)), int(rng.integers(300, 6000)), int(2 ** rng.integers(1, 13)),
+                         int(2 ** rng.integers(0, 6) * 3 ** rng.integers(0, 4) * 5 ** rng.integers(0, 3))]))
+    Wt = max(Wt, 2)
+    x = (oracle.white_noise(2 * Wt, seed) * np.float32(10.0 ** rng.uniform(-3, 0))).reshape(-1, 2)
+    truth = oracle.np_truth_frame(x, Wt)
+    assert truth.shape == (Wt - 1, 2)
+    if Wt > 2:
+        assert np.abs(oracle.fft_process(x, Wt, oracle.F64) - truth).max() <= 1e-11 * np.abs(truth).max()
+        assert mags_err(oracle.fft_process(x, Wt, oracle.F32), truth) <= 1.0
+    assert oracle.fft_process(x[:Wt - 1], Wt) is None                     # fft.rs:72
