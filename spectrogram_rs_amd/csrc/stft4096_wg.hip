@@ -139,18 +139,12 @@ __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
         } else {
             const float *s0 = p.pcm + (p.first_frame + job) * p.H * p.C;
             if (C2) {
-                if (false && kSlideWindow && sequential && p.H == 256) {  // stereo is not traffic-bound: not worth the VGPRs
-                    // next frame = this frame shifted by one row
+                // (a sliding register window like the mono one was tried here: stereo input is not traffic-bound and
+                // the extra live registers cost more than the saved row loads)
 #pragma unroll
-                    for (int a = 0; a < 7; ++a) { sa[a] = sa[a + 1]; sb[a] = sb[a + 1]; }
-                    const float2 v = reinterpret_cast<const float2 *>(s0)[tid + 256 * 7];
-                    sa[7] = v.x; sb[7] = v.y;
-                } else {
-#pragma unroll
-                    for (int a = 0; a < 8; ++a) {
-                        const float2 v = reinterpret_cast<const float2 *>(s0)[tid + 256 * a];
-                        sa[a] = v.x; sb[a] = v.y;
-                    }
+                for (int a = 0; a < 8; ++a) {
+                    const float2 v = reinterpret_cast<const float2 *>(s0)[tid + 256 * a];
+                    sa[a] = v.x; sb[a] = v.y;
                 }
             } else {
 #pragma unroll
