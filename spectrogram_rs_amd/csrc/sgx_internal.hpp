@@ -34,7 +34,7 @@ static_assert(sizeof(SampleEntry) == 16, "SampleEntry must be 16 bytes");
 
 struct Tables {
     std::vector<float> window;      // [W]      fft.rs:61
-    std::vector<float2> twiddle;    // [P/2]    e^{-2 pi i j / P}
+    std::vector<float2> twiddle;    // [P]      e^{-2 pi i j / P}, the full circle
     std::vector<float> edges;       // [R+1]    log_scaling.rs:114-119
     std::vector<RowEntry> rows;     // [R]
     std::vector<SampleEntry> samples;

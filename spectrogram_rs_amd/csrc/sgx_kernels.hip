@@ -8,6 +8,7 @@
 // so that its bytes equal the CPU restatement's; FFT code asks for FMAs explicitly.
 #include <hip/hip_fp16.h>
 
+#include "lds_fft.hpp"
 #include "sgx_internal.hpp"
 
 namespace sgx {
@@ -37,7 +38,7 @@ __device__ __forceinline__ float2 cmul(float2 a, float2 b)
 // Data flow: PCM -> (l + i r) * hann -> LDS; the zero padding is never materialised: with
 // z[n] = 0 for n >= W the first decimation-in-frequency stage degenerates to
 //   s[n] = z[n], s[n + W] = z[n] * w_P^n,
-// after which log2(P) - 1 in-place radix-2 DIF stages leave F in bit-reversed order.
+// after which the two halves are length-W problems: in-place radix-4 DIF stages leave F digit-reversed.
 __global__ void __launch_bounds__(256) stft_generic_kernel(StftGenericParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -60,27 +61,18 @@ __global__ void __launch_bounds__(256) stft_generic_kernel(StftGenericParams p)
     }
     __syncthreads();
 
-    for (uint32_t h = W >> 1, lh = p.logP - 2; h >= 1; h >>= 1, --lh) {
-        const uint32_t tw_stride = W / h;  // w_{2h}^j = w_P^{j * P / (2h)}
-        for (uint32_t b = tid; b < W; b += nt) {
-            const uint32_t grp = b >> lh, j = b & (h - 1);
-            const uint32_t i0 = (grp << (lh + 1)) + j, i1 = i0 + h;
-            const float2 u = s[i0], v = s[i1];
-            s[i0] = make_float2(u.x + v.x, u.y + v.y);
-            const float2 d = make_float2(u.x - v.x, u.y - v.y);
-            s[i1] = (j == 0) ? d : cmul(d, p.twiddle[j * tw_stride]);
-        }
-        __syncthreads();
-        if (h == 1) break;
-    }
+    // the two halves are independent length-W transforms now (even bins / odd bins): radix-4 stages in place
+    // (lds_fft.hpp), each half's result in digit-reversed order
+    if (p.logP >= 2) ldsfft::forward_dif(s, p.logP, p.logP - 1, p.twiddle, p.logP, tid, nt);
 
     // fft.rs:81-98: a = F[k], b = F[P - k]; left = |a + conj b| / 2, right = |a - conj b| / 2; * 2/W
     float *out = p.mags + ((size_t)(frame_local * p.pairs + pair) * M) * 2;
-    const uint32_t sh = 32 - p.logP;
+    // bin k: half k & 1 (the pruned first stage), then the digit-reversed position of k >> 1 inside it
+    const uint32_t logW = p.logP - 1;
     for (uint32_t j = tid; j < M; j += nt) {
-        const uint32_t k = j + 1;
-        const float2 a = s[__brev(k) >> sh];
-        const float2 b = s[__brev(P - k) >> sh];
+        const uint32_t k = j + 1, kp = P - k;
+        const float2 a = s[(k & 1u) * W + ldsfft::pos_of(k >> 1, logW)];
+        const float2 b = s[(kp & 1u) * W + ldsfft::pos_of(kp >> 1, logW)];
         const float sre = a.x + b.x, sim = a.y - b.y;
         const float dre = a.x - b.x, dim = a.y + b.y;
         const float left = sqrtf(fmaf(sre, sre, sim * sim)) * 0.5f * p.scale;

@@ -58,13 +58,17 @@ void build_tables(uint32_t W, uint32_t R, uint32_t sr, double f_min, double f_ma
         }
     }
 
-    // Forward twiddles e^{-2 pi i j / P}, j < P/2, rounded from double (FFTW computes its
+    // Forward twiddles e^{-2 pi i j / P}, j < P, rounded from double (FFTW computes its
     // twiddles in extended precision too; fft.rs:20-24 Sign::Forward).
-    out.twiddle.resize(P / 2);
-    for (uint32_t j = 0; j < P / 2; ++j) {
+    // The full circle: a radix-4 stage uses w^j, w^2j and w^3j.
+    out.twiddle.resize(P);
+    for (uint32_t j = 0; j < P; ++j) {
         double ang = -2.0 * M_PI * (double)j / (double)P;
         double c = cos(ang), s = sin(ang);
+        if (j == 0) { c = 1.0; s = 0.0; }
         if (4 * j == P) { c = 0.0; s = -1.0; }
+        if (2 * j == P) { c = -1.0; s = 0.0; }
+        if (4 * j == 3 * P) { c = 0.0; s = 1.0; }
         out.twiddle[j] = make_float2((float)c, (float)s);
     }
 

@@ -10,10 +10,11 @@
 //
 // Only n < W inputs are non-zero (the padding), and only k < P outputs are needed, so the circular
 // convolution length is L = pow2 >= P + W - 1 (8192 for both windows above: 64 KB of LDS).
-//   1. a[n] = z[n] c[n] -> LDS, zero to L           2. forward DIF FFT_L (bit-reversed result)
-//   3. multiply by B^ = FFT_L(conj chirp) / L, precomputed in float64, stored bit-reversed
-//   4. inverse DIT FFT_L from bit-reversed input (natural result)      5. F[k] = c[k] y[k], split.
+//   1. a[n] = z[n] c[n] -> LDS, zero to L           2. forward DIF FFT_L, radix 4 (digit-reversed result)
+//   3. multiply by B^ = FFT_L(conj chirp) / L, precomputed in float64, stored in the same digit-reversed order
+//   4. inverse DIT FFT_L from digit-reversed input (natural result)      5. F[k] = c[k] y[k], split.
 // Chirp angles use n^2 mod 2P in integers, so they are exact before the single float rounding.
+#include "lds_fft.hpp"
 #include "sgx_internal.hpp"
 
 namespace sgx {
@@ -22,8 +23,8 @@ namespace blu {
 
 struct BluTables {
     float2 *d_chirp = nullptr;  // [P]    c[n]
-    float2 *d_bhat = nullptr;   // [L]    FFT_L(b) / L in bit-reversed order
-    float2 *d_tw = nullptr;     // [L/2]  e^{-2 pi i j / L}
+    float2 *d_bhat = nullptr;   // [L]    FFT_L(b) / L at ldsfft::pos_of(k)
+    float2 *d_tw = nullptr;     // [L]    e^{-2 pi i j / L}
     uint32_t L = 0, logL = 0;
 };
 
@@ -69,38 +70,15 @@ __global__ void __launch_bounds__(1024) stft_bluestein_kernel(Params p)
     }
     __syncthreads();
 
-    // 2. forward FFT_L, in-place radix-2 DIF: natural in, bit-reversed out
-    for (uint32_t h = L >> 1, lh = p.logL - 1;; h >>= 1, --lh) {
-        const uint32_t tw_stride = (L >> 1) / h;
-        for (uint32_t b = tid; b < (L >> 1); b += nt) {
-            const uint32_t grp = b >> lh, j = b & (h - 1);
-            const uint32_t i0 = (grp << (lh + 1)) + j, i1 = i0 + h;
-            const float2 u = s[i0], v = s[i1];
-            s[i0] = make_float2(u.x + v.x, u.y + v.y);
-            const float2 d = make_float2(u.x - v.x, u.y - v.y);
-            s[i1] = (j == 0) ? d : cmul(d, p.tw[j * tw_stride]);
-        }
-        __syncthreads();
-        if (h == 1) break;
-    }
+    // 2. forward FFT_L in place (radix 4): natural in, digit-reversed out
+    ldsfft::forward_dif(s, p.logL, p.tw, tid, nt);
 
-    // 3. spectrum of the convolution (B^ carries the 1/L of the inverse transform)
+    // 3. spectrum of the convolution (B^ carries the 1/L of the inverse transform and is stored in the same order)
     for (uint32_t i = tid; i < L; i += nt) s[i] = cmul(s[i], p.bhat[i]);
     __syncthreads();
 
-    // 4. inverse FFT_L, in-place radix-2 DIT with conjugate twiddles: bit-reversed in, natural out
-    for (uint32_t h = 1, lh = 0; h < L; h <<= 1, ++lh) {
-        const uint32_t tw_stride = (L >> 1) / h;
-        for (uint32_t b = tid; b < (L >> 1); b += nt) {
-            const uint32_t grp = b >> lh, j = b & (h - 1);
-            const uint32_t i0 = (grp << (lh + 1)) + j, i1 = i0 + h;
-            const float2 u = s[i0];
-            const float2 v = (j == 0) ? s[i1] : cmul_conj(s[i1], p.tw[j * tw_stride]);
-            s[i0] = make_float2(u.x + v.x, u.y + v.y);
-            s[i1] = make_float2(u.x - v.x, u.y - v.y);
-        }
-        __syncthreads();
-    }
+    // 4. inverse FFT_L in place with conjugate twiddles: digit-reversed in, natural out
+    ldsfft::inverse_dit(s, p.logL, p.tw, tid, nt);
 
     // 5. F[k] = c[k] y[k]; split + magnitude + scale (fft.rs:81-98); k = 1 .. W-1 kept
     float *out = p.mags + ((size_t)(frame_local * p.pairs + pair) * M) * 2;
@@ -156,7 +134,7 @@ hipError_t bluestein_init(sgx_ctx *c, void **out)
     while (L < P + W - 1) { L <<= 1; ++logL; }
     t->L = L;
     t->logL = logL;
-    std::vector<float2> chirp(P), bhat(L), tw(L / 2);
+    std::vector<float2> chirp(P), bhat(L), tw(L);
     std::vector<double> cr(P), ci(P);
     for (uint32_t n = 0; n < P; ++n) {
         const unsigned long long q = ((unsigned long long)n * n) % (2ull * P);  // n^2 mod 2P: exact
@@ -169,15 +147,14 @@ hipError_t bluestein_init(sgx_ctx *c, void **out)
     for (uint32_t m = 0; m < P; ++m) { br[m] = cr[m]; bi[m] = -ci[m]; }
     for (uint32_t m = 1; m < W; ++m) { br[L - m] = cr[m]; bi[L - m] = -ci[m]; }
     fft_host(br, bi);
-    for (uint32_t i = 0; i < L; ++i) {
-        uint32_t r = 0;
-        for (uint32_t b = 0; b < logL; ++b) r |= ((i >> b) & 1u) << (logL - 1 - b);
-        bhat[r] = make_float2((float)(br[i] / (double)L), (float)(bi[i] / (double)L));
-    }
-    for (uint32_t j = 0; j < L / 2; ++j) {
+    for (uint32_t i = 0; i < L; ++i)
+        bhat[ldsfft::pos_of(i, logL)] = make_float2((float)(br[i] / (double)L), (float)(bi[i] / (double)L));
+    for (uint32_t j = 0; j < L; ++j) {  // the full circle: a radix-4 stage uses w^j, w^2j and w^3j
         const double ang = -2.0 * M_PI * (double)j / (double)L;
         double cs = cos(ang), sn = sin(ang);
         if (4 * j == L) { cs = 0.0; sn = -1.0; }
+        if (2 * j == L) { cs = -1.0; sn = 0.0; }
+        if (4 * j == 3 * L) { cs = 0.0; sn = 1.0; }
         tw[j] = make_float2((float)cs, (float)sn);
     }
     auto up = [](float2 **dst, const std::vector<float2> &v) {

@@ -48,7 +48,7 @@ def main():
             print(f"render_mags only: median {med:.3f} ms -> {F / med / 1e3:.1f} M columns/s", flush=True)
 
 
-if __name__ == "__main__" and "--extra" not in sys.argv and "--live" not in sys.argv:
+if __name__ == "__main__" and "--extra" not in sys.argv and "--live" not in sys.argv and "--generic-sizes" not in sys.argv:
     main()
 
 
@@ -121,3 +121,20 @@ def live_ticks(ticks=600):
 
 if __name__ == "__main__" and "--live" in sys.argv:
     live_ticks()
+
+
+def generic_sizes(frames=200_000):
+    """the generic power-of-two kernel at other window sizes (mono and stereo)"""
+    for W in (512, 1024, 4096):
+        for ch in (1, 2):
+            eng = SpectrogramEngine(48000.0, window_samples=W, hop_samples=W // 8, channels=ch)
+            F = frames * 2048 // W
+            pcm = eng.white_noise((F - 1) * eng.H + eng.W)
+            out = torch.empty((F, 1, eng.M, 2), dtype=torch.float32, device="cuda")
+            med, best = timeit(lambda: eng.stft_batch(pcm, out=out), iters=5)
+            print(f"generic W={W} ch={ch} kernel={eng.info.stft_kernel} F={F}: median {med:.3f} ms -> {F / med / 1e3:.1f} M frames/s, "
+                  f"{F * (eng.H * ch * 4 + eng.M * 8) / med / 1e6:.0f} GB/s algorithmic", flush=True)
+
+
+if __name__ == "__main__" and "--generic-sizes" in sys.argv:
+    generic_sizes()
