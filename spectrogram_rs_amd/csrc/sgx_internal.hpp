@@ -110,7 +110,7 @@ namespace sgx {
 
 // kernel launchers (each returns hipSuccess or the launch error)
 hipError_t launch_stft_generic(const sgx_ctx *c, const float *d_pcm, uint32_t channels, uint32_t pairs, size_t first_frame,
-                               size_t n_frames, float *d_mags);
+                               size_t n_frames, size_t total_frames, float *d_mags);
 bool fast4096_supported(const sgx_ctx *c);
 hipError_t fast4096_init(sgx_ctx *c);
 void fast4096_destroy(sgx_ctx *c);

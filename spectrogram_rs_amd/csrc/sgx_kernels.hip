@@ -20,9 +20,12 @@ namespace sgx {
 struct StftGenericParams {
     const float *pcm;      // [n][C]
     const float *window;   // [W]
-    const float2 *twiddle; // [P/2]
+    const float2 *twiddle; // [P]   e^{-2 pi i j / P}
     float *mags;           // [F][pairs][M][2]
     unsigned long long first_frame;
+    // mono pairs (frames 2q and 2q+1 ride in the real and imaginary part of one transform, as in stft4096_wg.hip):
+    unsigned long long pair_base, n_frames, total_frames;
+    uint32_t mono_pairs;
     uint32_t W, logP, H, C, pairs;
     float half_scale;      // applied as (hypot * 0.5f) * scale
     float scale;
@@ -45,16 +48,32 @@ __global__ void __launch_bounds__(256) stft_generic_kernel(StftGenericParams p)
     float2 *s = reinterpret_cast<float2 *>(smem_raw);
     const uint32_t W = p.W, P = 2 * W, M = W - 1;
     const uint32_t tid = threadIdx.x, nt = blockDim.x;
-    const unsigned long long frame_local = blockIdx.x;
     const uint32_t pair = blockIdx.y;
-    const unsigned long long t = p.first_frame + frame_local;
-    const uint32_t cl = p.C == 1 ? 0 : 2 * pair, cr = p.C == 1 ? 0 : 2 * pair + 1;
-    const float *src = p.pcm + (size_t)(t * p.H) * p.C;
+    // (l, r) of one frame -- or, for a mono stream, frames 2q and 2q+1 by GLOBAL index: the split that separates left
+    // from right then separates the two frames, each is written as (m, m), and any sub-range writes the same bytes
+    long long row_a, row_b = -1;   // output rows (frames relative to first_frame); < 0 or >= n_frames: not stored
+    const float *src_a, *src_b;
+    uint32_t cl, cr;
+    bool data_b = true;
+    if (p.mono_pairs) {
+        const unsigned long long fa = 2 * (p.pair_base + blockIdx.x), fb = fa + 1;
+        row_a = (long long)fa - (long long)p.first_frame;
+        row_b = row_a + 1;
+        data_b = fb < p.total_frames;
+        src_a = p.pcm + (size_t)(fa * p.H);
+        src_b = data_b ? src_a + p.H : src_a;
+        cl = cr = 0;
+    } else {
+        row_a = (long long)blockIdx.x;
+        src_a = src_b = p.pcm + (size_t)((p.first_frame + blockIdx.x) * p.H) * p.C;
+        cl = p.C == 1 ? 0 : 2 * pair;
+        cr = p.C == 1 ? 0 : 2 * pair + 1;
+    }
 
     for (uint32_t n = tid; n < W; n += nt) {
         const float w = p.window[n];
-        const float l = src[(size_t)n * p.C + cl];
-        const float r = src[(size_t)n * p.C + cr];
+        const float l = src_a[(size_t)n * p.C + cl];
+        const float r = data_b ? src_b[(size_t)n * p.C + cr] : 0.0f;
         const float2 z = make_float2(l * w, r * w);  // complex * real, fft.rs:59-63
         s[n] = z;
         s[n + W] = cmul(z, p.twiddle[n]);
@@ -66,7 +85,10 @@ __global__ void __launch_bounds__(256) stft_generic_kernel(StftGenericParams p)
     if (p.logP >= 2) ldsfft::forward_dif(s, p.logP, p.logP - 1, p.twiddle, p.logP, tid, nt);
 
     // fft.rs:81-98: a = F[k], b = F[P - k]; left = |a + conj b| / 2, right = |a - conj b| / 2; * 2/W
-    float *out = p.mags + ((size_t)(frame_local * p.pairs + pair) * M) * 2;
+    const bool st_a = row_a >= 0 && (unsigned long long)row_a < p.n_frames;
+    const bool st_b = p.mono_pairs && row_b >= 0 && (unsigned long long)row_b < p.n_frames;
+    float2 *out_a = reinterpret_cast<float2 *>(p.mags) + ((size_t)(st_a ? row_a : 0) * p.pairs + pair) * M;
+    float2 *out_b = reinterpret_cast<float2 *>(p.mags) + ((size_t)(st_b ? row_b : 0) * p.pairs + pair) * M;
     // bin k: half k & 1 (the pruned first stage), then the digit-reversed position of k >> 1 inside it
     const uint32_t logW = p.logP - 1;
     for (uint32_t j = tid; j < M; j += nt) {
@@ -77,15 +99,20 @@ __global__ void __launch_bounds__(256) stft_generic_kernel(StftGenericParams p)
         const float dre = a.x - b.x, dim = a.y + b.y;
         const float left = sqrtf(fmaf(sre, sre, sim * sim)) * 0.5f * p.scale;
         const float right = sqrtf(fmaf(dre, dre, dim * dim)) * 0.5f * p.scale;
-        reinterpret_cast<float2 *>(out)[j] = make_float2(left, right);
+        if (p.mono_pairs) {
+            if (st_a) out_a[j] = make_float2(left, left);
+            if (st_b) out_b[j] = make_float2(right, right);
+        } else {
+            out_a[j] = make_float2(left, right);
+        }
     }
 }
 
 hipError_t launch_stft_generic(const sgx_ctx *c, const float *d_pcm, uint32_t channels, uint32_t pairs, size_t first_frame,
-                               size_t n_frames, float *d_mags)
+                               size_t n_frames, size_t total_frames, float *d_mags)
 {
     if (n_frames == 0) return hipSuccess;
-    StftGenericParams p;
+    StftGenericParams p{};
     p.pcm = d_pcm;
     p.window = c->d_window;
     p.twiddle = c->d_twiddle;
@@ -104,6 +131,23 @@ hipError_t launch_stft_generic(const sgx_ctx *c, const float *d_pcm, uint32_t ch
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
+    p.n_frames = n_frames;
+    p.total_frames = total_frames;
+    if (channels == 1 && !(c->cfg.flags & SGX_FLAG_INDEPENDENT_FRAMES)) {
+        // one workgroup per frame PAIR (2q, 2q+1); an odd first frame / last frame shares its transform with a
+        // neighbour outside the range, which is computed and not stored
+        p.mono_pairs = 1;
+        const unsigned long long q0 = first_frame / 2, q1 = (first_frame + n_frames + 1) / 2;
+        const unsigned long long max_chunk = 1u << 30;
+        for (unsigned long long q = q0; q < q1; q += max_chunk) {
+            const unsigned long long chunk = q1 - q < max_chunk ? q1 - q : max_chunk;
+            p.pair_base = q;
+            hipLaunchKernelGGL(stft_generic_kernel, dim3((unsigned)chunk, 1), dim3(256), lds, c->stream, p);
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) return e;
+        }
+        return hipSuccess;
+    }
     // gridDim.x is limited to 2^31-1; frames are chunked far below that by the caller
     const size_t max_chunk = 1u << 30;
     size_t done = 0;
@@ -111,6 +155,7 @@ hipError_t launch_stft_generic(const sgx_ctx *c, const float *d_pcm, uint32_t ch
         size_t chunk = n_frames - done < max_chunk ? n_frames - done : max_chunk;
         StftGenericParams q = p;
         q.first_frame = first_frame + done;
+        q.n_frames = chunk;
         q.mags = d_mags + done * (size_t)pairs * c->M * 2;
         hipLaunchKernelGGL(stft_generic_kernel, dim3((unsigned)chunk, pairs), dim3(256), lds, c->stream, q);
         hipError_t e = hipGetLastError();
