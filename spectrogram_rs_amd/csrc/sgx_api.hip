@@ -96,7 +96,7 @@ hipError_t run_stft(const sgx_ctx *c, const float *d_pcm, uint32_t channels, uin
 {
     if (c->stft_kernel == 5 && (channels != 1 || !(c->cfg.flags & SGX_FLAG_INDEPENDENT_FRAMES)))
         return sgx::launch_stft_wg16384(c, c->d_fast_16k, d_pcm, channels, pairs, first, n, total, d_mags);
-    if (c->stft_kernel == 4) return sgx::launch_stft_bluestein(c, c->d_blu, d_pcm, channels, pairs, first, n, d_mags);
+    if (c->stft_kernel == 4) return sgx::launch_stft_bluestein(c, c->d_blu, d_pcm, channels, pairs, first, n, total, d_mags);
     if (c->stft_kernel == 3) return sgx::launch_stft_wgp4096(c, c->d_fast_wg, d_pcm, channels, pairs, first, n, total, d_mags);
     if (c->stft_kernel == 2) return sgx::launch_stft_wg4096(c, c->d_fast_wg, d_pcm, channels, pairs, first, n, total, d_mags);
     if (c->stft_kernel == 1) return sgx::launch_stft_fast4096(c, d_pcm, channels, pairs, first, n, total, d_mags);

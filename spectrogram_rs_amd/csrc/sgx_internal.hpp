@@ -136,7 +136,7 @@ bool bluestein_supported(uint32_t W);
 hipError_t bluestein_init(sgx_ctx *c, void **out);
 void bluestein_destroy(void *tables);
 hipError_t launch_stft_bluestein(const sgx_ctx *c, const void *tables, const float *d_pcm, uint32_t channels, uint32_t pairs,
-                                 size_t first_frame, size_t n_frames, float *d_mags);
+                                 size_t first_frame, size_t n_frames, size_t total_frames, float *d_mags);
 hipError_t launch_stft_wg4096_f16(const sgx_ctx *c, const void *tables, const float *d_pcm, uint32_t channels, uint32_t pairs,
                                   size_t first_frame, size_t n_frames, size_t total_frames, void *d_mags_f16);
 hipError_t launch_to_half(const sgx_ctx *c, const float *d_in, void *d_out, size_t n_pairs);

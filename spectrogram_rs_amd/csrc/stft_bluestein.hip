@@ -34,6 +34,9 @@ struct Params {
     const float2 *chirp, *bhat, *tw;
     float *mags;
     unsigned long long first_frame;
+    // mono pairs (frames 2q and 2q+1 ride in the real and imaginary part of one transform, as in stft4096_wg.hip):
+    unsigned long long pair_base, n_frames, total_frames;
+    uint32_t mono_pairs;
     uint32_t W, P, L, logL, H, C, pairs;
     float scale;
 };
@@ -53,18 +56,35 @@ __global__ void __launch_bounds__(1024) stft_bluestein_kernel(Params p)
     float2 *s = reinterpret_cast<float2 *>(smem_raw);
     const uint32_t W = p.W, P = p.P, L = p.L, M = W - 1;
     const uint32_t tid = threadIdx.x, nt = blockDim.x;
-    const unsigned long long frame_local = blockIdx.x;
     const uint32_t pair = blockIdx.y;
-    const unsigned long long t = p.first_frame + frame_local;
-    const uint32_t cl = p.C == 1 ? 0 : 2 * pair, cr = p.C == 1 ? 0 : 2 * pair + 1;
-    const float *src = p.pcm + (size_t)(t * p.H) * p.C;
+    // (l, r) of one frame -- or, for a mono stream, frames 2q and 2q+1 by GLOBAL index (see sgx_kernels.hip)
+    long long row_a, row_b = -1;
+    const float *src_a, *src_b;
+    uint32_t cl, cr;
+    bool data_b = true;
+    if (p.mono_pairs) {
+        const unsigned long long fa = 2 * (p.pair_base + blockIdx.x), fb = fa + 1;
+        row_a = (long long)fa - (long long)p.first_frame;
+        row_b = row_a + 1;
+        data_b = fb < p.total_frames;
+        src_a = p.pcm + (size_t)(fa * p.H);
+        src_b = data_b ? src_a + p.H : src_a;
+        cl = cr = 0;
+    } else {
+        row_a = (long long)blockIdx.x;
+        src_a = src_b = p.pcm + (size_t)((p.first_frame + blockIdx.x) * p.H) * p.C;
+        cl = p.C == 1 ? 0 : 2 * pair;
+        cr = p.C == 1 ? 0 : 2 * pair + 1;
+    }
 
     // 1. (l + i r) * hann (fft.rs:53-63), times the chirp; zeros up to L
     for (uint32_t n = tid; n < L; n += nt) {
         float2 v = make_float2(0.0f, 0.0f);
         if (n < W) {
             const float w = p.window[n];
-            v = cmul(make_float2(src[(size_t)n * p.C + cl] * w, src[(size_t)n * p.C + cr] * w), p.chirp[n]);
+            const float l = src_a[(size_t)n * p.C + cl];
+            const float r = data_b ? src_b[(size_t)n * p.C + cr] : 0.0f;
+            v = cmul(make_float2(l * w, r * w), p.chirp[n]);
         }
         s[n] = v;
     }
@@ -81,7 +101,10 @@ __global__ void __launch_bounds__(1024) stft_bluestein_kernel(Params p)
     ldsfft::inverse_dit(s, p.logL, p.tw, tid, nt);
 
     // 5. F[k] = c[k] y[k]; split + magnitude + scale (fft.rs:81-98); k = 1 .. W-1 kept
-    float *out = p.mags + ((size_t)(frame_local * p.pairs + pair) * M) * 2;
+    const bool st_a = row_a >= 0 && (unsigned long long)row_a < p.n_frames;
+    const bool st_b = p.mono_pairs && row_b >= 0 && (unsigned long long)row_b < p.n_frames;
+    float2 *out_a = reinterpret_cast<float2 *>(p.mags) + ((size_t)(st_a ? row_a : 0) * p.pairs + pair) * M;
+    float2 *out_b = reinterpret_cast<float2 *>(p.mags) + ((size_t)(st_b ? row_b : 0) * p.pairs + pair) * M;
     for (uint32_t j = tid; j < M; j += nt) {
         const uint32_t k = j + 1;
         const float2 a = cmul(s[k], p.chirp[k]);
@@ -90,7 +113,12 @@ __global__ void __launch_bounds__(1024) stft_bluestein_kernel(Params p)
         const float dre = a.x - b.x, dim = a.y + b.y;
         const float left = sqrtf(fmaf(sre, sre, sim * sim)) * 0.5f * p.scale;
         const float right = sqrtf(fmaf(dre, dre, dim * dim)) * 0.5f * p.scale;
-        reinterpret_cast<float2 *>(out)[j] = make_float2(left, right);
+        if (p.mono_pairs) {
+            if (st_a) out_a[j] = make_float2(left, left);
+            if (st_b) out_b[j] = make_float2(right, right);
+        } else {
+            out_a[j] = make_float2(left, right);
+        }
     }
 }
 
@@ -187,12 +215,12 @@ void bluestein_destroy(void *tables)
 }
 
 hipError_t launch_stft_bluestein(const sgx_ctx *c, const void *tables, const float *d_pcm, uint32_t channels, uint32_t pairs,
-                                 size_t first_frame, size_t n_frames, float *d_mags)
+                                 size_t first_frame, size_t n_frames, size_t total_frames, float *d_mags)
 {
     using namespace blu;
     if (n_frames == 0) return hipSuccess;
     const auto *t = static_cast<const BluTables *>(tables);
-    Params p;
+    Params p{};
     p.pcm = d_pcm;
     p.window = c->d_window;
     p.chirp = t->d_chirp;
@@ -208,9 +236,26 @@ hipError_t launch_stft_bluestein(const sgx_ctx *c, const void *tables, const flo
     p.scale = 2.0f / (float)c->W;
     const size_t lds = (size_t)t->L * sizeof(float2);
     const size_t max_chunk = 1u << 30;
+    p.first_frame = first_frame;
+    p.n_frames = n_frames;
+    p.total_frames = total_frames;
+    if (channels == 1 && !(c->cfg.flags & SGX_FLAG_INDEPENDENT_FRAMES)) {
+        p.mono_pairs = 1;
+        p.mags = d_mags;
+        const unsigned long long q0 = first_frame / 2, q1 = (first_frame + n_frames + 1) / 2;
+        for (unsigned long long q = q0; q < q1; q += max_chunk) {
+            const unsigned long long chunk = q1 - q < max_chunk ? q1 - q : max_chunk;
+            p.pair_base = q;
+            hipLaunchKernelGGL(stft_bluestein_kernel, dim3((unsigned)chunk, 1), dim3(1024), lds, c->stream, p);
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) return e;
+        }
+        return hipSuccess;
+    }
     for (size_t done = 0; done < n_frames; done += max_chunk) {
         const size_t chunk = n_frames - done < max_chunk ? n_frames - done : max_chunk;
         p.first_frame = first_frame + done;
+        p.n_frames = chunk;
         p.mags = d_mags + done * (size_t)pairs * c->M * 2;
         hipLaunchKernelGGL(stft_bluestein_kernel, dim3((unsigned)chunk, pairs), dim3(1024), lds, c->stream, p);
         hipError_t e = hipGetLastError();
