@@ -42,7 +42,7 @@ __device__ __forceinline__ float2 cmul(float2 a, float2 b)
 // z[n] = 0 for n >= W the first decimation-in-frequency stage degenerates to
 //   s[n] = z[n], s[n + W] = z[n] * w_P^n,
 // after which the two halves are length-W problems: in-place radix-4 DIF stages leave F digit-reversed.
-__global__ void __launch_bounds__(256) stft_generic_kernel(StftGenericParams p)
+__global__ void __launch_bounds__(1024) stft_generic_kernel(StftGenericParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float2 *s = reinterpret_cast<float2 *>(smem_raw);
@@ -126,6 +126,8 @@ hipError_t launch_stft_generic(const sgx_ctx *c, const float *d_pcm, uint32_t ch
     p.half_scale = 0.5f;
     p.scale = 2.0f / (float)c->W;
     const size_t lds = (size_t)c->P * sizeof(float2);
+    // 16 waves per CU whatever the LDS image allows: 4 x 256 threads up to P = 4096, 2 x 512 at 8192, 1 x 1024 at 16384
+    const unsigned threads = c->P >= 16384 ? 1024u : (c->P >= 8192 ? 512u : 256u);
     if (lds > 64 * 1024) {  // per launch: the attribute is per device, and a process may hold contexts on several
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(stft_generic_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -142,7 +144,7 @@ hipError_t launch_stft_generic(const sgx_ctx *c, const float *d_pcm, uint32_t ch
         for (unsigned long long q = q0; q < q1; q += max_chunk) {
             const unsigned long long chunk = q1 - q < max_chunk ? q1 - q : max_chunk;
             p.pair_base = q;
-            hipLaunchKernelGGL(stft_generic_kernel, dim3((unsigned)chunk, 1), dim3(256), lds, c->stream, p);
+            hipLaunchKernelGGL(stft_generic_kernel, dim3((unsigned)chunk, 1), dim3(threads), lds, c->stream, p);
             hipError_t e = hipGetLastError();
             if (e != hipSuccess) return e;
         }
@@ -157,7 +159,7 @@ hipError_t launch_stft_generic(const sgx_ctx *c, const float *d_pcm, uint32_t ch
         q.first_frame = first_frame + done;
         q.n_frames = chunk;
         q.mags = d_mags + done * (size_t)pairs * c->M * 2;
-        hipLaunchKernelGGL(stft_generic_kernel, dim3((unsigned)chunk, pairs), dim3(256), lds, c->stream, q);
+        hipLaunchKernelGGL(stft_generic_kernel, dim3((unsigned)chunk, pairs), dim3(threads), lds, c->stream, q);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
         done += chunk;
