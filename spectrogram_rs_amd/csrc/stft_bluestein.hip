@@ -236,6 +236,9 @@ hipError_t launch_stft_bluestein(const sgx_ctx *c, const void *tables, const flo
     p.scale = 2.0f / (float)c->W;
     const size_t lds = (size_t)t->L * sizeof(float2);
     const size_t max_chunk = 1u << 30;
+    // one radix-4 butterfly per thread and stage where the transform is long enough (short windows: fewer idle lanes)
+    unsigned threads = t->L / 4;
+    threads = threads > 1024u ? 1024u : (threads < 64u ? 64u : threads);
     p.first_frame = first_frame;
     p.n_frames = n_frames;
     p.total_frames = total_frames;
@@ -246,7 +249,7 @@ hipError_t launch_stft_bluestein(const sgx_ctx *c, const void *tables, const flo
         for (unsigned long long q = q0; q < q1; q += max_chunk) {
             const unsigned long long chunk = q1 - q < max_chunk ? q1 - q : max_chunk;
             p.pair_base = q;
-            hipLaunchKernelGGL(stft_bluestein_kernel, dim3((unsigned)chunk, 1), dim3(1024), lds, c->stream, p);
+            hipLaunchKernelGGL(stft_bluestein_kernel, dim3((unsigned)chunk, 1), dim3(threads), lds, c->stream, p);
             hipError_t e = hipGetLastError();
             if (e != hipSuccess) return e;
         }
@@ -257,7 +260,7 @@ hipError_t launch_stft_bluestein(const sgx_ctx *c, const void *tables, const flo
         p.first_frame = first_frame + done;
         p.n_frames = chunk;
         p.mags = d_mags + done * (size_t)pairs * c->M * 2;
-        hipLaunchKernelGGL(stft_bluestein_kernel, dim3((unsigned)chunk, pairs), dim3(1024), lds, c->stream, p);
+        hipLaunchKernelGGL(stft_bluestein_kernel, dim3((unsigned)chunk, pairs), dim3(threads), lds, c->stream, p);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
