@@ -18,6 +18,8 @@
  *     reference unwrap()s: fft.rs:24,77).
  *   - A context is not thread-safe: one context per thread / stream / GPU (the reference holds
  *     its transform in a RefCell on the GTK main thread: gpu_spectrogram.rs:58).
+ *   - Device buffers are at least 8-byte aligned ((l, r) pairs are moved as 8-byte words); hipMalloc and torch
+ *     allocations are 256-byte aligned, which is also what the store pattern of the kernels is tuned for.
  *   - There is NO CPU fallback: without a HIP device sgx_create() fails with SGX_ERR_NO_DEVICE.
  */
 #ifndef SGX_H
