@@ -13,4 +13,5 @@ python3 tools/pmc_summary.py gpurun_out/pr_sq1 gpurun_out/pr_sq2 > gpurun_out/pr
 timeout -k 10 300 python tools/quick_bench.py --frames 1000000 --render > gpurun_out/pr_other.txt 2>&1
 timeout -k 10 300 python tools/quick_bench.py --extra >> gpurun_out/pr_other.txt 2>&1
 timeout -k 10 300 python tools/quick_bench.py --live >> gpurun_out/pr_other.txt 2>&1
+timeout -k 10 300 python tools/quick_bench.py --generic-sizes >> gpurun_out/pr_other.txt 2>&1
 echo profile round done
