@@ -35,7 +35,7 @@ W, H, M, R = 2048, 256, 2047, 1024
 ALGO_BYTES_STFT = H * 1 * 4 + M * 2 * 4  # 17 400 B / frame: each input sample once, each output byte once
 ALGO_BYTES_PIXEL = H * 1 * 4 + R * 4     # 5 120 B / frame
 KERNEL_NAMES = {
-    0: ("generic power-of-two (workgroup per frame, LDS radix-2)", "sgx::stft_generic_kernel"),
+    0: ("generic power-of-two (workgroup per frame, LDS radix-4)", "sgx::stft_generic_kernel"),
     1: ("stft4096 wave-per-transform", "sgx::stft4096_kernel<6, true>"),
     2: ("stft4096 workgroup-per-transform (256 threads x 16 points, radix-16 x3, mono frame pairs), scalar codelets",
         "sgx::wg::stft4096_wg_kernel<true, 0, false, false>"),

@@ -96,6 +96,7 @@ hipError_t run_stft(const sgx_ctx *c, const float *d_pcm, uint32_t channels, uin
 {
     if (c->stft_kernel == 5 && (channels != 1 || !(c->cfg.flags & SGX_FLAG_INDEPENDENT_FRAMES)))
         return sgx::launch_stft_wg16384(c, c->d_fast_16k, d_pcm, channels, pairs, first, n, total, d_mags);
+    if (c->stft_kernel == 6) return sgx::launch_stft_mixed(c, c->d_mix, d_pcm, channels, pairs, first, n, total, d_mags);
     if (c->stft_kernel == 4) return sgx::launch_stft_bluestein(c, c->d_blu, d_pcm, channels, pairs, first, n, total, d_mags);
     if (c->stft_kernel == 3) return sgx::launch_stft_wgp4096(c, c->d_fast_wg, d_pcm, channels, pairs, first, n, total, d_mags);
     if (c->stft_kernel == 2) return sgx::launch_stft_wg4096(c, c->d_fast_wg, d_pcm, channels, pairs, first, n, total, d_mags);
@@ -174,10 +175,10 @@ int sgx_create(const sgx_config *cfg, sgx_ctx **out_ctx)
     if (cfg->lut_index_mode > SGX_LUT_ROUND_NM1) return bail(SGX_ERR_INVALID_ARG, "sgx_create: unknown lut_index_mode");
     if (c->sr_u32 == 0) return bail(SGX_ERR_INVALID_ARG, "sgx_create: sample_rate must be at least 1 Hz");
     const bool pow2 = (c->P & (c->P - 1)) == 0 && c->P <= 16384;
-    if (!pow2 && !sgx::bluestein_supported(c->W))
+    if (!pow2 && !sgx::bluestein_supported(c->W) && !sgx::mixed_supported(c->W))
         return bail(SGX_ERR_UNSUPPORTED,
                     "sgx_create: transform length 2W = " + std::to_string(c->P) +
-                        " is not supported by this build (power of two up to 16384, or any 2W with 3W - 1 <= 16384)");
+                        " is not supported by this build (up to 16384 with prime factors 2, 3, 5, 7 only, or any 2W with 3W - 1 <= 16384)");
     c->logP = 0;
     while ((1u << c->logP) < c->P) ++c->logP;
 
@@ -208,7 +209,12 @@ int sgx_create(const sgx_config *cfg, sgx_ctx **out_ctx)
     if (rc != SGX_OK) { std::string m = c->err; return bail(rc, m); }
 
     c->stft_kernel = 0;
-    if (!pow2) {
+    if (!pow2 && sgx::mixed_supported(c->W) && !((cfg->flags & SGX_FLAG_FORCE_GENERIC) && sgx::bluestein_supported(c->W))) {
+        // a length FFTW would factor: mixed-radix transform of exactly 2W points (SGX_FLAG_FORCE_GENERIC: chirp-z instead)
+        e = sgx::mixed_init(c, &c->d_mix);
+        if (e != hipSuccess) return bail(SGX_ERR_HIP, std::string("sgx_create: mixed-radix tables: ") + hipGetErrorString(e));
+        c->stft_kernel = 6;
+    } else if (!pow2) {
         e = sgx::bluestein_init(c, &c->d_blu);
         if (e != hipSuccess) return bail(SGX_ERR_HIP, std::string("sgx_create: Bluestein tables: ") + hipGetErrorString(e));
         c->stft_kernel = 4;
@@ -236,6 +242,8 @@ void sgx_destroy(sgx_ctx *c)
     c->d_fast_wg = nullptr;
     sgx::bluestein_destroy(c->d_blu);
     c->d_blu = nullptr;
+    sgx::mixed_destroy(c->d_mix);
+    c->d_mix = nullptr;
     sgx::wg16384_destroy(c->d_fast_16k);
     c->d_fast_16k = nullptr;
     void *ptrs[] = {c->d_window, c->d_twiddle, c->d_rows, c->d_samples, c->d_lut_thr, c->d_alpha_thr,

@@ -72,7 +72,7 @@ struct sgx_ctx {
     uint32_t W = 0, P = 0, M = 0, H = 0, C = 0, pairs = 0, R = 0, sr_u32 = 0, logP = 0;
     int device = 0;
     hipStream_t stream = nullptr;
-    int stft_kernel = 0;  // 0 generic, 1 tuned 4096 wave-per-transform, 2 tuned 4096 workgroup-per-transform (scalar codelets), 3 the same with packed (re, im) arithmetic, 4 Bluestein (2W not a power of two), 5 tuned 16384
+    int stft_kernel = 0;  // 0 generic, 1 tuned 4096 wave-per-transform, 2 tuned 4096 workgroup-per-transform (scalar codelets), 3 the same with packed (re, im) arithmetic, 4 Bluestein (2W not a power of two), 5 tuned 16384, 6 mixed radix (2W = 2^a 3^b 5^c 7^d)
 
     sgx::Tables tab;
     sgx::Palette pal;
@@ -89,6 +89,7 @@ struct sgx_ctx {
     void *d_fast = nullptr;        // tables of the wave-per-transform kernel (opaque here)
     void *d_fast_wg = nullptr;     // tables of the workgroup-per-transform kernel
     void *d_blu = nullptr;         // tables of the Bluestein (non-power-of-two) kernel
+    void *d_mix = nullptr;         // tables of the mixed-radix (2, 3, 5, 7-smooth lengths) kernel
     void *d_fast_16k = nullptr;    // tables of the 16384-point workgroup-per-transform kernel
 
     // workspaces (grown on demand, kept)
@@ -132,6 +133,11 @@ hipError_t wg16384_init(sgx_ctx *c, void **out);
 void wg16384_destroy(void *tables);
 hipError_t launch_stft_wg16384(const sgx_ctx *c, const void *tables, const float *d_pcm, uint32_t channels, uint32_t pairs,
                                size_t first_frame, size_t n_frames, size_t total_frames, float *d_mags);
+bool mixed_supported(uint32_t W);
+hipError_t mixed_init(sgx_ctx *c, void **out);
+void mixed_destroy(void *tables);
+hipError_t launch_stft_mixed(const sgx_ctx *c, const void *tables, const float *d_pcm, uint32_t channels, uint32_t pairs,
+                             size_t first_frame, size_t n_frames, size_t total_frames, float *d_mags);
 bool bluestein_supported(uint32_t W);
 hipError_t bluestein_init(sgx_ctx *c, void **out);
 void bluestein_destroy(void *tables);

@@ -11,9 +11,13 @@ pytestmark = pytest.mark.gpu
 
 
 def draw(rng):
-    kind = rng.choice(["pow2", "pow2", "odd"])
+    kind = rng.choice(["pow2", "pow2", "odd", "smooth"])
     if kind == "pow2":
         W = int(2 ** rng.integers(2, 13))               # 4 .. 4096 (2W = the power-of-two kernels)
+    elif kind == "smooth":                              # 2W = 2^a 3^b 5^c 7^d up to 16384: the mixed-radix kernel
+        W = 1
+        while W < 4 or W > 8192 or W & (W - 1) == 0:
+            W = int(2 ** rng.integers(0, 8) * 3 ** rng.integers(0, 5) * 5 ** rng.integers(0, 4) * 7 ** rng.integers(0, 3))
     else:
         W = int(rng.integers(5, 5400))                  # chirp-z kernel: any length with 3W - 1 <= 16384
         if W & (W - 1) == 0:
@@ -56,6 +60,7 @@ def test_random_configuration(seed, mags_err, gradients):
     if total == 0:
         assert eng.render_batch(dev).shape[0] == 0
         return
+    assert eng.info.stft_kernel in (0, 2, 4, 5, 6)
     # float32 against float32: each within the tolerance of the exact transform (three roundings more for chirp-z)
     assert mags_err(got, ref) <= (3.0 if eng.info.stft_kernel == 4 else 2.0), c
     # any sub-range writes the bytes of the full run

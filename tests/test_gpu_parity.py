@@ -108,9 +108,10 @@ def test_config4_16384_point_kernel(torch_cuda, mags_err, ch, force_generic):
     assert np.array_equal(rg.reshape(own.shape), own)
 
 
-@pytest.mark.parametrize("Wt,Ht", [(512, 64), (1024, 333), (4096, 512), (2400, 93), (735, 200)])
+@pytest.mark.parametrize("Wt,Ht", [(512, 64), (1024, 333), (4096, 512), (2400, 93), (735, 200), (1102, 100)])
 def test_generic_kernel_pairs_mono_frames_by_global_index(torch_cuda, mags_err, Wt, Ht):
-    # sizes served by the generic power-of-two kernel and by the chirp-z kernel: a mono stream rides two frames per transform there too
+    # sizes served by the generic power-of-two kernel, the mixed-radix kernel (4800 = 2^6 3 5^2, 1470 = 2 3 5 7^2) and the
+    # chirp-z kernel (2204 = 4 * 19 * 29): a mono stream rides two frames per transform there too
     # (frames 2q and 2q+1 in the real / imaginary part), any sub-range writes the bytes of the full run, and
     # SGX_FLAG_INDEPENDENT_FRAMES restores the reference's (s, s) dataflow
     torch = torch_cuda
@@ -118,8 +119,8 @@ def test_generic_kernel_pairs_mono_frames_by_global_index(torch_cuda, mags_err, 
     dev = to_dev(torch, pcm)
     ref = oracle.stream_process(pcm, 1, Wt, Ht, threads=8)
     eng = engine(window_samples=Wt, hop_samples=Ht, channels=1)
-    assert eng.info.stft_kernel == (0 if Wt & (Wt - 1) == 0 else 4)
-    tol = 2.0 if eng.info.stft_kernel == 0 else 3.0
+    assert eng.info.stft_kernel == (0 if Wt & (Wt - 1) == 0 else (4 if Wt == 1102 else 6))
+    tol = 3.0 if eng.info.stft_kernel == 4 else 2.0
     got = eng.stft_batch(dev).cpu().numpy()
     assert got.shape == ref.shape == (38, 1, Wt - 1, 2)
     assert mags_err(got, ref) <= tol and np.array_equal(got[..., 0], got[..., 1])
@@ -169,19 +170,27 @@ def test_process_one_mirrors_process(torch_cuda, mags_err):
 def test_unsupported_length_is_reported_not_approximated(torch_cuda):
     from spectrogram_rs_amd import SgxError
     with pytest.raises(SgxError) as ei:
-        engine(window_samples=6000)  # 2W = 12000 is not a power of two and 3W - 1 > 16384
-    assert ei.value.code == -2 and "12000" in str(ei.value)
+        engine(window_samples=6001)  # 2W = 12002 = 2 * 17 * 353: not 7-smooth, and 3W - 1 > 16384 rules the chirp-z kernel out
+    assert ei.value.code == -2 and "12002" in str(ei.value)
     with pytest.raises(SgxError):
         engine(window_samples=16384)  # 2W = 32768 does not fit the LDS
+    assert engine(window_samples=5000).info.stft_kernel == 6    # 10000 = 2^4 5^4: mixed radix
+    assert engine(window_samples=6000).info.stft_kernel == 6    # 12000 = 2^5 3 5^3: past the chirp-z range, still served
+    assert engine(window_samples=5003).info.stft_kernel == 4    # 10006 = 2 * 5003: chirp-z
 
 
-@pytest.mark.parametrize("sr,period,Wexp", [(48000.0, 0.05, 2400), (44100.0, 0.05, 2205), (48000.0, 0.01, 480), (8000.0, 0.0125, 100)])
-def test_duration_sized_windows_like_the_app(torch_cuda, mags_err, sr, period, Wexp):
-    # FastFourierTransform::new(sample_rate, 0.05) (gpu_spectrogram.rs:323): W = 2400 / 2205, 2W not a power of two
+@pytest.mark.parametrize("chirp_z", [False, True])
+@pytest.mark.parametrize("sr,period,Wexp", [(48000.0, 0.05, 2400), (44100.0, 0.05, 2205), (48000.0, 0.01, 480), (8000.0, 0.0125, 100),
+                                            (22050.0, 0.05, 1102), (48000.0, 0.0386, 1852)])
+def test_duration_sized_windows_like_the_app(torch_cuda, mags_err, sr, period, Wexp, chirp_z):
+    # FastFourierTransform::new(sample_rate, 0.05) (gpu_spectrogram.rs:323): W = 2400 / 2205, 2W not a power of two.
+    # Lengths with prime factors 2, 3, 5, 7 only (4800, 4410, 960, 200) take the mixed-radix kernel, the others
+    # (2204 = 4 * 19 * 29, 3704 = 8 * 463) the chirp-z kernel, which force_generic selects for the smooth ones too.
     torch = torch_cuda
     from spectrogram_rs_amd import SpectrogramEngine
-    eng = SpectrogramEngine(sr, period=period, stride=2.0 / 1024, channels=2)
-    assert eng.W == Wexp == oracle.window_samples(sr, period) and eng.info.stft_kernel == 4
+    eng = SpectrogramEngine(sr, period=period, stride=2.0 / 1024, channels=2, force_generic=chirp_z)
+    smooth = Wexp in (2400, 2205, 480, 100)
+    assert eng.W == Wexp == oracle.window_samples(sr, period) and eng.info.stft_kernel == (6 if smooth and not chirp_z else 4)
     Ht = eng.H
     assert Ht == oracle.hop_samples(sr, 2.0 / 1024)
     n = Wexp + 12 * Ht + 5
@@ -190,8 +199,10 @@ def test_duration_sized_windows_like_the_app(torch_cuda, mags_err, sr, period, W
     ref = oracle.stream_process(pcm, 2, Wexp, Ht, threads=8)
     assert got.shape == ref.shape == (13, 1, Wexp - 1, 2)
     truth = np.stack([oracle.np_truth_frame(pcm.reshape(-1, 2)[t * Ht:t * Ht + Wexp], Wexp) for t in (0, 7, 12)])
-    assert mags_err(got[[0, 7, 12], 0], truth) <= 2.0   # chirp-z: two FFTs + three chirp products in float32
-    assert mags_err(got, ref) <= 3.0
+    if eng.info.stft_kernel == 6:
+        assert mags_err(got[[0, 7, 12], 0], truth) <= 1.0 and mags_err(got, ref) <= 2.0
+    else:   # chirp-z: two FFTs + three chirp products in float32
+        assert mags_err(got[[0, 7, 12], 0], truth) <= 2.0 and mags_err(got, ref) <= 3.0
     # the pixel path rides on it (two-kernel route) and is bit-exact on the engine's own magnitudes
     eng.set_builtin_gradient("viridis")
     rgba = eng.render_batch(to_dev(torch, pcm)).cpu().numpy()

@@ -65,7 +65,7 @@ def config4(frames=20000):
 
 
 def app_default(frames=20000):
-    """the app's own operating point: 0.05 s window at 48 kHz (W 2400, Bluestein), hop 93, stereo"""
+    """the app's own operating point: 0.05 s window at 48 kHz (W 2400: 4800-point mixed radix), hop 93, stereo"""
     eng = SpectrogramEngine(48000.0, period=0.05, stride=2.0 / 1024, channels=2)
     n = (frames - 1) * eng.H + eng.W
     pcm = eng.white_noise(n)
