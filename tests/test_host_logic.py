@@ -79,3 +79,38 @@ def test_log_axis_matches_oracle_and_roundtrips():
         assert ax.map(ax.unmap(p, (0, 1024)), (0, 1024)) == p
     e = np.array([np.float32(ax.unmap(p, (0, 1024))) for p in range(1025)], np.float32)
     assert np.array_equal(e, oracle.bin_edges(1024))
+
+
+def test_mixed_radix_block_index_arithmetic_is_exact_for_every_supported_length():
+    # csrc/stft_mixed.hip splits a butterfly number b into (block, offset) with one float multiply,
+    # block = uint((b + 0.5f) * (1.0f / m)), instead of an integer division.  float32 arithmetic is the same on the
+    # host: every stage of every supported length (2W <= 16384 with prime factors 2, 3, 5, 7) is checked here.
+    def stages(P):
+        n, out = P, []
+        for f in (7, 5, 3):
+            while n % f == 0:
+                out.append(f)
+                n //= f
+        while n % 4 == 0:
+            out.append(4)
+            n //= 4
+        if n % 2 == 0:
+            out.append(2)
+            n //= 2
+        return out if n == 1 else None
+
+    lengths = 0
+    for P in range(8, 16385, 2):
+        radices = stages(P)
+        if radices is None:
+            continue
+        lengths += 1
+        ns = P
+        for r in radices:
+            m = ns // r
+            b = np.arange(P // r, dtype=np.float32)
+            got = ((b + np.float32(0.5)) * (np.float32(1.0) / np.float32(m))).astype(np.uint32)
+            assert np.array_equal(got, (np.arange(P // r) // m).astype(np.uint32)), (P, r, m)
+            ns = m
+        assert ns == 1
+    assert lengths > 300
