@@ -301,8 +301,14 @@ hipError_t launch_stft_mixed(const sgx_ctx *c, const void *tables, const float *
                                            (int)lds);
         if (e != hipSuccess) return e;
     }
-    // about one radix-4 butterfly per thread and stage
+    // about one radix-4 butterfly per thread and stage, and as many resident workgroups as the LDS image allows
+    // (2048 threads per CU): independent workgroups fill each other's barrier waits
     unsigned threads = ((c->P / 4 + 63) / 64) * 64;
+    const unsigned resident = (unsigned)((160 * 1024) / (lds ? lds : 1));
+    if (resident >= 2) {
+        const unsigned cap = (2048u / (resident > 8 ? 8 : resident)) / 64 * 64;
+        if (threads > cap) threads = cap;
+    }
     threads = threads > 1024u ? 1024u : (threads < 64u ? 64u : threads);
     const size_t max_chunk = 1u << 30;
     if (channels == 1 && !(c->cfg.flags & SGX_FLAG_INDEPENDENT_FRAMES)) {
