@@ -126,8 +126,9 @@ hipError_t launch_stft_generic(const sgx_ctx *c, const float *d_pcm, uint32_t ch
     p.half_scale = 0.5f;
     p.scale = 2.0f / (float)c->W;
     const size_t lds = (size_t)c->P * sizeof(float2);
-    // 16 waves per CU whatever the LDS image allows: 4 x 256 threads up to P = 4096, 2 x 512 at 8192, 1 x 1024 at 16384
-    const unsigned threads = c->P >= 16384 ? 1024u : (c->P >= 8192 ? 512u : 256u);
+    // workgroup size by measurement (tools/quick_bench.py --generic-sizes): about one radix-4 butterfly per thread and
+    // stage for short transforms, 16 waves per CU where the LDS image limits residency (2 x 512 at 8192, 1 x 1024 at 16384)
+    const unsigned threads = c->P >= 16384 ? 1024u : (c->P >= 8192 ? 512u : (c->P >= 2048 ? 256u : (c->P >= 1024 ? 128u : 64u)));
     if (lds > 64 * 1024) {  // per launch: the attribute is per device, and a process may hold contexts on several
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(stft_generic_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
