@@ -168,7 +168,8 @@ __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
     // the stores and the next transform's first pass (its row loads are already in flight); they drop to 0 once that
     // pass is in LDS.  A transform that is nearly done is finished first, its stores are issued earlier and the store
     // stream overlaps the other workgroups' arithmetic better: +6 % (mono), and with the intermediate steps 1 and 2 for
-    // the second pass +12 % for stereo input (same-device A/B; the steps cost mono 1 %).
+    // the second pass +12 % for stereo input (same-device A/B; the steps cost mono 1 %).  The fused pixel path holds
+    // priority 1 through its sample pass and 3 from its row pass on: +12 % over no priorities.
     for (unsigned long long job = job_begin; job < job_end; ++job) {
         if (MONO && PAIRING == kPairAdjacentRow && kSlideWindow && pending) {
             // this transform = the previous one moved on by two rows.  vmcnt counts in issue order: the two row
@@ -256,7 +257,8 @@ __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
         fft16(xr, xi);
 #endif
         if (job + 1 < job_end) fetch(job + 1, true);  // ahead of this transform's stores (see above)
-        __builtin_amdgcn_s_setprio(3);
+        if (RENDER) __builtin_amdgcn_s_setprio(1);  // the pixel passes are long: 3 only from the row pass (the pixel stores) on
+        else __builtin_amdgcn_s_setprio(3);
         lds_barrier();  // everyone has read image 2
         // partner exchange: publish q3 = 8..15 (the bins P-k of the kept half)
 #pragma unroll
@@ -324,6 +326,7 @@ __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
             uchar4 *rgba = reinterpret_cast<uchar4 *>(p.rgba);
             uchar4 *dst_a = rgba + ((size_t)(have_first ? f0 : 0) * p.pairs + p.pair) * (size_t)p.R;
             uchar4 *dst_b = rgba + ((size_t)f1 * p.pairs + p.pair) * (size_t)p.R;
+            __builtin_amdgcn_s_setprio(3);
             row_pass<MONO>(p, row_words, vbuf, dst_a, dst_b, have_first, have_second, thr, lut, tid);
         }
     }
