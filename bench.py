@@ -59,7 +59,7 @@ def parse():
 
 def load_traffic():
     """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/hbm_traffic.json), or None."""
-    path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    path = os.path.join(ROOT, "profiles", "hbm_traffic.json")  # the latest round's copy (profiles/rNN_hbm_traffic.json)
     try:
         with open(path) as f:
             return json.load(f)
