@@ -101,7 +101,7 @@ typedef struct sgx_info {
     uint32_t rows;            /* R */
     uint32_t sample_rate_u32; /* SampleRate(sample_rate as u32)      simple_spectrogram.rs:138 */
     uint32_t total_samples_per_column; /* sum over rows of magnitude_in's sample count */
-    uint32_t stft_kernel;     /* 0 = generic power-of-two, 1 = 4096-point wave-per-transform, 2 = 4096-point workgroup-per-transform (default), 3 = the same with packed (re, im) arithmetic, 4 = Bluestein chirp-z (any 2W), 5 = 16384-point workgroup-per-transform, 6 = mixed radix (2W = 2^a 3^b 5^c 7^d, e.g. the application's 4800 and 4410) */
+    uint32_t stft_kernel;     /* 0 = generic power-of-two, 1 = 4096-point wave-per-transform, 2 = 4096-point workgroup-per-transform (default), 3 = the same with packed (re, im) arithmetic, 4 = Bluestein chirp-z (any 2W), 5 = 16384-point workgroup-per-transform, 6 = mixed radix (2W = 2^a 3^b 5^c 7^d <= 20480, e.g. the application's 4800, 4410 and 19200) */
     uint32_t reserved;
     uint64_t mags_bytes_per_frame; /* pairs * M * 2 * 4 */
     uint64_t rgba_bytes_per_frame; /* pairs * R * 4     */

@@ -178,7 +178,7 @@ int sgx_create(const sgx_config *cfg, sgx_ctx **out_ctx)
     if (!pow2 && !sgx::bluestein_supported(c->W) && !sgx::mixed_supported(c->W))
         return bail(SGX_ERR_UNSUPPORTED,
                     "sgx_create: transform length 2W = " + std::to_string(c->P) +
-                        " is not supported by this build (up to 16384 with prime factors 2, 3, 5, 7 only, or any 2W with 3W - 1 <= 16384)");
+                        " is not supported by this build (up to 20480 with prime factors 2, 3, 5, 7 only, or any 2W with 3W - 1 <= 16384)");
     c->logP = 0;
     while ((1u << c->logP) < c->P) ++c->logP;
 

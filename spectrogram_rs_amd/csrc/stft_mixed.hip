@@ -118,7 +118,7 @@ __device__ __forceinline__ void stage(float2 *s, const Params &p, int st, uint32
     const uint32_t m = p.m[st], tws = p.tws[st], count = p.P / R;
     const float inv_m = p.inv_m[st];
     for (uint32_t b = tid; b < count; b += nt) {
-        const uint32_t blk = (uint32_t)(((float)b + 0.5f) * inv_m);  // b / m: exact for b < 2^14 (the error stays below 0.5 / m)
+        const uint32_t blk = (uint32_t)(((float)b + 0.5f) * inv_m);  // b / m: exact for every supported length (tests/test_host_logic.py)
         const uint32_t j = b - blk * m;
         float2 *base = s + blk * m * R + j;
         float2 x[R];
@@ -212,7 +212,8 @@ __global__ void __launch_bounds__(1024) stft_mixed_kernel(Params p)
 bool mixed_supported(uint32_t W)
 {
     uint32_t n = 2 * W;
-    if (W < 4 || n > 16384) return false;  // the transform lives in LDS: 8 bytes per point, 128 KB at most
+    if (W < 4 || n > 20480) return false;  // the transform lives in LDS: 8 bytes per point, all 160 KB of a CU at most
+                                           // (192 kHz x 0.05 s: 2W = 19 200)
     for (uint32_t f : {2u, 3u, 5u, 7u})
         while (n % f == 0) n /= f;
     return n == 1;

@@ -14,9 +14,9 @@ def draw(rng):
     kind = rng.choice(["pow2", "pow2", "odd", "smooth"])
     if kind == "pow2":
         W = int(2 ** rng.integers(2, 13))               # 4 .. 4096 (2W = the power-of-two kernels)
-    elif kind == "smooth":                              # 2W = 2^a 3^b 5^c 7^d up to 16384: the mixed-radix kernel
+    elif kind == "smooth":                              # 2W = 2^a 3^b 5^c 7^d up to 20480: the mixed-radix kernel
         W = 1
-        while W < 4 or W > 8192 or W & (W - 1) == 0:
+        while W < 4 or W > 10240 or W & (W - 1) == 0:
             W = int(2 ** rng.integers(0, 8) * 3 ** rng.integers(0, 5) * 5 ** rng.integers(0, 4) * 7 ** rng.integers(0, 3))
     else:
         W = int(rng.integers(5, 5400))                  # chirp-z kernel: any length with 3W - 1 <= 16384

@@ -176,20 +176,25 @@ def test_unsupported_length_is_reported_not_approximated(torch_cuda):
         engine(window_samples=16384)  # 2W = 32768 does not fit the LDS
     assert engine(window_samples=5000).info.stft_kernel == 6    # 10000 = 2^4 5^4: mixed radix
     assert engine(window_samples=6000).info.stft_kernel == 6    # 12000 = 2^5 3 5^3: past the chirp-z range, still served
+    assert engine(window_samples=10240).info.stft_kernel == 6   # 20480 = 2^12 5: the largest transform one CU's LDS holds
+    with pytest.raises(SgxError):
+        engine(window_samples=10290)                            # 20580 = 2^2 3 5 7^3: smooth but 164 640 B
     assert engine(window_samples=5003).info.stft_kernel == 4    # 10006 = 2 * 5003: chirp-z
 
 
 @pytest.mark.parametrize("chirp_z", [False, True])
 @pytest.mark.parametrize("sr,period,Wexp", [(48000.0, 0.05, 2400), (44100.0, 0.05, 2205), (48000.0, 0.01, 480), (8000.0, 0.0125, 100),
-                                            (22050.0, 0.05, 1102), (48000.0, 0.0386, 1852)])
+                                            (22050.0, 0.05, 1102), (48000.0, 0.0386, 1852), (192000.0, 0.05, 9600)])
 def test_duration_sized_windows_like_the_app(torch_cuda, mags_err, sr, period, Wexp, chirp_z):
     # FastFourierTransform::new(sample_rate, 0.05) (gpu_spectrogram.rs:323): W = 2400 / 2205, 2W not a power of two.
-    # Lengths with prime factors 2, 3, 5, 7 only (4800, 4410, 960, 200) take the mixed-radix kernel, the others
+    # Lengths with prime factors 2, 3, 5, 7 only (4800, 4410, 960, 200; 19 200 at 192 kHz) take the mixed-radix kernel, the others
     # (2204 = 4 * 19 * 29, 3704 = 8 * 463) the chirp-z kernel, which force_generic selects for the smooth ones too.
     torch = torch_cuda
     from spectrogram_rs_amd import SpectrogramEngine
+    if Wexp == 9600 and chirp_z:
+        pytest.skip("2W = 19 200 is beyond the chirp-z kernel (3W - 1 > 16384): mixed radix only")
     eng = SpectrogramEngine(sr, period=period, stride=2.0 / 1024, channels=2, force_generic=chirp_z)
-    smooth = Wexp in (2400, 2205, 480, 100)
+    smooth = Wexp in (2400, 2205, 480, 100, 9600)
     assert eng.W == Wexp == oracle.window_samples(sr, period) and eng.info.stft_kernel == (6 if smooth and not chirp_z else 4)
     Ht = eng.H
     assert Ht == oracle.hop_samples(sr, 2.0 / 1024)

@@ -84,7 +84,7 @@ def test_log_axis_matches_oracle_and_roundtrips():
 def test_mixed_radix_block_index_arithmetic_is_exact_for_every_supported_length():
     # csrc/stft_mixed.hip splits a butterfly number b into (block, offset) with one float multiply,
     # block = uint((b + 0.5f) * (1.0f / m)), instead of an integer division.  float32 arithmetic is the same on the
-    # host: every stage of every supported length (2W <= 16384 with prime factors 2, 3, 5, 7) is checked here.
+    # host: every stage of every supported length (2W <= 20480 with prime factors 2, 3, 5, 7) is checked here.
     def stages(P):
         n, out = P, []
         for f in (7, 5, 3):
@@ -100,7 +100,7 @@ def test_mixed_radix_block_index_arithmetic_is_exact_for_every_supported_length(
         return out if n == 1 else None
 
     lengths = 0
-    for P in range(8, 16385, 2):
+    for P in range(8, 20481, 2):
         radices = stages(P)
         if radices is None:
             continue
