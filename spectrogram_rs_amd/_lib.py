@@ -25,6 +25,7 @@ FLAG_WAVE_KERNEL = 2
 FLAG_NO_FUSED_RENDER = 4
 FLAG_PACKED_KERNEL = 8
 FLAG_INDEPENDENT_FRAMES = 16
+FLAG_LEGACY_16K = 32
 LIVE_MAGS, LIVE_MAGS_F16, LIVE_RGBA = 0, 1, 2
 LIVE_REFERENCE_SKIP = 1
 

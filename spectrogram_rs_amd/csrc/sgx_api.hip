@@ -94,7 +94,10 @@ int ensure_workspace(sgx_ctx *c, size_t frames)
 hipError_t run_stft(const sgx_ctx *c, const float *d_pcm, uint32_t channels, uint32_t pairs, size_t first, size_t n,
                     size_t total, float *d_mags)
 {
-    if (c->stft_kernel == 5 && (channels != 1 || !(c->cfg.flags & SGX_FLAG_INDEPENDENT_FRAMES)))
+    // W = 8192: the four-residue kernel for (l, r) streams; mono frame pairs are (measured) 14 % faster on the first design
+    if (c->stft_kernel == 5 && channels != 1)
+        return sgx::launch_stft_q16384(c, c->d_q16k, d_pcm, channels, pairs, first, n, total, d_mags);
+    if ((c->stft_kernel == 7 || c->stft_kernel == 5) && (channels != 1 || !(c->cfg.flags & SGX_FLAG_INDEPENDENT_FRAMES)))
         return sgx::launch_stft_wg16384(c, c->d_fast_16k, d_pcm, channels, pairs, first, n, total, d_mags);
     if (c->stft_kernel == 6) return sgx::launch_stft_mixed(c, c->d_mix, d_pcm, channels, pairs, first, n, total, d_mags);
     if (c->stft_kernel == 4) return sgx::launch_stft_bluestein(c, c->d_blu, d_pcm, channels, pairs, first, n, total, d_mags);
@@ -224,8 +227,13 @@ int sgx_create(const sgx_config *cfg, sgx_ctx **out_ctx)
         e = sgx::wg4096_init(c, &c->d_fast_wg);
         if (e != hipSuccess) return bail(SGX_ERR_HIP, std::string("sgx_create: tuned kernel tables: ") + hipGetErrorString(e));
         c->stft_kernel = (cfg->flags & SGX_FLAG_WAVE_KERNEL) ? 1 : ((cfg->flags & SGX_FLAG_PACKED_KERNEL) ? 3 : 2);
-    } else if (!(cfg->flags & SGX_FLAG_FORCE_GENERIC) && sgx::wg16384_supported(c)) {
+    } else if (!(cfg->flags & SGX_FLAG_FORCE_GENERIC) && (cfg->flags & SGX_FLAG_LEGACY_16K) && sgx::wg16384_supported(c)) {
         e = sgx::wg16384_init(c, &c->d_fast_16k);
+        if (e != hipSuccess) return bail(SGX_ERR_HIP, std::string("sgx_create: 16384-point kernel tables: ") + hipGetErrorString(e));
+        c->stft_kernel = 7;
+    } else if (!(cfg->flags & SGX_FLAG_FORCE_GENERIC) && sgx::q16384_supported(c)) {
+        e = sgx::q16384_init(c, &c->d_q16k);
+        if (e == hipSuccess) e = sgx::wg16384_init(c, &c->d_fast_16k);  // serves mono frame pairs and sgx_process_one's mono contexts
         if (e != hipSuccess) return bail(SGX_ERR_HIP, std::string("sgx_create: 16384-point kernel tables: ") + hipGetErrorString(e));
         c->stft_kernel = 5;
     }
@@ -246,6 +254,8 @@ void sgx_destroy(sgx_ctx *c)
     c->d_mix = nullptr;
     sgx::wg16384_destroy(c->d_fast_16k);
     c->d_fast_16k = nullptr;
+    sgx::q16384_destroy(c->d_q16k);
+    c->d_q16k = nullptr;
     void *ptrs[] = {c->d_window, c->d_twiddle, c->d_rows, c->d_samples, c->d_lut_thr, c->d_alpha_thr,
                     c->d_lut_rgba, c->d_t_thr, c->d_band_rows, c->d_band_samples, c->d_levels, c->d_ws_mags, c->d_one_in, c->d_one_out, c->d_cksum};
     for (void *p : ptrs)

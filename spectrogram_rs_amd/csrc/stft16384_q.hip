@@ -1,0 +1,581 @@
+// stft16384_q.hip -- tuned STFT for W = 8192 (P = 16384), second design: the transform is cut into FOUR independent
+// 4096-point transforms, run two at a time by a 512-thread workgroup, two workgroups per CU.
+// (BASELINE config 4: 16384-point, hop 512, 8 interleaved channels = 4 (l, r) pairs per hop position.)
+//
+// Replaces FastFourierTransform::process (fft.rs:43-99) + the hop loop (audio_transform.rs:34-42).
+//
+// Why.  The first design (stft16384_wg.hip) holds the whole padded transform in LDS: 141 KB, one 1024-thread workgroup
+// per CU, all 16 waves in the same phase, four LDS round trips per transform -- 0.19 of the HBM roofline.  The zero
+// padding (fft.rs:65-69: only n < W is non-zero) makes the decimation by 4 of the OUTPUT cheap:
+//
+//     F[4 j + c] = sum_{n' < 4096} u_c[n'] w_4096^{n' j},
+//     u_c[n'] = (z[n'] + (-i)^c z[n' + 4096]) w_16384^{c n'},     z[n] = (l[n] + i r[n]) hann[n]
+//
+// (the terms n' + 8192, n' + 12288 are the padding).  The four residues c are four independent 4096-point
+// transforms -- the size the headline kernel (stft4096_wg.hip) is tuned for -- and the L/R split (fft.rs:81-89)
+// pairs bin k with P - k, i.e. residue c with (4 - c) mod 4: 0 and 2 with themselves, 1 with 3.
+//
+// Shape.  512 threads = 256 lane PAIRS.  Lane pair `col` (0..255) plays the part of one thread of the 4096-point
+// kernel; the even lane runs residue c = S, the odd lane residue c = S + 2, for S = 0 (even bins), then S = 1 (odd
+// bins).  Lane b of a pair loads the samples n = col + 256 a + 4096 b (a < 16: coalesced 8 bytes per pair) and the
+// butterfly z[n'] +- (-i)^S z[n' + 4096] is one DPP multiply-add per component (quad_perm [1,0,3,2], the sign a
+// per-lane constant): no sample is loaded twice inside a pass, nothing crosses LDS for the decimation.  The twiddle
+// w_16384^{c n'} = w_16384^{c col} w_64^{c a} is split: the 64 values w_64^{c a} (with the scale 1 / W and the
+// butterfly's sign) sit in LDS, the per-column factor rides on the pass-1 twiddles (table T_c[q1][col] =
+// w_16384^{col (4 q1 + c)}, read per pass: no twiddle register lives longer than its pass).  Then three in-register
+// radix-16 passes with two LDS transposes and the half-spectrum partner exchange, exactly the 4096-point kernel's,
+// the two residues interleaved element by element in LDS (address = 2 index + b: every access pattern of that kernel
+// stays conflict-free with twice the stride).  After S = 1 a lane holds bins k = 4 j + 2 b and k + 1 of its eight j: one
+// 16-byte store per (lane, j), fully coalesced; the S = 0 magnitudes wait in 16 registers meanwhile.
+// LDS: 70 KB + 2 KB of twiddles per workgroup, two workgroups per CU = 4 waves per SIMD in two independent phases.
+//
+// Interleaved multi-channel input ([n][C], C > 2) is de-interleaved into per-pair planes first (one pass, its traffic
+// reported): a pair's samples are 8 bytes out of every 4 C, and gathering them per transform costs every transform
+// a 128-byte line for each 32 useful bytes.
+#include <type_traits>
+
+#if !defined(Q_HOLD) && !defined(Q_NO_HOLD)
+#define Q_NO_HOLD 1   // see the store loop
+#endif
+#ifndef Q_NO_PRIO
+#define Q_PRIO 1
+#define Q_PREFETCH_LATE 1
+#endif
+
+#include "sgx_internal.hpp"
+
+namespace sgx {
+
+namespace q16k {
+
+typedef float f2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float cl_fma(float a, float c, float u) { return fmaf(a, c, u); }
+__device__ __forceinline__ f2v cl_fma(f2v a, float c, f2v u) { return __builtin_elementwise_fma(a, f2v{c, c}, u); }
+
+#include "fft_codelets.inc"
+
+constexpr int kW = 8192, kP = 16384, kM = 8191;
+constexpr int kS1 = 272;                 // row stride of the pass-1 -> pass-2 image [q1][col]   (as stft4096_wg.hpp)
+constexpr int kS2 = 257;                 // row stride of the pass-2 -> pass-3 image [t0][q1 + 16 q2]
+constexpr int kImg = 16 * kS1;           // indices per residue
+constexpr int kBufComplex = 2 * kImg;    // 8704 complex = 69 632 B, the two residues interleaved: (index, b) at 2 index + b
+constexpr size_t kLdsBytes = (size_t)(kBufComplex + 256 + 64) * sizeof(float2);
+
+struct Params {
+    const float *pcm;        // MONO: [n] floats; else per-pair planes of (l, r): plane p starts at pcm + p * plane_floats
+    size_t plane_floats;
+    long long sample_base;   // absolute sample index of pcm[0] (the de-interleaved workspace holds a sub-range)
+    const float2 *T;         // [2][8][512][2]  pass S, lane tid = 2 col + b (residue c = S + 2 b): [S][q1 / 2][tid][q1 % 2] = w_16384^{col (4 q1 + c)}
+    const float2 *tw2;       // [16][16]   w_256^{t0 q2} at [q2][t0]
+    const float2 *tw0;       // [4][16]    sign_c / W * w_64^{c a}   (sign_2 = -1: the butterfly leaves -(z0 - z1) in the odd lane)
+    const float *win4;       // [4][512][4]  the Hann table of fft.rs:61 as lanes read it: [a / 4][tid][a % 4] = hann[col + 256 a + 4096 b]
+    float *mags;
+    unsigned long long first_frame, n_frames, total_frames, pair_base, n_jobs;
+    uint32_t H, pairs;
+};
+
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+__device__ __forceinline__ float2 cmulf(float2 a, float2 b)
+{
+    return make_float2(fmaf(a.x, b.x, -(a.y * b.y)), fmaf(a.x, b.y, a.y * b.x));
+}
+// the value of the other lane of the pair (lanes 2j <-> 2j+1)
+__device__ __forceinline__ float pair_swap(float v)
+{
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, true));
+}
+
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// Every global access goes through a raw buffer descriptor: a wave-uniform base (4 SGPRs) + ONE 32-bit lane offset +
+// a scalar offset.  Per-lane 64-bit pointers cost this kernel the handful of registers that decide between zero
+// spills and a dozen -- and a spill RELOAD is a vector-memory load: issued behind the magnitude stores it drains the
+// whole store stream (vmcnt retires in order) and the software pipeline with it.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void *base)
+{
+    const unsigned long long a = (unsigned long long)base;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((unsigned long long)hi << 32) | lo), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ float2 ld_f2(__amdgpu_buffer_rsrc_t r, int voff, int soff)
+{
+    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+    return make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
+}
+__device__ __forceinline__ u32x4 ld_u4(__amdgpu_buffer_rsrc_t r, int voff, int soff)
+{
+    return __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+}
+__device__ __forceinline__ float ld_f1(__amdgpu_buffer_rsrc_t r, int voff, int soff)
+{
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ void st_f2(__amdgpu_buffer_rsrc_t r, int voff, int soff, float a, float b)
+{
+    __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(a), __float_as_uint(b)}, r, voff, soff, 0);
+}
+__device__ __forceinline__ void st_f4(__amdgpu_buffer_rsrc_t r, int voff, int soff, float a, float b, float c, float d)
+{
+    __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(a), __float_as_uint(b), __float_as_uint(c), __float_as_uint(d)}, r, voff, soff, 0);
+}
+#ifdef Q_ABL_NOSTORE
+#define Q_STORE_OK(v) ((v) == 12345.678f)   // ablation builds: (practically) never true, but the value stays live
+#else
+#define Q_STORE_OK(v) true
+#endif
+
+
+template <bool MONO>
+__global__ void __launch_bounds__(512, 4) stft16384_q_kernel(Params p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2 *buf = reinterpret_cast<float2 *>(smem_raw);
+    float2 *tw2 = buf + kBufComplex;
+
+    float2 *tw0 = tw2 + 256;
+    if (threadIdx.x < 256) tw2[threadIdx.x] = p.tw2[threadIdx.x];
+    if (threadIdx.x < 64) tw0[threadIdx.x] = p.tw0[threadIdx.x];
+    // Lane roles are re-derived from the thread index at the head of every phase (two or three integer instructions)
+    // instead of living in registers for the whole kernel: the dozen lane constants (sample offset, table offset,
+    // five LDS bases, output offset, the butterfly's sign) are what pushed this kernel over 128 registers.
+    auto lane = [&]() { int t = threadIdx.x; asm volatile("" : "+v"(t)); return t; };
+    __syncthreads();
+
+    // Software pipeline: the samples (and window factors) of the NEXT pass are requested while this pass is between its
+    // third FFT and its partner exchange, i.e. before this pass's stores: vmcnt retires in issue order, so a load
+    // issued behind the stores would wait for every one of them to reach memory (measured on the first version of this
+    // kernel, where the loads came after: no overlap at all between the memory phases and the arithmetic -- the launch
+    // took the SUM of its load time, its store time and its compute time).
+    float pl[16], pr[16], pw[16];
+    struct JobIn { const float *base; bool data_second; };   // base: wave-uniform
+    auto job_in = [&](unsigned long long job) {
+        JobIn j{nullptr, true};
+        if (MONO) {
+            const unsigned long long f = 2 * (p.pair_base + job);
+            j.data_second = f + 1 < p.total_frames;
+            j.base = p.pcm + ((long long)(f * p.H) - p.sample_base);
+        } else {
+            const unsigned long long hop = job / p.pairs;
+            const uint32_t pair = (uint32_t)(job - hop * p.pairs);
+            j.base = p.pcm + (size_t)pair * p.plane_floats + 2 * ((long long)((p.first_frame + hop) * p.H) - p.sample_base);
+        }
+        return j;
+    };
+    const int second_off = MONO ? (int)(p.H * 4) : 0;   // mono: the pair's second frame starts H samples on
+    auto prefetch = [&](const JobIn &j) {
+        // an opaque zero offset: the two passes of a job read the same addresses, and the compiler would otherwise
+        // carry the first pass's 48 values across it in registers instead of loading them again (from L1 / L2)
+        int opaque0 = 0;
+        asm volatile("" : "+s"(opaque0));
+        const __amdgpu_buffer_rsrc_t rs = uniform_rsrc(j.base + opaque0);
+        const int sec = j.data_second ? second_off : 0;
+        const int t = lane(), n0 = (t >> 1) + 4096 * (t & 1);   // this lane's samples: n0 + 256 a
+        const int n0_4 = 4 * n0, n0_8 = 8 * n0;                 // byte offsets into a mono / an (l, r) stream and the window
+#pragma unroll
+        for (int a = 0; a < 16; ++a) {
+#ifdef Q_ABL_NOLOAD
+            pl[a] = (float)(a + 1); pr[a] = (float)t;
+            (void)n0_4; (void)n0_8; (void)rs; (void)sec;
+#else
+            if (MONO) {
+                pl[a] = ld_f1(rs, n0_4, 1024 * a);
+                pr[a] = ld_f1(rs, n0_4, 1024 * a + sec);
+            } else {
+                const float2 v = ld_f2(rs, n0_8, 2048 * a);
+                pl[a] = v.x; pr[a] = v.y;
+            }
+#endif
+        }
+    };
+    // The Hann factors of this lane are the same for every job and both passes: 16 registers for the life of the
+    // workgroup.  (Every vector-memory instruction costs the CU's address / tag path ~16 cycles whatever its width --
+    // measured: the first versions of this kernel were bound by TA / TCP busy time, not by bytes and not by arithmetic --
+    // so tables are laid out for 16-byte lane reads and nothing is loaded twice that can stay.)
+    {
+        const __amdgpu_buffer_rsrc_t rw = uniform_rsrc(p.win4);
+        const int t = lane();
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const u32x4 w = ld_u4(rw, 16 * t, g * (512 * 16));
+            pw[4 * g] = __uint_as_float(w.x); pw[4 * g + 1] = __uint_as_float(w.y);
+            pw[4 * g + 2] = __uint_as_float(w.z); pw[4 * g + 3] = __uint_as_float(w.w);
+        }
+    }
+
+    JobIn cur = job_in(blockIdx.x < p.n_jobs ? blockIdx.x : 0);
+    if (blockIdx.x < p.n_jobs) prefetch(cur);
+    for (unsigned long long job = blockIdx.x; job < p.n_jobs; job += gridDim.x) {
+        long long f0, f1;
+        bool have_first = true, have_second = true;
+        const bool data_second = cur.data_second;
+        uint32_t pair = 0;
+        if (MONO) {
+            f0 = (long long)(2 * (p.pair_base + job)) - (long long)p.first_frame;
+            f1 = f0 + 1;
+            have_first = f0 >= 0;
+            have_second = f1 < (long long)p.n_frames;
+        } else {
+            f0 = (long long)(job / p.pairs);
+            f1 = f0;
+            pair = (uint32_t)(job - (unsigned long long)f0 * p.pairs);
+        }
+        const bool more = job + gridDim.x < p.n_jobs;
+        const JobIn nxt = job_in(more ? job + gridDim.x : job);
+
+#ifndef Q_NO_HOLD
+        float mlE[8], mrE[8];  // the even bins' magnitudes wait here for the odd bins'
+#endif
+        // (a real loop, not two inlined copies: code size, and nothing of the first pass may stay live into the second)
+#pragma nounroll
+        for (int S = 0; S < 2; ++S) {
+            // ---- decimation by 4 of the output (see the head of the file)
+            //      S = 0: d = v + sigma swap(v):      even lane z0 + z1 = t_0, odd lane z1 - z0 = -t_2
+            //      S = 1: w = v (even), i v (odd);  d = w - sigma swap(w):  even lane z0 - i z1 = t_1, odd lane z0 + i z1 = t_3
+            float xr[16], xi[16];
+            {
+            const int b = lane() & 1;
+            const float sigma = b ? -1.0f : 1.0f;
+            const float2 *tw0c = tw0 + (S + 2 * b) * 16;
+            auto front = [&](auto is_odd_pass) {
+                constexpr bool ODD = decltype(is_odd_pass)::value;
+#pragma unroll
+                for (int a = 0; a < 16; ++a) {
+                    const float vr = pl[a] * pw[a], vi = (MONO && !data_second) ? 0.0f : pr[a] * pw[a];   // Hann (fft.rs:53-63)
+                    float dr, di;
+                    if (!ODD) {
+                        dr = fmaf(pair_swap(vr), sigma, vr);
+                        di = fmaf(pair_swap(vi), sigma, vi);
+                    } else {
+                        const float wr = b ? -vi : vr, wi = b ? vr : vi;
+                        dr = fmaf(pair_swap(wr), -sigma, wr);
+                        di = fmaf(pair_swap(wi), -sigma, wi);
+                    }
+                    const float2 t = tw0c[a];
+                    xr[a] = fmaf(dr, t.x, -(di * t.y));
+                    xi[a] = fmaf(dr, t.y, di * t.x);
+                }
+            };
+            if (S == 0) front(std::false_type{});
+            else front(std::true_type{});
+            }
+            float2 tw1[16];
+            {
+                const __amdgpu_buffer_rsrc_t rT = uniform_rsrc(p.T);
+                const int lane_T = 16 * lane();
+#pragma unroll
+                for (int g = 0; g < 8; ++g) {
+#ifdef Q_ABL_NOT
+                    tw1[2 * g] = make_float2(1.0f, 0.25f * (float)g); tw1[2 * g + 1] = make_float2(1.0f, 0.125f * (float)g);
+                    (void)rT; (void)lane_T;
+#else
+                    const u32x4 w = ld_u4(rT, lane_T, (S * 8 + g) * (512 * 16));
+                    tw1[2 * g] = make_float2(__uint_as_float(w.x), __uint_as_float(w.y));
+                    tw1[2 * g + 1] = make_float2(__uint_as_float(w.z), __uint_as_float(w.w));
+#endif
+                }
+            }
+
+            // ---- pass 1: thread col: 16-point FFT over a -> q1, twiddle w_4096^{col q1} w_16384^{c col}
+            fft16(xr, xi);
+            lds_barrier();  // the previous pass's partner reads are complete
+            {
+                float2 *w1 = buf + lane();   // element (index, b) at 2 index + b = 2 (q kS1 + col) + b = 2 q kS1 + tid
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int pos = FFT16_OUT[q];
+                    const float2 v = make_float2(xr[pos], xi[pos]);
+                    w1[2 * q * kS1] = cmulf(v, tw1[q]);
+                }
+            }
+#ifdef Q_PRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
+            lds_barrier();
+
+            // ---- pass 2: thread (q1, t0), col = t0 + 16 t1: FFT16 over t1 -> q2, twiddle w_256^{t0 q2}
+            const int t_2 = lane(), q1_2 = t_2 >> 5, t0_2 = (t_2 >> 1) & 15, b_2 = t_2 & 1;   // pass-2 role
+#pragma unroll
+            for (int t1 = 0; t1 < 16; ++t1) {
+                const float2 v = buf[2 * (q1_2 * kS1 + t0_2 + 16 * t1) + b_2];
+                xr[t1] = v.x; xi[t1] = v.y;
+            }
+            // the pass's twiddles are requested with its data (the pass-1 twiddle registers are free again): fetched one
+            // by one behind the FFT, each would cost the wave an LDS round trip in front of its store
+#pragma unroll
+            for (int q2 = 1; q2 < 16; ++q2) tw1[q2] = tw2[q2 * 16 + t0_2];
+            fft16(xr, xi);
+            lds_barrier();  // everyone has read image 1
+#pragma unroll
+            for (int q2 = 0; q2 < 16; ++q2) {
+                const int pos = FFT16_OUT[q2];
+                const float2 v = make_float2(xr[pos], xi[pos]);
+                buf[2 * (t0_2 * kS2 + q1_2 + 16 * q2) + b_2] = q2 == 0 ? v : cmulf(v, tw1[q2]);
+            }
+            lds_barrier();
+
+            // ---- pass 3: thread col = q1 + 16 q2: FFT16 over t0 -> q3; j = col + 256 q3, bin k = 4 j + c
+            {
+                const float2 *r3 = buf + lane();
+#pragma unroll
+                for (int t0 = 0; t0 < 16; ++t0) {
+                    const float2 v = r3[2 * t0 * kS2];
+                    xr[t0] = v.x; xi[t0] = v.y;
+                }
+            }
+            fft16(xr, xi);
+#ifdef Q_PRIO
+            __builtin_amdgcn_s_setprio(3);  // a pass that is nearly done goes first: its stores and next loads start earlier (as stft4096_wg.hip)
+#endif
+            // the next pass's samples: the same job's for S = 0, the next job's for S = 1 (ahead of the stores below)
+#ifndef Q_PREFETCH_LATE
+            if (S == 0) prefetch(cur);
+            else if (more) prefetch(nxt);
+#endif
+            lds_barrier();  // everyone has read image 2
+            // partner exchange: publish q3 = 8..15 (the bins P - k of the kept half)
+            {
+                float2 *wp = buf + lane();
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int pos = FFT16_OUT[8 + j];
+                    wp[2 * j * 256] = make_float2(xr[pos], xi[pos]);
+                }
+            }
+#ifdef Q_PREFETCH_LATE
+            // (requested once the published half of the spectrum has left its 16 registers)
+            if (S == 0) prefetch(cur);
+            else if (more) prefetch(nxt);
+#endif
+            lds_barrier();
+
+            // ---- split + magnitude (fft.rs:81-98).  P - k for k = 4 j + c is 4 j' + (4 - c) % 4 with
+            //      c = 0: j' = 4096 - j (lane pair 256 - col, q3' = 15 - q3; col 0: itself, one row up, as stft4096_wg.hip)
+            //      c > 0: j' = 4095 - j (lane pair 255 - col, q3' = 15 - q3); residues 1 and 3 trade places
+            const int tid = lane(), col = tid >> 1, b = tid & 1;
+            const int pcol = (S == 0 && b == 0) ? (col == 0 ? 256 : 256 - col) : 255 - col;
+            const int pb = S == 0 ? b : 1 - b;
+            const float2 *pp = buf + 2 * pcol + pb;
+#ifdef Q_ABL_CONTIG
+            const int lane_out = 8 * tid + S * 4096 - 8 * S;   // TIMING ONLY: a wrong, contiguous layout
+#else
+            const int lane_out = 16 * tid;   // bin k = 4 (col + 256 q3) + 2 b (+ S) lives at byte 8 (k - 1) of its row
+#endif
+            // rows: bin k lives at byte 8 (k - 1) of its row, so the descriptors start 8 bytes before the rows
+            const __amdgpu_buffer_rsrc_t r0 = uniform_rsrc(reinterpret_cast<const char *>(p.mags + (((size_t)(have_first ? f0 : 0) * p.pairs + pair) * (size_t)kM) * 2) - 8);
+            const __amdgpu_buffer_rsrc_t r1 = uniform_rsrc(reinterpret_cast<const char *>(p.mags + (((size_t)f1 * p.pairs + pair) * (size_t)kM) * 2) - 8);
+            float ml[8], mr[8];
+#pragma unroll
+            for (int q3 = 0; q3 < 8; ++q3) {
+                const int pos = FFT16_OUT[q3];
+                const float2 pv = pp[2 * (7 - q3) * 256];
+                const float ar = xr[pos], ai = xi[pos];
+                const float pr_ = ar + pv.x, pi_ = ai - pv.y;   // a + conj(b) = 2 L^
+                const float qr_ = ar - pv.x, qi_ = ai + pv.y;   // a - conj(b) = 2i R^
+                ml[q3] = __builtin_amdgcn_sqrtf(fmaf(pr_, pr_, pi_ * pi_));  // the scale 1 / W rides on tw0
+                mr[q3] = __builtin_amdgcn_sqrtf(fmaf(qr_, qr_, qi_ * qi_));
+#ifdef Q_NO_HOLD
+                // every pass stores its own bins: 8 bytes per lane at a 16-byte stride; the other half of each line
+                // follows from the other pass and L2 merges them.  (Holding the even bins' magnitudes for one 16-byte
+                // store per lane costs 16 registers the software pipeline needs: with them the kernel spills, and a
+                // spill reload behind the stores drains the store stream.)
+                const bool dc = q3 == 0 && S == 0 && tid == 0;   // k = 0 (DC) is not an output (fft.rs:81)
+                if (!dc && Q_STORE_OK(ml[q3])) {
+                    if (MONO) {
+                        if (have_first) st_f2(r0, lane_out, 8192 * q3 + 8 * S, ml[q3], ml[q3]);
+                        if (have_second) st_f2(r1, lane_out, 8192 * q3 + 8 * S, mr[q3], mr[q3]);
+                    } else {
+                        st_f2(r0, lane_out, 8192 * q3 + 8 * S, ml[q3], mr[q3]);
+                    }
+                }
+#endif
+            }
+#ifndef Q_NO_HOLD
+            if (S == 0) {
+#pragma unroll
+                for (int q3 = 0; q3 < 8; ++q3) { mlE[q3] = ml[q3]; mrE[q3] = mr[q3]; }
+            } else {
+                // ---- store: bins k = 4 j + 2 b (even, from S = 0) and k + 1 (odd), j = col + 256 q3: 16 bytes per lane,
+                //      consecutive lanes consecutive addresses.  k = 0 (DC) is not an output (fft.rs:81).
+#pragma unroll
+                for (int q3 = 0; q3 < 8; ++q3) {
+                    if (!Q_STORE_OK(ml[q3])) continue;
+                    const bool dc = q3 == 0 && tid == 0;
+                    if (MONO) {
+                        if (!dc) {
+                            if (have_first) st_f4(r0, lane_out, 8192 * q3, mlE[q3], mlE[q3], ml[q3], ml[q3]);
+                            if (have_second) st_f4(r1, lane_out, 8192 * q3, mrE[q3], mrE[q3], mr[q3], mr[q3]);
+                        } else {
+                            if (have_first) st_f2(r0, lane_out, 8, ml[q3], ml[q3]);
+                            if (have_second) st_f2(r1, lane_out, 8, mr[q3], mr[q3]);
+                        }
+                    } else {
+                        if (!dc) st_f4(r0, lane_out, 8192 * q3, mlE[q3], mrE[q3], ml[q3], mr[q3]);
+                        else st_f2(r0, lane_out, 8, ml[q3], mr[q3]);
+                    }
+                }
+            }
+#endif
+        }
+        cur = nxt;
+    }
+}
+
+// [n][C] interleaved -> per-pair planes of (l, r): plane p holds samples [first, first + n) of channels (2p, 2p + 1)
+__global__ void __launch_bounds__(256) deinterleave_pairs_kernel(const float *pcm, float *planes, size_t plane_floats,
+                                                                 size_t first, size_t n, uint32_t C, uint32_t pairs)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float2 *row = reinterpret_cast<const float2 *>(pcm + (first + i) * C);
+        for (uint32_t pr = 0; pr < pairs; ++pr)
+            reinterpret_cast<float2 *>(planes + (size_t)pr * plane_floats)[i] = row[pr];
+    }
+}
+
+struct TablesQ {
+    float2 *d_T = nullptr, *d_tw2 = nullptr, *d_tw0 = nullptr;
+    float *d_win4 = nullptr;
+    float *d_planes = nullptr;   // de-interleave workspace, grown on demand
+    size_t planes_floats = 0;
+};
+
+}  // namespace q16k
+
+bool q16384_supported(const sgx_ctx *c)
+{
+    // (l, r) pairs are moved as 8-byte words: the stream must be mono or have an even channel count
+    return c->W == q16k::kW && (c->C == 1 || (c->C & 1) == 0);
+}
+
+hipError_t q16384_init(sgx_ctx *c, void **out)
+{
+    using namespace q16k;
+    auto *t = new TablesQ();
+    auto unit = [](unsigned long long idx, unsigned long long N, double &cs, double &sn) {
+        idx %= N;
+        const double ang = -2.0 * M_PI * (double)idx / (double)N;
+        cs = cos(ang); sn = sin(ang);
+        if (idx == 0) { cs = 1.0; sn = 0.0; }
+        if (4 * idx == N) { cs = 0.0; sn = -1.0; }
+        if (2 * idx == N) { cs = -1.0; sn = 0.0; }
+        if (4 * idx == 3 * N) { cs = 0.0; sn = 1.0; }
+    };
+    std::vector<float2> T(4 * 16 * 256), tw2(256), tw0(64);
+    std::vector<float> win4((size_t)kW);
+    double cs, sn;
+    for (int S = 0; S < 2; ++S)
+        for (int q = 0; q < 16; ++q)
+            for (int tid = 0; tid < 512; ++tid) {
+                const int col = tid >> 1, cc = S + 2 * (tid & 1);
+                unit((unsigned long long)col * (4 * q + cc), kP, cs, sn);
+                T[(((size_t)S * 8 + q / 2) * 512 + tid) * 2 + (q & 1)] = make_float2((float)cs, (float)sn);
+            }
+    for (int a = 0; a < 16; ++a)
+        for (int tid = 0; tid < 512; ++tid)
+            win4[(((size_t)(a / 4)) * 512 + tid) * 4 + (a & 3)] = c->tab.window[(tid >> 1) + 256 * a + 4096 * (tid & 1)];
+    for (int q = 0; q < 16; ++q)
+        for (int t0 = 0; t0 < 16; ++t0) { unit((unsigned long long)t0 * q, 256, cs, sn); tw2[q * 16 + t0] = make_float2((float)cs, (float)sn); }
+    // sign_c * 2^-13 * w_64^{c a}: the scale (hypot / 2) * (2 / W) = 1 / W is a power of two and commutes with every rounding
+    for (int cc = 0; cc < 4; ++cc)
+        for (int a = 0; a < 16; ++a) {
+            unit((unsigned long long)cc * a, 64, cs, sn);
+            const double sc = (cc == 2 ? -1.0 : 1.0) / (double)kW;
+            tw0[cc * 16 + a] = make_float2((float)(sc * cs), (float)(sc * sn));
+        }
+    auto up = [](float2 **dst, const std::vector<float2> &v) {
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(dst), v.size() * sizeof(float2));
+        if (e == hipSuccess) e = hipMemcpy(*dst, v.data(), v.size() * sizeof(float2), hipMemcpyHostToDevice);
+        return e;
+    };
+    hipError_t e = up(&t->d_T, T);
+    if (e == hipSuccess) e = up(&t->d_tw2, tw2);
+    if (e == hipSuccess) e = up(&t->d_tw0, tw0);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&t->d_win4), win4.size() * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(t->d_win4, win4.data(), win4.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(stft16384_q_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(stft16384_q_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
+    if (e != hipSuccess) {
+        q16384_destroy(t);
+        return e;
+    }
+    *out = t;
+    return hipSuccess;
+}
+
+void q16384_destroy(void *tables)
+{
+    auto *t = static_cast<q16k::TablesQ *>(tables);
+    if (!t) return;
+    if (t->d_T) (void)hipFree(t->d_T);
+    if (t->d_tw2) (void)hipFree(t->d_tw2);
+    if (t->d_tw0) (void)hipFree(t->d_tw0);
+    if (t->d_win4) (void)hipFree(t->d_win4);
+    if (t->d_planes) (void)hipFree(t->d_planes);
+    delete t;
+}
+
+hipError_t launch_stft_q16384(const sgx_ctx *c, void *tables, const float *d_pcm, uint32_t channels, uint32_t pairs,
+                              size_t first_frame, size_t n_frames, size_t total_frames, float *d_mags)
+{
+    using namespace q16k;
+    if (n_frames == 0) return hipSuccess;
+    auto *t = static_cast<TablesQ *>(tables);
+    int n_cu = 256;
+    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device);
+    Params p{};
+    p.T = t->d_T;
+    p.tw2 = t->d_tw2;
+    p.tw0 = t->d_tw0;
+    p.win4 = t->d_win4;
+    p.mags = d_mags;
+    p.first_frame = first_frame;
+    p.n_frames = n_frames;
+    p.total_frames = total_frames;
+    p.H = c->H;
+    p.pairs = pairs;
+    const bool mono = channels == 1 && !(c->cfg.flags & SGX_FLAG_INDEPENDENT_FRAMES);
+    if (channels == 1 && !mono) return hipErrorNotSupported;  // caller falls back to the generic kernel
+    p.pair_base = mono ? first_frame / 2 : 0;
+    p.n_jobs = mono ? (first_frame + n_frames + 1) / 2 - first_frame / 2 : (unsigned long long)n_frames * pairs;
+    if (channels > 2) {
+        // per-pair planes of the sample range these frames read: [first_frame H, (first_frame + n - 1) H + W)
+        const size_t first_sample = first_frame * (size_t)c->H;
+        const size_t n_samp = (n_frames - 1) * (size_t)c->H + kW;
+        const size_t plane = (2 * n_samp + 63) & ~(size_t)63;  // floats per plane, 256-byte multiples
+        if (plane * pairs > t->planes_floats) {
+            hipError_t e = hipStreamSynchronize(c->stream);  // a previous launch may still read the old planes
+            if (e != hipSuccess) return e;
+            if (t->d_planes) { (void)hipFree(t->d_planes); t->d_planes = nullptr; t->planes_floats = 0; }
+            e = hipMalloc(reinterpret_cast<void **>(&t->d_planes), plane * pairs * sizeof(float));
+            if (e != hipSuccess) return e;
+            t->planes_floats = plane * pairs;
+        }
+        const unsigned blocks = (unsigned)std::min<size_t>((n_samp + 255) / 256, (size_t)n_cu * 16);
+        hipLaunchKernelGGL(deinterleave_pairs_kernel, dim3(blocks), dim3(256), 0, c->stream, d_pcm, t->d_planes, plane, first_sample,
+                           n_samp, channels, pairs);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        p.pcm = t->d_planes;
+        p.plane_floats = plane;
+        p.sample_base = (long long)first_sample;
+    } else {
+        p.pcm = d_pcm;
+        p.plane_floats = 0;
+        p.sample_base = 0;
+    }
+    // persistent workgroups, two per CU (72 KB of LDS each); jobs are dealt round-robin in output-row order
+    unsigned long long blocks = (unsigned long long)n_cu * 2;
+    if (blocks > p.n_jobs) blocks = p.n_jobs;
+    const dim3 grid((unsigned)blocks), block(512);
+    if (mono) hipLaunchKernelGGL((stft16384_q_kernel<true>), grid, block, kLdsBytes, c->stream, p);
+    else hipLaunchKernelGGL((stft16384_q_kernel<false>), grid, block, kLdsBytes, c->stream, p);
+    return hipGetLastError();
+}
+
+}  // namespace sgx

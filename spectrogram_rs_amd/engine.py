@@ -21,7 +21,7 @@ class SpectrogramEngine:
                  interp: int = _lib.INTERP_CUBIC, lut_index_mode: int = _lib.LUT_FLOOR_N,
                  device: Optional[int] = None, force_generic: bool = False, gradient: Optional[str] = None,
                  wave_kernel: bool = False, fused_render: bool = True, packed_kernel: bool = False,
-                 independent_frames: bool = False):
+                 independent_frames: bool = False, legacy_16k: bool = False):
         import torch
 
         self._lib = _lib.load()
@@ -42,7 +42,7 @@ class SpectrogramEngine:
         cfg.device = -1 if device is None else int(device)
         cfg.flags = (_lib.FLAG_FORCE_GENERIC if force_generic else 0) | (_lib.FLAG_WAVE_KERNEL if wave_kernel else 0) \
             | (0 if fused_render else _lib.FLAG_NO_FUSED_RENDER) | (_lib.FLAG_PACKED_KERNEL if packed_kernel else 0) \
-            | (_lib.FLAG_INDEPENDENT_FRAMES if independent_frames else 0)
+            | (_lib.FLAG_INDEPENDENT_FRAMES if independent_frames else 0) | (_lib.FLAG_LEGACY_16K if legacy_16k else 0)
         if device is not None and torch.cuda.is_available():
             torch.cuda.set_device(int(device))
         rc = self._lib.sgx_create(C.byref(cfg), C.byref(self._ctx))
@@ -70,6 +70,12 @@ class SpectrogramEngine:
 
     def close(self):
         if getattr(self, "_ctx", None) is not None and self._ctx.value:
+            # rings handed out by live() point into the context: they are destroyed first (include/sgx.h)
+            for ref in list(getattr(self, "_rings", ())):
+                ring = ref()
+                if ring is not None:
+                    ring.close()
+            self._rings = []
             self._lib.sgx_destroy(self._ctx)
             self._ctx = C.c_void_p()
 
@@ -97,7 +103,26 @@ class SpectrogramEngine:
 
         assert isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous(), \
             "expected a contiguous float32 CUDA tensor"
+        assert t.device == self.device, f"tensor on {t.device}, engine on {self.device}"
         return C.c_void_p(t.data_ptr())
+
+    def _out(self, out, shape, dtype):
+        """The caller's output buffer, checked (the kernels write shape-many elements through a raw pointer), or a
+        fresh one.  Also re-binds the context to torch's current stream: a batch call is ordered like a torch op."""
+        import torch
+
+        self.use_current_stream()
+        if out is None:
+            return torch.empty(shape, dtype=dtype, device=self.device)
+        need = 1
+        for d in shape:
+            need *= int(d)
+        assert isinstance(out, torch.Tensor) and out.is_cuda and out.device == self.device, \
+            f"out must be a CUDA tensor on {self.device}"
+        assert out.dtype == dtype, f"out must be {dtype}, got {out.dtype}"
+        assert out.is_contiguous(), "out must be contiguous"
+        assert out.numel() >= need, f"out holds {out.numel()} elements, the call writes {need}"
+        return out
 
     # ---- sizes -----------------------------------------------------------------------------
     def num_frames(self, n_samples: int) -> int:
@@ -114,10 +139,7 @@ class SpectrogramEngine:
         n = max(total - first_frame, 0)
         if max_frames is not None:
             n = min(n, max_frames)
-        if out is None:
-            out = torch.empty((n, self.pairs, self.M, 2), dtype=torch.float32, device=pcm.device)
-        else:
-            assert out.numel() >= n * self.pairs * self.M * 2 and out.dtype == torch.float32 and out.is_contiguous()
+        out = self._out(out, (n, self.pairs, self.M, 2), torch.float32)
         got = C.c_size_t(0)
         if n:
             self._check(self._lib.sgx_stft_batch(self._ctx, self._dev_f32(pcm), n_samples, first_frame, n,
@@ -135,8 +157,7 @@ class SpectrogramEngine:
         n = max(total - first_frame, 0)
         if max_frames is not None:
             n = min(n, max_frames)
-        if out is None:
-            out = torch.empty((n, self.pairs, self.M, 2), dtype=torch.float16, device=pcm.device)
+        out = self._out(out, (n, self.pairs, self.M, 2), torch.float16)
         got = C.c_size_t(0)
         if n:
             self._check(self._lib.sgx_stft_batch_f16(self._ctx, self._dev_f32(pcm), n_samples, first_frame, n,
@@ -162,8 +183,7 @@ class SpectrogramEngine:
         n = max(total - first_frame, 0)
         if max_frames is not None:
             n = min(n, max_frames)
-        if out is None:
-            out = torch.empty((n, self.pairs, self.R, 4), dtype=torch.uint8, device=pcm.device)
+        out = self._out(out, (n, self.pairs, self.R, 4), torch.uint8)
         got = C.c_size_t(0)
         if n:
             self._check(self._lib.sgx_render_batch(self._ctx, self._dev_f32(pcm), n_samples, first_frame, n,
@@ -176,8 +196,7 @@ class SpectrogramEngine:
         import torch
 
         n = mags.numel() // (self.M * 2)
-        if out is None:
-            out = torch.empty((n, self.R, 4), dtype=torch.uint8, device=mags.device)
+        out = self._out(out, (n, self.R, 4), torch.uint8)
         if n:
             self._check(self._lib.sgx_render_mags(self._ctx, self._dev_f32(mags), n, C.c_void_p(out.data_ptr())))
         return out
@@ -189,8 +208,7 @@ class SpectrogramEngine:
 
         ranges = np.ascontiguousarray(ranges, np.float32).reshape(-1, 2)
         n = mags.numel() // (self.M * 2)
-        if out is None:
-            out = torch.empty((n, ranges.shape[0], 2), dtype=torch.float32, device=mags.device)
+        out = self._out(out, (n, ranges.shape[0], 2), torch.float32)
         if n and ranges.shape[0]:
             self._check(self._lib.sgx_magnitude_in(self._ctx, self._dev_f32(mags), n, ranges.ctypes.data_as(C.c_void_p),
                                                    ranges.shape[0], C.c_void_p(out.data_ptr())))
@@ -208,7 +226,13 @@ class SpectrogramEngine:
     # ---- live capture ----------------------------------------------------------------------
     def live(self, capacity: int = 4096, reference_skip: bool = False) -> "LiveRing":
         """The ring between the audio callback and the GUI tick, consumed side resident on the device."""
-        return LiveRing(self, capacity, reference_skip)
+        import weakref
+
+        ring = LiveRing(self, capacity, reference_skip)
+        if not hasattr(self, "_rings"):
+            self._rings = []
+        self._rings = [r for r in self._rings if r() is not None] + [weakref.ref(ring)]
+        return ring
 
     # ---- colour scheme ---------------------------------------------------------------------
     def set_gradient(self, rgb: np.ndarray, stereo: bool = False):

@@ -38,6 +38,7 @@ class SimpleSpectrogram:
         self._period, self._window_samples, self._device, self._interp = period, window_samples, device, interp
         self.stride = 2.0 / width  # :102
         self.engine: Optional[SpectrogramEngine] = None
+        self.live = None
         self.set_sample_rate(sample_rate)
         self.buffer = torch.zeros((height, width, 4), dtype=torch.uint8, device=self.engine.device)
 
@@ -45,6 +46,11 @@ class SimpleSpectrogram:
         """:214-219 -- replaces the transform wholesale"""
         sr = np.float32(sample_rate)
         hop = int(np.float32(self.stride) * sr)
+        # the ring holds a pointer to the engine's context: it goes first (include/sgx.h: destroy every ring
+        # before sgx_destroy).  The reference calls this on every input-device change.
+        if self.live is not None:
+            self.live.close()
+            self.live = None
         if self.engine is not None:
             self.engine.close()
         kw = dict(window_samples=self._window_samples) if self._window_samples else dict(period=self._period)

@@ -12,5 +12,5 @@ for d in sys.argv[1:]:
         for r in rows:
             acc[(r["Kernel_Name"][:60], r["Counter_Name"], r.get("Grid_Size", ""))].append(float(r["Counter_Value"]))
         for (k, c, g), v in sorted(acc.items()):
-            if "stft" in k or "render" in k or "magnitude" in k:
+            if "stft" in k or "render" in k or "magnitude" in k or "deinterleave" in k:
                 print(f"{k:60s} grid={g:>8s} {c:28s} n={len(v):3d} mean={sum(v)/len(v):.4g}")

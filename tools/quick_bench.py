@@ -48,20 +48,22 @@ def main():
             print(f"render_mags only: median {med:.3f} ms -> {F / med / 1e3:.1f} M columns/s", flush=True)
 
 
-if __name__ == "__main__" and "--extra" not in sys.argv and "--live" not in sys.argv and "--generic-sizes" not in sys.argv:
+if __name__ == "__main__" and not any(f in sys.argv for f in ("--extra", "--live", "--generic-sizes", "--config4")):
     main()
 
 
-def config4(frames=20000):
+def config4(frames=20000, legacy=False, channels=8):
     """BASELINE config 4: 16384-point STFT, hop 512, 8 interleaved channels (4 pairs)"""
-    eng = SpectrogramEngine(48000.0, window_samples=8192, hop_samples=512, channels=8)
+    eng = SpectrogramEngine(48000.0, window_samples=8192, hop_samples=512, channels=channels, legacy_16k=legacy)
     n = (frames - 1) * eng.H + eng.W
     pcm = eng.white_noise(n)
-    out = torch.empty((frames, 4, eng.M, 2), dtype=torch.float32, device="cuda")
+    out = torch.empty((frames, eng.pairs, eng.M, 2), dtype=torch.float32, device="cuda")
     med, best = timeit(lambda: eng.stft_batch(pcm, out=out), iters=5)
-    byts = frames * (512 * 8 * 4 + 4 * eng.M * 8)
-    print(f"config4 kernel={eng.info.stft_kernel} hops={frames}: median {med:.3f} ms -> {frames / med / 1e3:.3f} M hop positions/s "
-          f"({4 * frames / med / 1e3:.3f} M transforms/s), {byts / med / 1e6:.1f} GB/s algorithmic", flush=True)
+    byts = frames * (512 * channels * 4 + eng.pairs * eng.M * 8)
+    tr = eng.pairs * frames * (1 if channels > 1 else 0.5)
+    print(f"config4 ch={channels} kernel={eng.info.stft_kernel} hops={frames}: median {med:.3f} ms best {best:.3f} -> {frames / med / 1e3:.3f} M hop positions/s "
+          f"({tr / med / 1e3:.3f} M transforms/s), {byts / med / 1e6:.1f} GB/s algorithmic = {byts / med / 1e6 / 8000:.3f} of 8 TB/s", flush=True)
+    return out
 
 
 def app_default(frames=20000):
@@ -74,6 +76,17 @@ def app_default(frames=20000):
     print(f"app default W={eng.W} H={eng.H} kernel={eng.info.stft_kernel}: median {med:.3f} ms -> {frames / med / 1e3:.3f} M frames/s "
           f"(real time is {48000 / eng.H:.0f} frames/s)", flush=True)
 
+
+if __name__ == "__main__" and "--config4" in sys.argv:
+    for ch in ((2,) if "--stereo-only" in sys.argv else (8, 2, 1)):
+        if "--new-only" in sys.argv:
+            config4(legacy=False, channels=ch)
+            continue
+        a = config4(legacy=True, channels=ch)
+        b = config4(legacy=False, channels=ch)
+        d = (a - b).abs().max().item()
+        print(f"  ch={ch}: max |legacy - new| = {d:.3e} (peak {a.abs().max().item():.3e})", flush=True)
+        del a, b
 
 if __name__ == "__main__" and "--extra" in sys.argv:
     config4()
@@ -89,6 +102,17 @@ def f16(frames=1_000_000):
     byts = frames * (256 * 4 + eng.M * 4)
     print(f"stft f16 ring rows F={frames}: median {med:.3f} ms -> {frames / med / 1e3:.1f} M frames/s, {byts / med / 1e6:.1f} GB/s algorithmic", flush=True)
 
+
+if __name__ == "__main__" and "--config4" in sys.argv:
+    for ch in ((2,) if "--stereo-only" in sys.argv else (8, 2, 1)):
+        if "--new-only" in sys.argv:
+            config4(legacy=False, channels=ch)
+            continue
+        a = config4(legacy=True, channels=ch)
+        b = config4(legacy=False, channels=ch)
+        d = (a - b).abs().max().item()
+        print(f"  ch={ch}: max |legacy - new| = {d:.3e} (peak {a.abs().max().item():.3e})", flush=True)
+        del a, b
 
 if __name__ == "__main__" and "--extra" in sys.argv:
     f16()
