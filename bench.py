@@ -3,27 +3,37 @@
 
 Contract (one JSON line on rank 0):
   python bench.py --gpus N --steps K --warmup W
-  N > 1 is launched by the driver as
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+  N > 1: either launched by the driver as
+      python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+  or BARE (`python bench.py --gpus N`): this process then touches no GPU at all, starts exactly that command as a
+  child (one fresh rank process per GPU), relays rank 0's JSON line and exits with the child's status.
 
-A "step" is one pass of the hot path over one batch of synthetic PCM that is already resident in
-HBM: BASELINE config 2 -- 1e6 frames of mono white noise (256 001 792 samples), W 2048 / P 4096 /
-H 256, output [1e6][2047][2] float32 magnitudes.  With N GPUs every rank transforms its own
-1e6-frame shard of one long stream (contiguous frame ranges, sample offset rank * 1e6 * H; no
-data-path collective: the path shards by frame) => weak scaling; value = N * 1e6 * K / t.
+A "step" is one pass of the hot path over one batch of synthetic PCM that is already resident in HBM: BASELINE
+config 2 -- 1e6 frames of mono white noise (256 001 792 samples), W 2048 / P 4096 / H 256, output [1e6][2047][2]
+float32 magnitudes.  With N GPUs every rank transforms its own 1e6-frame shard of one long stream (contiguous
+frame ranges, sample offset rank * 1e6 * H; no data-path collective: the path shards by frame) => weak scaling;
+value = N * 1e6 * K / t.
+
+Order of a run (every rank): W warm-up steps -> K "burst" steps on the still-cool device (timed per launch, NOT the
+headline) -> back-to-back steps for --sustain-s seconds (per-launch times kept) -> barrier, EXACTLY K timed steps,
+barrier: `value`, `ms_per_step` and `roofline.frac` come from these last K steps, i.e. from a device that has been
+under load for seconds (the first round's headline was a 66 ms burst on an idle device).
 
 Extra objects on the same line:
-  roofline     -- dominant kernel (the STFT kernel): algorithmic bytes per launch / measured
-                  launch duration (HIP events on the launch stream) against the 8 TB/s HBM peak
-  cpu_baseline -- the CPU oracle (oracle/, a port of the reference's algorithm; the reference itself
-                  is Rust + FFTW and cannot be built in this image) timed on this host's cores, on a
-                  bounded sample of the same stream (rank 0, N = 1 only)
-  pixel_path   -- BASELINE config 3 (N = 1) / config 5 shape (N > 1): PCM -> RGBA columns, and for
-                  N > 1 the RCCL gather of pixel columns to rank 0 (reported, not the headline value)
+  roofline     -- dominant kernel (the STFT kernel): algorithmic bytes per launch / launch duration (HIP events on the
+                  launch stream) against the 8 TB/s HBM peak; frac (timed region), frac_burst, frac_sustained
+  cpu_baseline -- the CPU oracle (oracle/, a port of the reference's algorithm; the reference itself is Rust + FFTW and
+                  cannot be built in this image) timed on this host's cores, bounded sample (rank 0, N = 1 only)
+  config3      -- (N = 1) BASELINE config 3: the same stream -> RGBA pixel columns, with its own roofline
+  config4      -- (N = 1) BASELINE config 4: 16384-point, hop 512, 8 interleaved channels, with its own roofline
+  config5      -- (N > 1) BASELINE config 5: 1e8 frames frame-sharded over the ranks, PCM generated on device chunk by
+                  chunk, pixel columns gathered to rank 0 over RCCL / xGMI, every piece consumed (checksummed) by the root
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -34,6 +44,9 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
 W, H, M, R = 2048, 256, 2047, 1024
 ALGO_BYTES_STFT = H * 1 * 4 + M * 2 * 4  # 17 400 B / frame: each input sample once, each output byte once
 ALGO_BYTES_PIXEL = H * 1 * 4 + R * 4     # 5 120 B / frame
+W4, H4, C4 = 8192, 512, 8
+ALGO_BYTES_CFG4 = H4 * C4 * 4 + (C4 // 2) * (W4 - 1) * 8  # 278 496 B / hop position
+PROFILE_ROUND = "r02"
 KERNEL_NAMES = {
     0: ("generic power-of-two (workgroup per frame, LDS radix-4)", "sgx::stft_generic_kernel"),
     1: ("stft4096 wave-per-transform", "sgx::stft4096_kernel<6, true>"),
@@ -41,44 +54,110 @@ KERNEL_NAMES = {
         "sgx::wg::stft4096_wg_kernel<true, 0, false, false>"),
     3: ("stft4096 workgroup-per-transform (256 threads x 16 points, radix-16 x3, mono frame pairs), packed (re, im) codelets",
         "sgx::wgp::stft4096_wgp_kernel<true, 0, false, false>"),
+    5: ("stft16384 as four 4096-point residues (512 threads = 256 lane pairs, DPP decimation)", "sgx::q16k::stft16384_q_kernel<false>"),
+    7: ("stft16384 workgroup-per-transform (1024 threads, whole transform in LDS)", "sgx::wg16k::stft16384_wg_kernel<false>"),
 }
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=1_000_000, help="frames per GPU per step (config 2: 1e6)")
-    ap.add_argument("--pixel-frames", type=int, default=262_144, help="frames per GPU for the pixel-path leg (0 = skip)")
-    ap.add_argument("--pixel-timeout", type=float, default=300.0, help="seconds after which a stalled pixel-path leg is given up")
+    ap.add_argument("--sustain-s", type=float, default=3.0, help="seconds of back-to-back steps before the timed region (0 = skip)")
+    ap.add_argument("--pixel-frames", type=int, default=1_000_000, help="N = 1: frames of the config-3 leg (0 = skip)")
+    ap.add_argument("--config4-hops", type=int, default=20_000, help="N = 1: hop positions of the config-4 leg (0 = skip)")
+    ap.add_argument("--config5-frames", type=int, default=100_000_000, help="N > 1: total frames of the config-5 leg (0 = skip)")
+    ap.add_argument("--config5-chunk", type=int, default=65_536, help="columns per rank per gather round")
+    ap.add_argument("--leg-timeout", type=float, default=600.0, help="seconds after which a stalled collective leg is given up (exit 3)")
     ap.add_argument("--cpu-frames", type=int, default=262_144, help="frames of the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--generic", action="store_true", help="force the generic power-of-two kernel")
-    return ap.parse_args()
+    ap.add_argument("--packed", action="store_true", help="the packed (re, im) variant of the 4096-point kernel (A/B)")
+    return ap.parse_args(argv)
 
 
-def load_traffic():
-    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/hbm_traffic.json), or None."""
-    path = os.path.join(ROOT, "profiles", "hbm_traffic.json")  # the latest round's copy (profiles/rNN_hbm_traffic.json)
+# ---------------------------------------------------------------------------------------------------
+# bare `python bench.py --gpus N`: no GPU call in this process; one fresh child per rank
+# ---------------------------------------------------------------------------------------------------
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_children(args, argv):
+    """Start `python -m torch.distributed.run --nproc-per-node N bench.py <argv>` and relay its output.  Nothing in
+    this process has initialised a GPU (no torch import, no HIP call): the ranks are ordinary child processes."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["BENCH_LAUNCHED_BY_PARENT"] = "1"
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True, bufsize=1)
+    line = None
+    for out in proc.stdout:
+        out = out.rstrip("\n")
+        if out.startswith("{") and '"metric"' in out:
+            line = out          # rank 0's JSON line: printed last, alone
+        else:
+            print(out, file=sys.stderr, flush=True)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    if rc == 0 and line is None:
+        print("bench.py: the ranks exited 0 without printing a JSON line", file=sys.stderr)
+        rc = 4
+    return rc
+
+
+def host_info():
+    model = None
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("model name"):
+                    model = ln.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    aff = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None
+    return {"nproc": os.cpu_count(), "affinity": aff, "cpu_model": model}
+
+
+def load_profile_json(name):
+    """A committed summary of this round's rocprofv3 --pmc passes (profiles/<round>_<name>.json), or None."""
+    path = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_{name}.json")
     try:
         with open(path) as f:
-            return json.load(f)
+            d = json.load(f)
+        d["source"] = os.path.relpath(path, ROOT)
+        return d
     except Exception:
         return None
 
 
+def stats_ms(v):
+    if not v:
+        return None
+    s = sorted(v)
+    return {"n": len(s), "min": s[0], "median": s[len(s) // 2], "mean": sum(s) / len(s), "max": s[-1]}
+
+
 def library_fft_rate(np, oracle, W, H, frames, cores, ref):
-    """frames/s of fft.rs:43-99 done with scipy.fft on the host (bounded sample; checked against the oracle's first
-    frames): the whole frame (numpy window / pack / split around the FFT) and the FFT call alone"""
+    """frames/s of the FFT call of fft.rs:77 alone, done with scipy.fft (pocketfft, complex64) on `cores` host threads
+    over a bounded sample (no FFTW in this image or on the GPU box); window / pack / split are checked against the
+    oracle's first frames but NOT part of the figure (numpy would do them on one thread)."""
     import scipy.fft
 
     win = oracle.hann_window(W)
-    batch, done, dt, dt_fft, first = 4096, 0, 0.0, 0.0, None
+    batch, done, dt_fft, first = 4096, 0, 0.0, None
     z = np.zeros((batch, 2 * W), np.complex64)                    # the padding half stays zero (out-of-place FFT)
     while done < frames:
         m = min(batch, frames - done)
         host = oracle.white_noise((m - 1) * H + W, first=done * H)
-        t0 = time.perf_counter()
         fr = np.lib.stride_tricks.as_strided(host, shape=(m, W), strides=(host.strides[0] * H, host.strides[0]))
         sw = fr * win
         z.real[:m, :W] = sw                                       # mono -> (s, s): l + i r
@@ -86,30 +165,42 @@ def library_fft_rate(np, oracle, W, H, frames, cores, ref):
         t1 = time.perf_counter()
         F = scipy.fft.fft(z[:m], axis=1, workers=cores)
         dt_fft += time.perf_counter() - t1
-        a, b = F[:, 1:W], F[:, 2 * W - 1:W:-1]                    # F[k], F[P - k], k = 1 .. W-1
-        out = np.stack([np.abs(a + np.conj(b)), np.abs(a - np.conj(b))], axis=2) * np.float32(1.0 / W)
-        dt += time.perf_counter() - t0
         if first is None:
-            first = out[:8].copy()
+            a, b = F[:8, 1:W], F[:8, 2 * W - 1:W:-1]              # F[k], F[P - k], k = 1 .. W-1
+            first = np.stack([np.abs(a + np.conj(b)), np.abs(a - np.conj(b))], axis=2) * np.float32(1.0 / W)
         done += m
     peak = np.abs(ref[:8, 0]).max(axis=(1, 2), keepdims=True)
     ok = bool((np.abs(first - ref[:8, 0]) <= 2e-5 * np.maximum(np.abs(ref[:8, 0]), 0.05 * peak)).all())
-    return {"value": frames / dt, "fft_call_only": frames / dt_fft, "unit": "frames/s", "cores": cores, "frames": frames,
-            "what": "scipy.fft (pocketfft) complex64 on all cores; numpy (one thread) does window / pack / split", "matches_oracle": ok}
+    return {"fft_call_only": frames / dt_fft, "unit": "frames/s", "cores": cores, "frames": frames,
+            "what": "scipy.fft (pocketfft) complex64 4096-point c2c, the FFT call alone, all host threads", "matches_oracle": ok}
 
 
-def main():
-    args = parse()
+def main_rank(args):
     import torch
     import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
+    args.gpus = world
+    if os.environ.get("BENCH_LAUNCH_ONLY") == "1":
+        # launcher self-test (tests/test_bench_launcher.py, no GPU): rendezvous over gloo, one all-reduce, a stub line
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world > 1:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            t = torch.tensor([float(rank)], dtype=torch.float64)
+            dist.all_reduce(t)
+            ranks_sum = float(t[0])
+        else:
+            ranks_sum = 0.0
+        if os.environ.get("BENCH_FAIL_RANK") == str(rank):
+            os._exit(7)
+        if rank == 0:
+            print(json.dumps({"metric": "launcher self-test", "n_gpus": world, "ranks_sum": ranks_sum,
+                              "launched_by_parent": os.environ.get("BENCH_LAUNCHED_BY_PARENT") == "1"}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return 0
     assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU fallback"
     # rehearsal knobs (one-GPU box): BENCH_BACKEND=gloo BENCH_SINGLE_DEVICE=1 run every rank on cuda:0 so
     # that the N > 1 control flow can be exercised without a second GPU; the driver never sets them
@@ -125,15 +216,23 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     from spectrogram_rs_amd import SpectrogramEngine
-    from spectrogram_rs_amd.sharding import chunks, frame_range, gather_columns, sample_range
+    from spectrogram_rs_amd.sharding import frame_range, sample_range, stream_columns
+
+    red_dev = torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")
 
     def barrier():
         if world > 1:
             dist.barrier()
 
+    def max_over_ranks(vals):
+        t = torch.tensor(vals, dtype=torch.float64, device=red_dev)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return [float(x) for x in t]
+
     F = args.frames
     eng = SpectrogramEngine(48000.0, window_samples=W, hop_samples=H, channels=1, device=local_rank,
-                            force_generic=args.generic, interp=1, gradient="viridis")
+                            force_generic=args.generic, packed_kernel=args.packed, interp=1, gradient="viridis")
     # weak scaling: one stream of world*F frames; rank g owns the contiguous range frame_range(g)
     # and generates exactly its samples (with the W-H halo) -- no input exchange
     first_frame, n_own = frame_range(rank, world, world * F)
@@ -143,13 +242,27 @@ def main():
     mags = torch.empty((F, 1, M, 2), dtype=torch.float32, device=eng.device)
     mags.zero_()  # first touch of the 16 GB output buffer belongs to the allocation, not to a step
 
+    def timed_launches(n):
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+        for a, b in evs:
+            a.record()
+            eng.stft_batch(pcm, out=mags)
+            b.record()
+        torch.cuda.synchronize()
+        return [a.elapsed_time(b) for a, b in evs]
+
     for _ in range(args.warmup):
         eng.stft_batch(pcm, out=mags)
     torch.cuda.synchronize()
+    burst = timed_launches(args.steps)          # cool device: the figure round 1 reported
+    sustained, t_s0 = [], time.perf_counter()
+    while args.sustain_s > 0 and time.perf_counter() - t_s0 < args.sustain_s:
+        sustained += timed_launches(32)          # ~0.1 s per batch; the queue is never empty for longer than a sync
+    sustain_wall = time.perf_counter() - t_s0
     barrier()
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     for a, b in evs:
         a.record()
         eng.stft_batch(pcm, out=mags)
@@ -157,19 +270,26 @@ def main():
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
-    kernel_ms = sum(a.elapsed_time(b) for a, b in evs) / max(len(evs), 1)
-    red_dev = eng.device if backend == "nccl" else "cpu"
-    t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=red_dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed, kernel_ms = float(t[0]), float(t[1])
+    timed = [a.elapsed_time(b) for a, b in evs]
+    kernel_ms = sum(timed) / max(len(timed), 1)
+    steady = sustained[len(sustained) // 3:]     # the first third of the window is still heating up
+    sustained_ms = (sum(steady) / len(steady)) if steady else kernel_ms
+    burst_ms = sum(burst) / max(len(burst), 1)
+    elapsed, kernel_ms, sustained_ms, burst_ms = max_over_ranks([elapsed, kernel_ms, sustained_ms, burst_ms])
     checksum = eng.checksum(mags[:4096])
+    try:
+        sclk = int(torch.cuda.clock_rate())
+    except Exception:  # noqa: BLE001 -- not every build exposes it
+        sclk = None
 
-    def build_line(pixel, cpu):
+    def frac_of(ms):
+        return F * ALGO_BYTES_STFT / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+
+    def build_line(extra):
         total_frames = world * F * args.steps
         value = total_frames / elapsed
         achieved = F * ALGO_BYTES_STFT / (kernel_ms * 1e-3) / 1e9
-        traffic = load_traffic()
+        traffic = load_profile_json("hbm_traffic")
         line = {
             "metric": "STFT frames/sec (4096-pt, hop 256)",
             "value": value,
@@ -188,139 +308,263 @@ def main():
                 "window": W, "fft_length": 2 * W, "hop": H, "channels": 1, "frames_per_gpu": F,
                 "kernel": KERNEL_NAMES[eng.info.stft_kernel][0],
                 "sharding": "contiguous frame ranges per rank, no data-path collective" if world > 1 else "single GPU",
+                "timed_region": f"{args.steps} steps after {args.warmup} warm-up steps, {args.steps} burst steps and {sustain_wall:.1f} s of back-to-back steps",
             },
             "achieved_GBps_algorithmic": value * ALGO_BYTES_STFT / 1e9,
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
+                "frac_burst": frac_of(burst_ms), "frac_sustained": frac_of(sustained_ms),
                 "traffic": ((traffic or {}).get("stft_bytes_per_frame") or 0) * F or None,
+                "traffic_source": (traffic or {}).get("source"),
                 "kernel": KERNEL_NAMES[eng.info.stft_kernel][1],
                 "launch_ms": kernel_ms, "bytes_per_frame": ALGO_BYTES_STFT, "frames_per_launch": F,
+                "launch_ms_burst": stats_ms(burst), "launch_ms_sustained": stats_ms(steady),
+                "sustain_s": sustain_wall, "sclk_mhz_after_run": sclk,
+                "note": "frac / launch_ms: the K timed steps (device hot); *_burst: the first K steps after warm-up; "
+                        "*_sustained: launches of the last two thirds of the sustain window; max over ranks",
             },
-            "cpu_baseline": cpu,
-            "pixel_path": pixel,
             "checksum_first_4096_frames": checksum,
         }
+        line.update(extra)
         return line
 
-    def pixel_leg():
-        if args.pixel_frames <= 0:
-            return None
-        Fp = min(args.pixel_frames, F)
-        chunk = min(65_536, Fp)
-        rgba = torch.empty((Fp, 1, R, 4), dtype=torch.uint8, device=eng.device)
-        counts = [Fp] * world
-        root_seen = [0]
-
-        def consume(first_col, piece):
-            # rank 0 consumes every gathered piece (here: touches it) instead of materialising the
-            # whole image -- 1e8 columns would be 410 GB, more than one GPU's HBM
-            root_seen[0] += int(piece.shape[0])
-
-        def render(c0, cn):
-            eng.render_batch(pcm, first_frame=c0, max_frames=cn, out=rgba[c0:c0 + cn])
-
-        def pixel_pass():
-            if world == 1:
-                for c0, cn in chunks(Fp, chunk):
-                    render(c0, cn)
-            else:
-                # the one exchange step of the path: finished pixel columns to rank 0 (RCCL over xGMI), world-1
-                # concurrent point-to-point flows per chunk; chunk i's transfer overlaps chunk i+1's kernel
-                gather_columns(rgba[:, 0], counts, dst=0, chunk=chunk, consume=consume, produce=render)
-
-        pixel_pass()
-        torch.cuda.synchronize()
-        barrier()
-        tp0 = time.perf_counter()
-        reps = 3
-        for _ in range(reps):
-            pixel_pass()
-        torch.cuda.synchronize()
-        barrier()
-        tp = torch.tensor([time.perf_counter() - tp0], dtype=torch.float64, device=red_dev)
-        if world > 1:
-            dist.all_reduce(tp, op=dist.ReduceOp.MAX)
-        fps = world * Fp * reps / float(tp[0])
-        pixel = {
-            "workload": ("config 3: " if world == 1 else "config 5 shape: ") + f"{Fp} frames/GPU -> 1024 log rows (cosine), Viridis RGBA"
-                        + ("" if world == 1 else f", RCCL gather of {chunk}-column chunks to rank 0"),
-            "frames_per_s": fps,
-            "algorithmic_GBps": fps * ALGO_BYTES_PIXEL / 1e9,
-            "gathered": world > 1,
-        }
-        return pixel
-
-    # ---- pixel path leg (config 3 / config 5 shape), not the headline value -----------------------
-    # The headline number above is already final.  The leg below contains the one collective exchange of the
-    # path; if it fails or stalls on some rank (a collective cannot be interrupted from Python), a watchdog
-    # still prints the JSON line -- with the failure recorded in "pixel_path" -- and ends the process.
-    pixel = None
+    # ---- everything below is reported beside the headline, which is final ------------------------------------
     import threading
 
     def on_stall():
         if rank == 0:
-            print(json.dumps(build_line({"error": f"pixel-path leg did not finish within {args.pixel_timeout} s"}, None)), flush=True)
-        os._exit(0)
+            print(json.dumps(build_line({"error": f"a collective leg did not finish within {args.leg_timeout} s"})), flush=True)
+        os._exit(3)   # a stalled exchange is a failed run: never status 0
 
-    watchdog = threading.Timer(args.pixel_timeout, on_stall)
+    extra = {}
+    watchdog = threading.Timer(args.leg_timeout, on_stall)
     watchdog.daemon = True
-    if args.pixel_frames > 0:
+    if world > 1:
         watchdog.start()
     try:
-        pixel = pixel_leg()
-    except Exception as e:  # noqa: BLE001 -- reported in the line, the headline stands
-        pixel = {"error": f"{type(e).__name__}: {e}"}
-        if world > 1:      # the other ranks may be waiting in the exchange: nothing collective from here on
-            if rank == 0:
-                print(json.dumps(build_line(pixel, None)), flush=True)
-            os._exit(0)
+        if world == 1:
+            del mags
+            torch.cuda.empty_cache()
+            if args.pixel_frames > 0:
+                extra["config3"] = config3_leg(args, torch, eng, pcm, F)
+            if args.config4_hops > 0:
+                extra["config4"] = config4_leg(args, torch, local_rank)
+        elif args.config5_frames > 0:
+            extra["config5"] = config5_leg(args, torch, dist, eng, rank, world, backend, barrier, max_over_ranks,
+                                           frame_range, stream_columns)
+    except Exception as e:  # noqa: BLE001 -- reported in the line; the headline stands, the status does not
+        extra["error"] = f"{type(e).__name__}: {e}"
+        if rank == 0:
+            print(json.dumps(build_line(extra)), flush=True)
+        os._exit(3)       # the other ranks may be waiting in the exchange: nothing collective from here on
     watchdog.cancel()
+
     # ---- CPU baseline: the oracle on this host's cores (rank 0, N = 1 only) ------------------------
-    cpu = None
     if rank == 0 and world == 1 and args.cpu_frames > 0:
-        import numpy as np
-
-        import oracle
-
-        cores = min(os.cpu_count() or 1, 16)
-        Fc = args.cpu_frames
-        piece = 65_536                       # frames per oracle call: bounds host memory to ~1 GB of output
-        host = oracle.white_noise((min(piece, Fc) - 1) * H + W)
-        oracle.stream_process(host[:W + 64 * H], 1, W, H, threads=cores)  # plan + page-in
-        cdt, done, ref = 0.0, 0, None
-        while done < Fc:
-            m = min(piece, Fc - done)
-            host = oracle.white_noise((m - 1) * H + W, first=done * H)
-            c0 = time.perf_counter()
-            out = oracle.stream_process(host, 1, W, H, threads=cores)
-            cdt += time.perf_counter() - c0
-            if ref is None:
-                ref = out[:64].copy()
-            done += m
-            del out
-        got = mags[:64, 0].cpu().numpy()
-        peak = np.abs(ref[:, 0]).max(axis=(1, 2), keepdims=True)
-        ok = bool((np.abs(got - ref[:, 0]) <= 2e-5 * np.maximum(np.abs(ref[:, 0]), 0.05 * peak)).all())
-        cpu = {
-            "value": Fc / cdt, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"first {Fc} frames of the same white-noise stream, float32 oracle (oracle/spectro_oracle.c), {cores} threads, "
-                      f"{cdt * cores:.1f} thread-seconds",
-            "parity_on_sample": ok,
-        }
-        # a second CPU figure for orientation: the same frames through an optimised library FFT (scipy's
-        # pocketfft, complex64, all cores) with numpy doing window, pack and split -- the nearest thing to the
-        # reference's FFTW-backed path that this image holds (no libfftw3f here or on the GPU box)
-        try:
-            cpu["library_fft"] = library_fft_rate(np, oracle, W, H, min(Fc, 32768), cores, ref)
-        except Exception as e:  # noqa: BLE001
-            cpu["library_fft"] = {"error": f"{type(e).__name__}: {e}"}
-
+        extra["cpu_baseline"] = cpu_baseline_leg(args, eng, pcm)
     if rank == 0:
-        print(json.dumps(build_line(pixel, cpu)), flush=True)
+        print(json.dumps(build_line(extra)), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    return 0
+
+
+def event_times(torch, fn, reps, warm=1):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for a, b in evs:
+        a.record()
+        fn()
+        b.record()
+    torch.cuda.synchronize()
+    return [a.elapsed_time(b) for a, b in evs]
+
+
+def config3_leg(args, torch, eng, pcm, F):
+    """BASELINE config 3: the same stream -> 1024 log rows (cosine) -> Viridis RGBA, one fused kernel."""
+    Fp = min(args.pixel_frames, F)
+    rgba = torch.empty((Fp, 1, R, 4), dtype=torch.uint8, device=eng.device)
+    rgba.zero_()
+    ms = event_times(torch, lambda: eng.render_batch(pcm, max_frames=Fp, out=rgba), reps=5, warm=2)
+    mean = sum(ms) / len(ms)
+    achieved = Fp * ALGO_BYTES_PIXEL / (mean * 1e-3) / 1e9
+    pipes = load_profile_json("pixel_pipes")
+    traffic = load_profile_json("hbm_traffic")
+    return {
+        "workload": f"configs[2]: {Fp} frames of the same stream -> 1024 log rows (cosine interpolation), Viridis RGBA, fused PCM-to-pixel kernel",
+        "frames_per_s": Fp / (mean * 1e-3),
+        "launch_ms": stats_ms(ms),
+        "roofline": {
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "bytes_per_frame": ALGO_BYTES_PIXEL, "frames_per_launch": Fp,
+            "traffic": ((traffic or {}).get("pixel_bytes_per_frame") or 0) * Fp or None,
+            "traffic_source": (traffic or {}).get("source"),
+            "kernel": "sgx::wg::stft4096_wg_kernel<true, 0, false, true>",
+            "binding_pipe": pipes,
+            "note": "48 flop per algorithmic byte: above the FP32 ridge (19.7), so the HBM fraction is low by construction; "
+                    "the binding pipes (VALU issue, LDS) are in binding_pipe, from this round's SQ counter pass",
+        },
+    }
+
+
+def config4_leg(args, torch, device):
+    """BASELINE config 4: 16384-point STFT, hop 512, 8 interleaved channels = 4 (l, r) pairs per hop position."""
+    from spectrogram_rs_amd import SpectrogramEngine
+
+    hops = args.config4_hops
+    eng = SpectrogramEngine(48000.0, window_samples=W4, hop_samples=H4, channels=C4, device=device)
+    pcm = eng.white_noise((hops - 1) * H4 + W4)
+    out = torch.empty((hops, C4 // 2, W4 - 1, 2), dtype=torch.float32, device=eng.device)
+    out.zero_()
+    ms = event_times(torch, lambda: eng.stft_batch(pcm, out=out), reps=5, warm=2)
+    mean = sum(ms) / len(ms)
+    achieved = hops * ALGO_BYTES_CFG4 / (mean * 1e-3) / 1e9
+    traffic = load_profile_json("hbm_traffic")
+    name = KERNEL_NAMES.get(eng.info.stft_kernel, ("?", "?"))
+    return {
+        "workload": f"configs[3]: 16384-pt Hann STFT, hop 512, 8 interleaved channels, {hops} hop positions ({4 * hops} transforms)",
+        "hop_positions_per_s": hops / (mean * 1e-3), "transforms_per_s": 4 * hops / (mean * 1e-3),
+        "launch_ms": stats_ms(ms), "kernel": name[0],
+        "roofline": {
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "bytes_per_hop_position": ALGO_BYTES_CFG4, "hop_positions_per_launch": hops,
+            "traffic": ((traffic or {}).get("config4_bytes_per_hop") or 0) * hops or None,
+            "traffic_source": (traffic or {}).get("source"),
+            "kernel": name[1],
+            "note": "launch = the de-interleave pass + the transform kernel (both inside the timed call)",
+        },
+    }
+
+
+def config5_leg(args, torch, dist, eng, rank, world, backend, barrier, max_over_ranks, frame_range, stream_columns):
+    """BASELINE config 5: config 3's pipeline over `--config5-frames` frames of one stream, frame-sharded over the
+    ranks; every rank generates its own PCM on the device chunk by chunk (nothing is exchanged on the input side),
+    renders the chunk and sends the finished 4 KB pixel columns to rank 0 (RCCL send / recv: world - 1 point-to-point
+    flows, one per xGMI link into the root); the root checksums every piece and keeps nothing (1e8 columns = 410 GB)."""
+    total, chunk = args.config5_frames, args.config5_chunk
+    ranges = [frame_range(r, world, total) for r in range(world)]
+    counts = [c for _, c in ranges]
+    my_first = ranges[rank][0]
+    dev = eng.device
+    pcm_buf = torch.empty((chunk - 1) * H + W, dtype=torch.float32, device=dev)
+    like = torch.empty((0, R, 4), dtype=torch.uint8, device=dev)
+    acc = torch.zeros(1, dtype=torch.int64, device=dev)
+    first_piece = {r: torch.zeros(1, dtype=torch.int64, device=dev) for r in range(world)}
+
+    def render_range(f0, n, buf):
+        ns = (n - 1) * H + W
+        eng.white_noise(ns, first=f0 * H, out=pcm_buf)
+        eng.render_batch(pcm_buf[:ns], max_frames=n, out=buf.view(-1, 1, R, 4))
+
+    def produce(c0, n, buf):
+        render_range(my_first + c0, n, buf)
+
+    def consume(g0, piece):
+        eng.checksum_add(piece, acc, base_word=g0 * R)
+        for r in range(world):
+            if g0 == ranges[r][0]:        # the first piece of rank r: kept apart for the sub-range check below
+                eng.checksum_add(piece, first_piece[r], base_word=g0 * R)
+
+    def run(produce_fn, consume_fn, send=True):
+        torch.cuda.synchronize()
+        barrier()
+        t0 = time.perf_counter()
+        got = stream_columns(counts, chunk, produce_fn, consume_fn, like=like, dst=0, send=send)
+        torch.cuda.synchronize()
+        barrier()
+        return time.perf_counter() - t0, got
+
+    # ranks as the communicator sees them
+    seen = [torch.zeros(1, dtype=torch.int64, device=dev if backend == "nccl" else "cpu") for _ in range(world)]
+    dist.all_gather(seen, torch.tensor([rank], dtype=torch.int64, device=seen[0].device))
+    ranks_seen = sorted(int(t[0]) for t in seen)
+
+    t_over, arrived = run(produce, consume)                       # the run that counts: render + gather, overlapped
+    t_comp, _ = run(produce, None, send=False)                    # render only
+    t_xfer, _ = run(None, lambda g0, p: None)                     # gather only (re-sends the ring's last contents)
+    t_over, t_comp, t_xfer = max_over_ranks([t_over, t_comp, t_xfer])
+    out = None
+    if rank == 0:
+        # the sharded bytes equal a single GPU's on a sub-range: the root renders the first chunk of every other rank
+        # itself and compares checksums with the piece that arrived from that rank
+        ok, scratch = True, torch.empty((chunk, R, 4), dtype=torch.uint8, device=dev)
+        for r in range(1, world):
+            n = min(chunk, counts[r])
+            if n == 0:
+                continue
+            render_range(ranges[r][0], n, scratch[:n])
+            ok = ok and eng.checksum(scratch[:n], base_word=ranges[r][0] * R) == (int(first_piece[r][0]) & (2**64 - 1))
+        overlap = (t_comp + t_xfer - t_over) / max(min(t_comp, t_xfer), 1e-9)
+        out = {
+            "workload": f"configs[4]: {total} frames of one white-noise stream frame-sharded over {world} GPUs "
+                        f"({counts[0]} per GPU), PCM generated on device per {chunk}-frame chunk, fused PCM-to-RGBA kernel, "
+                        f"pixel columns gathered to rank 0 chunk by chunk",
+            "backend": backend, "ranks_seen": ranks_seen, "frames_total": total, "frames_per_gpu": counts,
+            "chunk_columns": chunk, "rounds": (max(counts) + chunk - 1) // chunk,
+            "frames_per_s": total / t_over, "algorithmic_GBps": total * ALGO_BYTES_PIXEL / t_over / 1e9,
+            "overlapped_s": t_over, "render_only_s": t_comp, "gather_only_s": t_xfer,
+            "overlap_ratio": max(0.0, min(1.0, overlap)),
+            "gathered_bytes": arrived,
+            "GBps_into_root": arrived / t_over / 1e9, "GBps_into_root_gather_only": arrived / t_xfer / 1e9,
+            "GBps_per_source_link_gather_only": arrived / t_xfer / 1e9 / max(world - 1, 1),
+            "root_consumed": "sgx_checksum_add over every piece (its own included), nothing kept",
+            "checksum_all_columns": int(acc[0]) & (2**64 - 1),
+            "sharded_equals_single_gpu_on_first_chunk_of_every_rank": bool(ok),
+        }
+    return out
+
+
+def cpu_baseline_leg(args, eng, pcm):
+    import numpy as np
+
+    import oracle
+
+    info = host_info()
+    cores = min(info["affinity"] or info["nproc"] or 1, 64)   # the threads actually started
+    Fc = args.cpu_frames
+    piece = 65_536                       # frames per oracle call: bounds host memory to ~1 GB of output
+    host = oracle.white_noise((min(piece, Fc) - 1) * H + W)
+    oracle.stream_process(host[:W + 64 * H], 1, W, H, threads=cores)  # plan + page-in
+    cdt, done, ref = 0.0, 0, None
+    while done < Fc:
+        m = min(piece, Fc - done)
+        host = oracle.white_noise((m - 1) * H + W, first=done * H)
+        c0 = time.perf_counter()
+        out = oracle.stream_process(host, 1, W, H, threads=cores)
+        cdt += time.perf_counter() - c0
+        if ref is None:
+            ref = out[:64].copy()
+        done += m
+        del out
+    got = eng.stft_batch(pcm, max_frames=64).cpu().numpy()[:, 0]
+    peak = np.abs(ref[:, 0]).max(axis=(1, 2), keepdims=True)
+    ok = bool((np.abs(got - ref[:, 0]) <= 2e-5 * np.maximum(np.abs(ref[:, 0]), 0.05 * peak)).all())
+    cpu = {
+        "value": Fc / cdt, "unit": "frames/s", "cores": cores, "kind": "port",
+        "nproc": info["nproc"], "cpu_model": info["cpu_model"],
+        "sample": f"first {Fc} frames of the same white-noise stream, float32 oracle (oracle/spectro_oracle.c), {cores} threads, "
+                  f"{cdt * cores:.1f} thread-seconds",
+        "parity_on_sample": ok,
+    }
+    # a second CPU figure for orientation: the FFT call alone through an optimised library FFT (scipy's pocketfft,
+    # complex64, all host threads) -- the nearest thing to the reference's FFTW call that this image holds
+    try:
+        cpu["library_fft"] = library_fft_rate(np, oracle, W, H, min(Fc, 32768), cores, ref)
+    except Exception as e:  # noqa: BLE001
+        cpu["library_fft"] = {"error": f"{type(e).__name__}: {e}"}
+    return cpu
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse(argv)
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        return launch_children(args, argv)
+    return main_rank(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -278,6 +278,10 @@ SGX_API int sgx_synth_white_noise(sgx_ctx *ctx, float *d_out, uint64_t first, si
  * n_bytes (multiple of 4), with word indices starting at base_word: equal for any sharding of
  * the same bytes.  Synchronous. */
 SGX_API int sgx_checksum(sgx_ctx *ctx, const void *d_buf, size_t n_bytes, uint64_t base_word, uint64_t *h_out);
+/* The same sum, ADDED (mod 2^64) into a caller-owned device accumulator *d_acc and asynchronous on the context's
+ * stream: the root of a sharded run consumes every gathered piece of pixel columns this way without a host
+ * round trip per piece (1e8 columns are 410 GB: the image is never materialised).  Zero *d_acc first. */
+SGX_API int sgx_checksum_add(sgx_ctx *ctx, const void *d_buf, size_t n_bytes, uint64_t base_word, uint64_t *d_acc);
 
 #ifdef __cplusplus
 }

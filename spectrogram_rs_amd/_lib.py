@@ -111,6 +111,7 @@ SIGNATURES = [
     ("sgx_window", C.c_int, [_ctx, _vp]),
     ("sgx_synth_white_noise", C.c_int, [_ctx, _vp, C.c_uint64, _sz, C.c_uint32, C.c_uint32]),
     ("sgx_checksum", C.c_int, [_ctx, _vp, _sz, C.c_uint64, C.POINTER(C.c_uint64)]),
+    ("sgx_checksum_add", C.c_int, [_ctx, _vp, _sz, C.c_uint64, _vp]),
 ]
 
 GRADIENT_FN = C.CFUNCTYPE(None, C.c_double, C.POINTER(C.c_uint8), C.c_void_p)

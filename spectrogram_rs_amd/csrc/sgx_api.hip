@@ -563,4 +563,17 @@ int sgx_checksum(sgx_ctx *c, const void *d_buf, size_t n_bytes, uint64_t base_wo
     return SGX_OK;
 }
 
+int sgx_checksum_add(sgx_ctx *c, const void *d_buf, size_t n_bytes, uint64_t base_word, uint64_t *d_acc)
+{
+    if (!c || !d_acc) return SGX_ERR_INVALID_ARG;
+    if (n_bytes % 4) return fail(c, SGX_ERR_INVALID_ARG, "sgx_checksum_add: size must be a multiple of 4");
+    if (n_bytes == 0) return SGX_OK;
+    if (!d_buf) return fail(c, SGX_ERR_INVALID_ARG, "sgx_checksum_add: null buffer");
+    SGX_HIP(c, hipSetDevice(c->device));
+    hipError_t e = sgx::launch_checksum(c, static_cast<const uint32_t *>(d_buf), n_bytes / 4, base_word,
+                                        reinterpret_cast<unsigned long long *>(d_acc));
+    if (e != hipSuccess) return fail_hip(c, e, "sgx_checksum_add: kernel launch");
+    return SGX_OK;
+}
+
 }  // extern "C"

@@ -273,13 +273,24 @@ class SpectrogramEngine:
         return out
 
     # ---- harness helpers -------------------------------------------------------------------
-    def white_noise(self, n_samples: int, first: int = 0, seed: int = 0x5EED0001, channels: Optional[int] = None):
+    def white_noise(self, n_samples: int, first: int = 0, seed: int = 0x5EED0001, channels: Optional[int] = None, out=None):
         import torch
 
         ch = self.channels if channels is None else channels
-        out = torch.empty(n_samples * ch, dtype=torch.float32, device=self.device)
+        out = self._out(out, (n_samples * ch,), torch.float32)
         self._check(self._lib.sgx_synth_white_noise(self._ctx, C.c_void_p(out.data_ptr()), first, n_samples, ch, seed))
         return out
+
+    def checksum_add(self, t, acc, base_word: int = 0) -> None:
+        """Add the checksum of `t` (word indices from base_word) into `acc`, a one-element int64 tensor on this
+        device; asynchronous on the current stream (no host round trip)."""
+        import torch
+
+        assert acc.is_cuda and acc.device == self.device and acc.dtype == torch.int64 and acc.numel() == 1
+        assert t.is_cuda and t.device == self.device and t.is_contiguous()
+        self.use_current_stream()
+        self._check(self._lib.sgx_checksum_add(self._ctx, C.c_void_p(t.data_ptr()), t.numel() * t.element_size(),
+                                               base_word, C.c_void_p(acc.data_ptr())))
 
     def checksum(self, t, base_word: int = 0) -> int:
         nbytes = t.numel() * t.element_size()

@@ -124,6 +124,79 @@ def gather_columns(local, counts: List[int], dst: int = 0, chunk: int = 65536,
     return None
 
 
+def stream_columns(counts: List[int], chunk: int, produce: Optional[Callable], consume: Optional[Callable], *,
+                   like, dst: int = 0, group=None, slots: int = 2, send: bool = True):
+    """The gather of `gather_columns` for runs whose columns are never all resident: rank r renders its counts[r]
+    columns chunk by chunk into a ring of `slots` buffers (`produce(c0, n, buf)` fills buf[:n] with its columns
+    [c0, c0 + n)) and sends each chunk to `dst`, which hands every piece -- its own included -- to
+    `consume(global_first_column, tensor)` and keeps nothing.  BASELINE config 5: 1e8 columns = 410 GB, more than one
+    GPU's HBM, so neither the producers nor the root ever hold more than `slots` chunks per peer.
+
+    Round i's transfers are posted, round i + 1 is produced, then round i is waited for: with RCCL the xGMI
+    transfer of one chunk overlaps the kernel of the next (world - 1 concurrent point-to-point flows into the
+    root, one per link; no ring, no reduction).  `produce=None` re-sends whatever the ring holds (transfer only),
+    `send=False` only produces (compute only): the two legs `bench.py` times beside the overlapped run.
+
+    `like`: a tensor giving dtype / device / trailing shape of one column block, e.g. torch.empty((0, R, 4), uint8).
+    Returns the number of bytes that arrived at `dst` from other ranks (on `dst`; 0 elsewhere)."""
+    import torch
+    import torch.distributed as dist
+
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    assert len(counts) == world and slots >= 2
+    staged = like.is_cuda and dist.get_backend(group) != "nccl"
+    starts = [sum(counts[:r]) for r in range(world)]
+    rounds = max((c + chunk - 1) // chunk for c in counts) if counts else 0
+    tail = tuple(like.shape[1:])
+    ring = [torch.empty((chunk,) + tail, dtype=like.dtype, device=like.device) for _ in range(slots)]
+    # the root's receive buffers: one ring per peer, allocated once (a fresh allocation per round would put the
+    # caching allocator on the critical path of every chunk)
+    recv = None
+    if rank == dst and send:
+        recv = [[None if r == dst or counts[r] == 0 else
+                 torch.empty((chunk,) + tail, dtype=like.dtype, device="cpu" if staged else like.device)
+                 for r in range(world)] for _ in range(slots)]
+    arrived = 0
+
+    def post(i):
+        c0 = i * chunk
+        n_per_rank = [max(min(chunk, counts[r] - c0), 0) for r in range(world)]
+        mine = ring[i % slots]
+        if produce is not None and n_per_rank[rank] > 0:
+            produce(c0, n_per_rank[rank], mine)
+        pieces, ops = [None] * world, []
+        if not send:
+            pieces[rank] = mine[:n_per_rank[rank]] if n_per_rank[rank] else None
+            return c0, pieces, []
+        if rank == dst:
+            for r in range(world):
+                if n_per_rank[r] == 0:
+                    continue
+                if r == dst:
+                    pieces[r] = mine[:n_per_rank[r]]
+                    continue
+                pieces[r] = recv[i % slots][r][:n_per_rank[r]]
+                ops.append(dist.P2POp(dist.irecv, pieces[r], r, group))
+        elif n_per_rank[rank] > 0:
+            ops.append(dist.P2POp(dist.isend, mine[:n_per_rank[rank]].cpu() if staged else mine[:n_per_rank[rank]], dst, group))
+        return c0, pieces, (dist.batch_isend_irecv(ops) if ops else [])
+
+    pending = post(0) if rounds else None
+    for i in range(rounds):
+        c0, pieces, reqs = pending
+        pending = post(i + 1) if i + 1 < rounds else None
+        pieces = _finish_round(pieces, reqs, staged, like.device)
+        if rank != dst or consume is None:
+            continue
+        for r in range(world):
+            if pieces[r] is None:
+                continue
+            if r != dst:
+                arrived += pieces[r].numel() * pieces[r].element_size()
+            consume(starts[r] + c0, pieces[r])
+    return arrived
+
+
 def combine_checksums(parts: List[int]) -> int:
     """sgx_checksum is a sum of per-word mixes with global word indices: shards add (mod 2^64)."""
     return sum(parts) & ((1 << 64) - 1)

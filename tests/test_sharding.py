@@ -72,6 +72,24 @@ def _worker(rank, world, port, total_frames, out_path):
 
     img2 = gather_columns(lazy, counts, dst=0, chunk=3, produce=produce)
     assert calls == list(chunks(count, 3))
+    # (d) the config-5 shape: columns exist one chunk at a time on every rank (a ring of two buffers), the root consumes
+    #     every piece and keeps nothing; then the transfer-only and compute-only legs the bench times beside it
+    from spectrogram_rs_amd.sharding import stream_columns
+
+    got_stream, made = {}, []
+
+    def fill(c0, n_cols, buf):
+        made.append((c0, n_cols))
+        buf[:n_cols] = cols[c0:c0 + n_cols]
+
+    like = torch.empty((0, R, 4), dtype=torch.uint8)
+    arrived = stream_columns(counts, 3, fill, lambda g0, t: got_stream.__setitem__(g0, t.clone()), like=like, dst=0)
+    assert made == list(chunks(count, 3))
+    assert stream_columns(counts, 3, None, lambda g0, t: None, like=like, dst=0) == arrived      # transfer only
+    assert stream_columns(counts, 3, fill, None, like=like, dst=0, send=False) == 0                # compute only
+    if rank == 0:
+        assert arrived == (total_frames - count) * R * 4
+        assert torch.equal(torch.cat([got_stream[k] for k in sorted(got_stream)]), img)
     if rank == 0:
         assert img.shape[0] == total_frames
         pieces = torch.cat([seen[k] for k in sorted(seen)])
