@@ -170,7 +170,7 @@ def library_fft_rate(np, oracle, W, H, frames, cores, ref):
             first = np.stack([np.abs(a + np.conj(b)), np.abs(a - np.conj(b))], axis=2) * np.float32(1.0 / W)
         done += m
     peak = np.abs(ref[:8, 0]).max(axis=(1, 2), keepdims=True)
-    ok = bool((np.abs(first - ref[:8, 0]) <= 2e-5 * np.maximum(np.abs(ref[:8, 0]), 0.05 * peak)).all())
+    ok = bool((np.abs(first - ref[:8, 0]) <= 2e-5 * np.maximum(np.abs(ref[:8, 0]), 0.02 * peak)).all())
     return {"fft_call_only": frames / dt_fft, "unit": "frames/s", "cores": cores, "frames": frames,
             "what": "scipy.fft (pocketfft) complex64 4096-point c2c, the FFT call alone, all host threads", "matches_oracle": ok}
 
@@ -541,7 +541,7 @@ def cpu_baseline_leg(args, eng, pcm):
         del out
     got = eng.stft_batch(pcm, max_frames=64).cpu().numpy()[:, 0]
     peak = np.abs(ref[:, 0]).max(axis=(1, 2), keepdims=True)
-    ok = bool((np.abs(got - ref[:, 0]) <= 2e-5 * np.maximum(np.abs(ref[:, 0]), 0.05 * peak)).all())
+    ok = bool((np.abs(got - ref[:, 0]) <= 2e-5 * np.maximum(np.abs(ref[:, 0]), 0.02 * peak)).all())
     cpu = {
         "value": Fc / cdt, "unit": "frames/s", "cores": cores, "kind": "port",
         "nproc": info["nproc"], "cpu_model": info["cpu_model"],

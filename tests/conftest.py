@@ -30,9 +30,13 @@ def gold():
 # ---- tolerance of the float magnitude bins (north_star: 1e-5 relative) --------------------------
 # A float32 FFT cannot hold 1e-5 *relative* on bins 100 dB below the frame peak,
 # so the bound is  |x - ref| <= REL * max(|ref|, FLOOR * frame_peak):
-# 1e-5 relative for every bin within 26 dB of the frame peak, 5e-7 of the peak below that.
+# 1e-5 relative for every bin within 34 dB of the frame peak, 2e-7 of the peak below that.
+# FLOOR is measured, not assumed (tools/err_bands.py, profiles/r02_error_by_level.txt; asserted per 10 dB band by
+# test_error_by_level_against_float64_truth): against the float64 truth every kernel's worst absolute error is
+# 1.7e-7 .. 2.8e-7 of the frame peak and sits in the top 10 dB, its pure relative error passes 1e-5 between 40 and
+# 50 dB below the peak, and the floor that would just hold is 0.007 .. 0.011.  (Round 1 used 0.05.)
 REL_TOL = 1e-5
-PEAK_FLOOR = 0.05
+PEAK_FLOOR = 0.02
 
 
 def mags_error(x, ref):

@@ -61,8 +61,15 @@ def test_random_configuration(seed, mags_err, gradients):
         assert eng.render_batch(dev).shape[0] == 0
         return
     assert eng.info.stft_kernel in (0, 2, 4, 5, 6)
-    # float32 against float32: each within the tolerance of the exact transform (three roundings more for chirp-z)
-    assert mags_err(got, ref) <= (3.0 if eng.info.stft_kernel == 4 else 2.0), c
+    if eng.info.stft_kernel == 4:
+        # lengths with a large prime factor: the float32 oracle evaluates that factor as a plain O(p^2) sum in float32
+        # (FFTW would not), so it is itself off by several times the tolerance there -- the reference for these sizes
+        # is the oracle's float64 mode, and the chirp-z kernel is held to 1x the tolerance against it like every other
+        truth = oracle.stream_process(pcm, ch, W, H, threads=8, precision=oracle.F64)
+        assert mags_err(got, truth) <= 1.0, c
+    else:
+        # float32 against float32: each within the tolerance of the exact transform
+        assert mags_err(got, ref) <= 2.0, c
     # any sub-range writes the bytes of the full run
     first = int(rng.integers(0, total))
     count = int(rng.integers(1, total - first + 1))

@@ -163,6 +163,29 @@ def test_widget_in_live_mode(torch_cuda, gradients):
     assert live.offset > 0 and torch_cuda.equal(live.buffer, host.buffer)
 
 
+def test_widget_survives_input_device_changes(torch_cuda):
+    # the reference calls set_sample_rate on every input-device change (simple_spectrogram.rs:214-219, main.rs:73): the
+    # transform is replaced wholesale.  The device-resident ring points into the context, so it has to go first --
+    # twice in a row used to free the context under a live ring (use after free in sgx_live_destroy).
+    from spectrogram_rs_amd import SimpleSpectrogram
+    w = SimpleSpectrogram(None, sample_rate=SR)
+    tone = (0.25 * np.sin(2 * np.pi * 440.0 * np.arange(6000) / SR)).astype(np.float32)
+    for sr in (44100, 48000, 96000, 48000):
+        old_ring, old_engine = w.live, w.engine
+        w.set_sample_rate(sr)
+        assert not old_ring._h.value and not old_engine._ctx.value       # both destroyed, ring first
+        assert w.engine.W == oracle.window_samples(float(sr), 0.05) and w.live is not old_ring
+        burst = tone[:w.live.capacity - 100]                               # (a fuller ring drops the overflow, as HeapRb does)
+        assert w.push(burst, 1) == len(burst)
+        assert w.snapshot() == w.engine.num_frames(len(burst))
+    # an engine closes the rings it handed out before its context
+    eng = engine(window_samples=2048, hop_samples=256)
+    ring = eng.live(4096)
+    eng.close()
+    assert not ring._h.value
+    ring.close()   # idempotent
+
+
 @pytest.mark.parametrize("sr,interp", [(48000, 0), (44100, 0), (96000, 1)])
 def test_spectrum_analyzer_levels(torch_cuda, sr, interp):
     # SpectrumAnalyzer::push_frequencies (spectrum_analyzer.rs:46-68): identical bars, push after push

@@ -26,6 +26,16 @@ def engine(**kw):
     return SpectrogramEngine(48000.0, **kw)
 
 
+def oracle_prime_factor(n):
+    """largest prime factor of n (the float32 oracle evaluates each prime factor p as a plain p-term sum)"""
+    p, big = 2, 1
+    while p * p <= n:
+        while n % p == 0:
+            big, n = p, n // p
+        p += 1
+    return max(big, n) if n > 1 else big
+
+
 def to_dev(torch, a):
     return torch.from_numpy(np.ascontiguousarray(a, np.float32)).cuda().reshape(-1)
 
@@ -120,7 +130,7 @@ def test_generic_kernel_pairs_mono_frames_by_global_index(torch_cuda, mags_err, 
     ref = oracle.stream_process(pcm, 1, Wt, Ht, threads=8)
     eng = engine(window_samples=Wt, hop_samples=Ht, channels=1)
     assert eng.info.stft_kernel == (0 if Wt & (Wt - 1) == 0 else (4 if Wt == 1102 else 6))
-    tol = 3.0 if eng.info.stft_kernel == 4 else 2.0
+    tol = 2.0
     got = eng.stft_batch(dev).cpu().numpy()
     assert got.shape == ref.shape == (38, 1, Wt - 1, 2)
     assert mags_err(got, ref) <= tol and np.array_equal(got[..., 0], got[..., 1])
@@ -204,10 +214,11 @@ def test_duration_sized_windows_like_the_app(torch_cuda, mags_err, sr, period, W
     ref = oracle.stream_process(pcm, 2, Wexp, Ht, threads=8)
     assert got.shape == ref.shape == (13, 1, Wexp - 1, 2)
     truth = np.stack([oracle.np_truth_frame(pcm.reshape(-1, 2)[t * Ht:t * Ht + Wexp], Wexp) for t in (0, 7, 12)])
-    if eng.info.stft_kernel == 6:
-        assert mags_err(got[[0, 7, 12], 0], truth) <= 1.0 and mags_err(got, ref) <= 2.0
-    else:   # chirp-z: two FFTs + three chirp products in float32
-        assert mags_err(got[[0, 7, 12], 0], truth) <= 2.0 and mags_err(got, ref) <= 3.0
+    # every kernel, the chirp-z one (two FFTs + three chirp products in float32) included, is held to 1x the tolerance
+    # against the float64 truth and 2x against the float32 oracle (two float32 transforms)
+    assert mags_err(got[[0, 7, 12], 0], truth) <= 1.0
+    if eng.info.stft_kernel == 6 or max(oracle_prime_factor(2 * Wexp), 2) <= 64:
+        assert mags_err(got, ref) <= 2.0   # (a large prime factor is an O(p^2) float32 sum in the float32 oracle: no reference)
     # the pixel path rides on it (two-kernel route) and is bit-exact on the engine's own magnitudes
     eng.set_builtin_gradient("viridis")
     rgba = eng.render_batch(to_dev(torch, pcm)).cpu().numpy()
@@ -228,11 +239,74 @@ def test_stream_wrapper_on_gpu(torch_cuda, mags_err):
     assert len(rb) == len(lr) - 7 * 93
 
 
+@pytest.mark.parametrize("Wt", [2048, 2400, 8192, 1102])
+def test_hann_table_is_the_oracles_bit_for_bit(torch_cuda, Wt):
+    # quirk Q6 (fft.rs:61) is a statement about bits: 0.5 * (1 - cosf((TAU_f32 * i as f32) / W as f32)), every operation in
+    # float32 in that order.  The table the kernels multiply by is the oracle's, bit for bit -- and so is what they apply:
+    # a unit impulse in the left channel at sample i comes out as 2 hann[i] / W in every bin of the left magnitude
+    eng = engine(window_samples=Wt, hop_samples=max(Wt // 8, 1), channels=2)
+    win = eng.window()
+    ref = oracle.hann_window(Wt)
+    assert win.dtype == ref.dtype == np.float32 and np.array_equal(win.view(np.uint32), ref.view(np.uint32))
+    assert win[0] == 0.0 and abs(float(win[Wt // 2]) - 1.0) < 1e-6          # periodic Hann: denominator W, not W - 1
+    torch = torch_cuda
+    for i in (1, Wt // 3, Wt - 1):
+        lr = np.zeros((Wt, 2), np.float32)
+        lr[i, 0] = 1.0
+        got = eng.stft_batch(to_dev(torch, lr)).cpu().numpy()[0, 0]
+        expect = 2.0 * np.float64(ref[i]) / Wt   # |L^[k]| = hann[i] for every k, scaled by 2 / W (fft.rs:92-98)
+        assert np.abs(got[:, 0] - expect).max() <= 4e-7 * max(expect, 1e-30) + 1e-12 and np.abs(got[:, 1]).max() <= 4e-7 * expect + 1e-12
+
+
+def _error_bands(got, truth):
+    peak = np.abs(truth).max(axis=(1, 2), keepdims=True)
+    level = 20 * np.log10(np.maximum(np.abs(truth), 1e-300) / peak)
+    rel = np.abs(got - truth) / np.maximum(np.abs(truth), 1e-300)
+    ab = np.abs(got - truth) / peak
+    rows = []
+    for lo in range(0, 160, 10):
+        m = (level <= -lo) & (level > -(lo + 10))
+        if m.any():
+            rows.append((lo, int(m.sum()), float(rel[m].max()), float(ab[m].max())))
+    return rows
+
+
+@pytest.mark.parametrize("name,Wt,Ht,ch,kw", [("4096 mono pairs", 2048, 256, 1, {}), ("4096 stereo", 2048, 256, 2, {}),
+                                              ("16384 stereo", 8192, 512, 2, {}), ("4800 mixed radix", 2400, 93, 2, {}),
+                                              ("2204 chirp-z", 1102, 100, 2, {}), ("3704 chirp-z", 1852, 100, 2, {}),
+                                              ("2048 generic", 1024, 128, 2, {})])
+def test_error_by_level_against_float64_truth(torch_cuda, name, Wt, Ht, ch, kw):
+    # What "1e-5 relative" can and cannot mean for a float32 transform, measured instead of assumed: per 10 dB band below
+    # the frame peak, the worst PURE relative error and the worst absolute error (as a fraction of the frame peak) of the
+    # GPU magnitudes against numpy's float64 FFT of the reference's f32-windowed frame.  Asserted: 1e-5 relative in every
+    # band down to 30 dB below the peak, 3e-7 of the peak everywhere (the floor of tests/conftest.py is 2e-7 from -34 dB).
+    torch = torch_cuda
+    eng = engine(window_samples=Wt, hop_samples=Ht, channels=ch, **kw)
+    frames = 8 if Wt >= 8192 else 16
+    n = (frames - 1) * Ht + Wt
+    t = np.arange(n, dtype=np.float64) / 48000.0
+    tone = (0.5 * np.sin(2 * np.pi * 997.0 * t)).astype(np.float32) + (1e-4 * oracle.white_noise(n, seed=3)).astype(np.float32)
+    sigs = {"white noise": oracle.white_noise(n * ch, seed=77),
+            "tone + noise 74 dB down": np.repeat(tone, ch) if ch > 1 else tone,
+            "sweep": np.repeat(oracle.sine_sweep(n), ch) if ch > 1 else oracle.sine_sweep(n)}
+    print(f"\n{name}: kernel {eng.info.stft_kernel}")
+    for sname, pcm in sigs.items():
+        got = eng.stft_batch(to_dev(torch, pcm)).cpu().numpy().astype(np.float64)[:, 0]
+        lr = pcm.reshape(-1, ch) if ch > 1 else np.stack([pcm, pcm], 1)
+        truth = np.stack([oracle.np_truth_frame(lr[f * Ht:f * Ht + Wt, :2], Wt) for f in range(got.shape[0])])
+        for lo, cnt, rel, ab in _error_bands(got, truth):
+            print(f"  {sname:24s} {-lo:5d}..{-lo - 10:5d} dB  bins {cnt:7d}  worst rel {rel:8.2e}  worst abs/peak {ab:8.2e}")
+            assert ab <= 3e-7, (name, sname, lo, ab)
+            if lo < 30:
+                assert rel <= 1e-5, (name, sname, lo, rel)
+
+
 # ---- properties at sizes the oracle does not reach -----------------------------------------------
 
 def test_full_size_properties(torch_cuda, mags_err):
+    # BASELINE config 2 at its own size: 1e6 frames (256 001 792 samples in, 16.4 GB out)
     torch = torch_cuda
-    F = 200_000
+    F = 1_000_000
     eng = engine(window_samples=W, hop_samples=H, channels=1)
     n = (F - 1) * H + W
     pcm = eng.white_noise(n)
@@ -248,7 +322,9 @@ def test_full_size_properties(torch_cuda, mags_err):
     assert mags_err(got, ref) <= 2.0
     # homogeneity: halving the input (exact in f32) halves every magnitude bit for bit
     half = eng.stft_batch(pcm * 0.5)
-    assert bool(torch.equal(half * 2.0, mags))
+    half *= 2.0
+    assert bool(torch.equal(half, mags))
+    del half
     # Parseval per frame: sum_k (m_k W/2)^2 over k=1..W-1 vs the windowed energy (DC/Nyquist excluded: loose bound)
     win = torch.from_numpy(eng.window()).cuda()
     idx = torch.arange(W, device="cuda")[None, :] + (torch.tensor(ts, device="cuda") * H)[:, None]
@@ -258,12 +334,15 @@ def test_full_size_properties(torch_cuda, mags_err):
     assert rel < 2e-2
     # determinism and shard-independence: any split of the frame range gives the same bytes
     a = eng.checksum(mags)
+    del mags
     again = eng.stft_batch(pcm)
     assert eng.checksum(again) == a
+    del again
     lo = eng.stft_batch(pcm, first_frame=0, max_frames=F // 2)
+    words_lo, c_lo = lo.numel(), eng.checksum(lo)
+    del lo
     hi = eng.stft_batch(pcm, first_frame=F // 2)
-    words_lo = lo.numel()
-    assert (eng.checksum(lo) + eng.checksum(hi, base_word=words_lo)) % (1 << 64) == a
+    assert (c_lo + eng.checksum(hi, base_word=words_lo)) % (1 << 64) == a
 
 
 def test_stream_longer_than_2_to_32_samples(torch_cuda, mags_err):
