@@ -304,5 +304,14 @@ def test_oracle_fft_on_random_lengths_against_numpy(seed, mags_err):
     assert truth.shape == (Wt - 1, 2)
     if Wt > 2:
         assert np.abs(oracle.fft_process(x, Wt, oracle.F64) - truth).max() <= 1e-11 * np.abs(truth).max()
-        assert mags_err(oracle.fft_process(x, Wt, oracle.F32), truth) <= 1.0
+        # the float32 mode evaluates a prime factor p of 2W as a plain p-term float32 sum (FFTW would use Rader /
+        # Bluestein there): its error grows with p, and for the large primes it is the float64 mode that is the
+        # reference (the GPU's chirp-z kernel is held to 1x against it: tests/test_gpu_fuzz.py)
+        p, big, m = 2, 1, 2 * Wt
+        while p * p <= m:
+            while m % p == 0:
+                big, m = p, m // p
+            p += 1
+        big = max(big, m) if m > 1 else big
+        assert mags_err(oracle.fft_process(x, Wt, oracle.F32), truth) <= (1.0 if big <= 64 else 4.0)
     assert oracle.fft_process(x[:Wt - 1], Wt) is None                     # fft.rs:72
