@@ -88,6 +88,7 @@ typedef struct sgx_config {
 #define SGX_FLAG_PACKED_KERNEL 8u  /* W = 2048: workgroup-per-transform kernel with packed (re, im) arithmetic instead of scalar (A/B) */
 #define SGX_FLAG_INDEPENDENT_FRAMES 16u /* mono: one transform per frame (the reference's (s, s) dataflow) instead of two frames
                                            per transform; half the throughput, no cross-frame rounding floor */
+#define SGX_FLAG_LUT_WALK 64u      /* fused pixel kernel: walk the dB thresholds from the log2 seed even where the host has shown that one compare pair settles the LUT index (A/B, and the test of the fallback) */
 #define SGX_FLAG_LEGACY_16K 32u    /* W = 8192: the first 16384-point kernel (whole transform in LDS, one workgroup per CU) instead of the four-residue one (A/B) */
 #define SGX_FLAG_WAVE_KERNEL 2u   /* W = 2048: use the wave-per-transform kernel instead of the workgroup-per-transform one (A/B) */
 
@@ -103,7 +104,8 @@ typedef struct sgx_info {
     uint32_t sample_rate_u32; /* SampleRate(sample_rate as u32)      simple_spectrogram.rs:138 */
     uint32_t total_samples_per_column; /* sum over rows of magnitude_in's sample count */
     uint32_t stft_kernel;     /* 0 = generic power-of-two, 1 = 4096-point wave-per-transform, 2 = 4096-point workgroup-per-transform (default), 3 = the same with packed (re, im) arithmetic, 4 = Bluestein chirp-z (any 2W), 5 = 16384-point as four 4096-point residues (default for W = 8192), 6 = mixed radix (2W = 2^a 3^b 5^c 7^d <= 20480, e.g. the application's 4800, 4410 and 19200), 7 = 16384-point, whole transform in LDS (SGX_FLAG_LEGACY_16K) */
-    uint32_t reserved;
+    uint32_t render_path;     /* sgx_render_batch as configured NOW (palette included): bit 0 = one fused PCM-to-pixel kernel,
+                                 bit 1 = its LUT index is seed + one compare pair (else seed + walk); 0 = two kernels */
     uint64_t mags_bytes_per_frame; /* pairs * M * 2 * 4 */
     uint64_t rgba_bytes_per_frame; /* pairs * R * 4     */
 } sgx_info;

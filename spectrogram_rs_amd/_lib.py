@@ -26,6 +26,7 @@ FLAG_NO_FUSED_RENDER = 4
 FLAG_PACKED_KERNEL = 8
 FLAG_INDEPENDENT_FRAMES = 16
 FLAG_LEGACY_16K = 32
+FLAG_LUT_WALK = 64
 LIVE_MAGS, LIVE_MAGS_F16, LIVE_RGBA = 0, 1, 2
 LIVE_REFERENCE_SKIP = 1
 
@@ -70,7 +71,7 @@ class sgx_info(C.Structure):
         ("sample_rate_u32", C.c_uint32),
         ("total_samples_per_column", C.c_uint32),
         ("stft_kernel", C.c_uint32),
-        ("reserved", C.c_uint32),
+        ("render_path", C.c_uint32),
         ("mags_bytes_per_frame", C.c_uint64),
         ("rgba_bytes_per_frame", C.c_uint64),
     ]

@@ -280,6 +280,9 @@ int sgx_query(const sgx_ctx *c, sgx_info *out)
     out->sample_rate_u32 = c->sr_u32;
     out->total_samples_per_column = (uint32_t)c->tab.samples.size();
     out->stft_kernel = (uint32_t)c->stft_kernel;
+    out->render_path = 0;
+    if ((c->stft_kernel == 2 || c->stft_kernel == 3) && !(c->cfg.flags & SGX_FLAG_NO_FUSED_RENDER) && sgx::wg4096_can_fuse_render(c, c->d_fast_wg))
+        out->render_path = 1u | (sgx::wg4096_seed_is_within_one(c) ? 2u : 0u);
     out->mags_bytes_per_frame = (uint64_t)c->pairs * c->M * 2 * sizeof(float);
     out->rgba_bytes_per_frame = (uint64_t)c->pairs * c->R * 4;
     return SGX_OK;

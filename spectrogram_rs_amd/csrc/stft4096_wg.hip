@@ -20,6 +20,8 @@
 // Mono streams (a mono sample is duplicated into (s, s): audio_input_list_model.rs:67-69) pack
 // TWO consecutive frames into one transform: frame 2j in the real part, frame 2j+1 in the
 // imaginary part; the same split that separates left from right separates the two frames.
+#include <cmath>
+
 #include "stft4096_wg.hpp"
 #ifndef SGX_ABL_NSTORE
 #define SGX_ABL_NSTORE 8
@@ -57,14 +59,15 @@ __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
     float2 *buf = reinterpret_cast<float2 *>(smem_raw);
     float2 *tw2 = buf + kBufComplex;
 
-    float *thr = reinterpret_cast<float *>(tw2 + 256);          // RENDER only: [256] (255 used)
-    uchar4 *lut = reinterpret_cast<uchar4 *>(thr + 256);        // RENDER only: [256]
+    float *thr = reinterpret_cast<float *>(tw2 + 256);          // RENDER only: thrx[kThrFloats] (pixel_for)
+    uchar4 *lut = reinterpret_cast<uchar4 *>(thr + kThrFloats); // RENDER only: [256]
 
     const int tid = threadIdx.x;
     tw2[tid] = p.tw2[tid];
     uint32_t row_words[4] = {0u, 0u, 0u, 0u};  // RENDER: the table words of this thread's rows tid + 256 i
     if (RENDER) {
-        thr[tid] = tid < 255 ? p.lut_thr[tid] : __builtin_nanf("");
+        thr[1 + tid] = tid < 255 ? p.lut_thr[tid] : __builtin_nanf("");
+        if (tid == 0) thr[0] = -__builtin_inff();
         lut[tid] = p.lut_rgba[tid];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -332,6 +335,30 @@ __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
     }
 }
 
+// Is the kernel's LUT-index seed floor(log2(power + 1e-7) a + b) (pixel_for) within one of the exact threshold count
+// for EVERY power?  u(p) = log2(p + 1e-7) a + b is monotone in p and the count steps from e to e + 1 at lut_thr[e]
+// (the exact switch point of the host's float32 evaluation, found by bisection over bit patterns), so it is enough
+// to look at the switch points: with u(lut_thr[e]) inside (e + 0.5, e + 1.5) for every e, a power between two
+// neighbouring switch points has u inside (count - 0.5, count + 1.5) and its floor is count - 1, count or count + 1.
+// The device's v_log_f32 (1 ulp), its float32 add and fma move u by less than 1e-3 -- far inside the half index kept
+// in hand.  Thresholds at +0 (levels every power reaches: dB ranges that start below the 1e-7 floor) are fine as long
+// as u(0) is not below their count; unreachable levels (NaN) or anything else unusual: walk instead.
+bool seed_within_one(const std::vector<float> &lut_thr, double guess_a, double guess_b)
+{
+    if (lut_thr.size() != 255) return false;
+    auto u = [&](double pw) { return log2(pw + 1e-7) * guess_a + guess_b; };
+    size_t zeros = 0;
+    for (size_t e = 0; e < lut_thr.size(); ++e) {
+        const float t = lut_thr[e];
+        if (!(t == t) || t < 0.0f || !std::isfinite(t)) return false;
+        if (e > 0 && t < lut_thr[e - 1]) return false;
+        if (t == 0.0f) { zeros = e + 1; continue; }
+        const double ue = u((double)t);
+        if (!(ue > (double)e + 0.5 && ue < (double)e + 1.5)) return false;
+    }
+    return u(0.0) > (double)zeros - 0.5;
+}
+
 }  // namespace wg
 
 hipError_t wg4096_init(sgx_ctx *c, void **out)
@@ -414,6 +441,26 @@ bool wg4096_can_fuse_render(const sgx_ctx *c, const void *tables)
 
 namespace {
 
+void seed_coefficients(const sgx_ctx *c, float &a, float &b)
+{
+    // t * n = (10 log10(x) - min_db) * n / (max_db - min_db) = log2(x) * a + b   (seed only)
+    const double span = (double)c->cfg.max_db - (double)c->cfg.min_db;
+    const double n = c->cfg.lut_index_mode == SGX_LUT_ROUND_NM1 ? 255.0 : 256.0;
+    a = (float)(10.0 * log10(2.0) * n / span);
+    b = (float)(-(double)c->cfg.min_db * n / span + (c->cfg.lut_index_mode == SGX_LUT_ROUND_NM1 ? 0.5 : 0.0));
+}
+
+}  // namespace
+
+bool wg4096_seed_is_within_one(const sgx_ctx *c)
+{
+    float a, b;
+    seed_coefficients(c, a, b);
+    return !(c->cfg.flags & SGX_FLAG_LUT_WALK) && wg::seed_within_one(c->pal.lut_thr, (double)a, (double)b);
+}
+
+namespace {
+
 template <bool RENDER>
 hipError_t launch_wg(const sgx_ctx *c, const void *tables, const float *d_pcm, uint32_t channels, uint32_t pairs,
                      size_t first_frame, size_t n_frames, size_t total_frames, float *d_mags, uint8_t *d_rgba, bool out_f16 = false)
@@ -449,11 +496,8 @@ hipError_t launch_wg(const sgx_ctx *c, const void *tables, const float *d_pcm, u
             p.rgba = d_rgba;
             p.R = c->R;
             p.interp = c->cfg.interp;
-            // t * n = (10 log10(x) - min_db) * n / (max_db - min_db) = log2(x) * a + b   (seed only)
-            const double span = (double)c->cfg.max_db - (double)c->cfg.min_db;
-            const double n = c->cfg.lut_index_mode == SGX_LUT_ROUND_NM1 ? 255.0 : 256.0;
-            p.guess_a = (float)(10.0 * log10(2.0) * n / span);
-            p.guess_b = (float)(-(double)c->cfg.min_db * n / span + (c->cfg.lut_index_mode == SGX_LUT_ROUND_NM1 ? 0.5 : 0.0));
+            seed_coefficients(c, p.guess_a, p.guess_b);
+            p.seed_pm1 = wg4096_seed_is_within_one(c) ? 1u : 0u;
         }
         // mono normally rides two frames per transform; SGX_FLAG_INDEPENDENT_FRAMES runs it as (s, s) pairs
         const bool mono = channels == 1 && !(c->cfg.flags & SGX_FLAG_INDEPENDENT_FRAMES);

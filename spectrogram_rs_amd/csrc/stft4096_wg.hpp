@@ -21,7 +21,8 @@ constexpr int kS1 = 272;            // row stride (complex) of the pass-1 -> pas
 constexpr int kS2 = 257;            // row stride (complex) of the pass-2 -> pass-3 image [t0][q1 + 16 q2]
 constexpr int kBufComplex = 16 * kS1;  // 4352 complex = 34 816 B (also holds 16*257 and 9*256)
 constexpr size_t kLdsBytes = (size_t)(kBufComplex + 256) * sizeof(float2);
-constexpr size_t kLdsBytesRender = kLdsBytes + 256 * sizeof(float) + 256 * sizeof(uchar4);
+constexpr int kThrFloats = 260;        // thrx[0] = -inf, thrx[1 + i] = threshold i (i < 255), thrx[256] = NaN, padding
+constexpr size_t kLdsBytesRender = kLdsBytes + kThrFloats * sizeof(float) + 256 * sizeof(uchar4);
 
 struct PackedSample {
     int32_t i0;   // cubic: floor(index); cosine: low
@@ -48,6 +49,7 @@ struct Params {
     uint8_t *rgba;             // [F][pairs][R][4]
     uint32_t R, interp;
     float guess_a, guess_b;    // LUT index ~ floor(log2(power + 1e-7) * a + b), then exact fix-up
+    uint32_t seed_pm1;         // the host has shown that this seed is never off by more than one (seed_within_one): one compare pair fixes it
 };
 
 // Which two mono frames share a transform: always (2j, 2j+1).
@@ -172,16 +174,30 @@ __device__ __forceinline__ void sample_pass(const Params &p, const float2 *m2, f
     }
 }
 
-// colorscheme.rs:59-61 as a threshold count; the log2 only seeds the search
-__device__ __forceinline__ uchar4 pixel_for(const Params &p, float l, float r, const float *thr, const uchar4 *lut)
+// colorscheme.rs:59-61 as a threshold count: the LUT index is the number of thresholds the power has reached, the
+// thresholds being the exact switch points of the host's float32 evaluation (sgx_tables.cpp).  v_log_f32 only SEEDS the
+// count.  thrx[0] = -inf, thrx[1 + i] = threshold i, thrx[256] = NaN (no power reaches it).
+//   seed_pm1 (the usual case): the host has checked, threshold by threshold, that the exact value the seed approximates
+//     lies within half an index of the count at every switch point (seed_within_one), so the seed is the count or one
+//     off and ONE pair of compares -- both table words fetched together -- settles it: no loop, no dependent LDS reads.
+//     (A NaN power: the seed is 0 and neither compare holds -> index 0, as the loops below give.)
+//   otherwise (dB ranges below the 1e-7 floor, unreachable levels): walk, as the first version of this kernel did.
+__device__ __forceinline__ uchar4 pixel_for(const Params &p, float l, float r, const float *thrx, const uchar4 *lut)
 {
     const float power = (l * l) + (r * r);
     int idx = (int)floorf(fmaf(__builtin_amdgcn_logf(power + 1e-7f), p.guess_a, p.guess_b));
     idx = idx < 0 ? 0 : (idx > 255 ? 255 : idx);
-    while (idx < 255 && power >= thr[idx]) ++idx;
-    while (idx > 0 && !(power >= thr[idx - 1])) --idx;
+    if (p.seed_pm1) {
+        const float lo = thrx[idx], hi = thrx[idx + 1];
+        idx += (power >= hi ? 1 : 0) - (power < lo ? 1 : 0);
+    } else {
+        while (idx < 255 && power >= thrx[idx + 1]) ++idx;
+        while (idx > 0 && !(power >= thrx[idx])) --idx;
+    }
     return lut[idx];  // alpha = 1.0 -> 255
 }
+
+bool seed_within_one(const std::vector<float> &lut_thr, double guess_a, double guess_b);
 
 // MONO: .x / .y of a sample are the two columns (frames) of the transform, each a (s, s) pixel; else one (l, r) pixel.
 // (Tried, same-device A/B: the thread's sample-table words and row words requested before the two barriers and the
@@ -189,7 +205,7 @@ __device__ __forceinline__ uchar4 pixel_for(const Params &p, float l, float r, c
 // kernels sit at the 128-VGPR cap of four waves per SIMD and every extra live value becomes scratch traffic.)
 template <bool MONO>
 __device__ __forceinline__ void row_pass(const Params &p, const uint32_t (&row_words)[4], const float2 *vbuf, uchar4 *dst_a, uchar4 *dst_b,
-                                         bool have_a, bool have_b, const float *thr, const uchar4 *lut, int tid)
+                                         bool have_a, bool have_b, const float *thr, const uchar4 *lut, int tid)  // thr: the thrx table of pixel_for
 {
     int i_row = 0;
     for (uint32_t py = tid; py < p.R; py += 256, ++i_row) {

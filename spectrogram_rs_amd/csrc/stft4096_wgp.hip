@@ -62,14 +62,15 @@ __global__ void __launch_bounds__(256, 4) stft4096_wgp_kernel(Params p)
     float2 *buf = reinterpret_cast<float2 *>(smem_raw);
     float2 *tw2 = buf + kBufComplex;
 
-    float *thr = reinterpret_cast<float *>(tw2 + 256);          // RENDER only: [256] (255 used)
-    uchar4 *lut = reinterpret_cast<uchar4 *>(thr + 256);        // RENDER only: [256]
+    float *thr = reinterpret_cast<float *>(tw2 + 256);          // RENDER only: thrx[kThrFloats] (pixel_for)
+    uchar4 *lut = reinterpret_cast<uchar4 *>(thr + kThrFloats); // RENDER only: [256]
 
     const int tid = threadIdx.x;
     tw2[tid] = p.tw2[tid];
     uint32_t row_words[4] = {0u, 0u, 0u, 0u};  // RENDER: the table words of this thread's rows tid + 256 i
     if (RENDER) {
-        thr[tid] = tid < 255 ? p.lut_thr[tid] : __builtin_nanf("");
+        thr[1 + tid] = tid < 255 ? p.lut_thr[tid] : __builtin_nanf("");
+        if (tid == 0) thr[0] = -__builtin_inff();
         lut[tid] = p.lut_rgba[tid];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -310,6 +311,7 @@ hipError_t launch_wgp(const sgx_ctx *c, const void *tables, const float *d_pcm, 
             const double n = c->cfg.lut_index_mode == SGX_LUT_ROUND_NM1 ? 255.0 : 256.0;
             p.guess_a = (float)(10.0 * log10(2.0) * n / span);
             p.guess_b = (float)(-(double)c->cfg.min_db * n / span + (c->cfg.lut_index_mode == SGX_LUT_ROUND_NM1 ? 0.5 : 0.0));
+            p.seed_pm1 = wg4096_seed_is_within_one(c) ? 1u : 0u;
         }
         // mono normally rides two frames per transform; SGX_FLAG_INDEPENDENT_FRAMES runs it as (s, s) pairs
         const bool mono = channels == 1 && !(c->cfg.flags & SGX_FLAG_INDEPENDENT_FRAMES);

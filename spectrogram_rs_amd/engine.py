@@ -21,7 +21,7 @@ class SpectrogramEngine:
                  interp: int = _lib.INTERP_CUBIC, lut_index_mode: int = _lib.LUT_FLOOR_N,
                  device: Optional[int] = None, force_generic: bool = False, gradient: Optional[str] = None,
                  wave_kernel: bool = False, fused_render: bool = True, packed_kernel: bool = False,
-                 independent_frames: bool = False, legacy_16k: bool = False):
+                 independent_frames: bool = False, legacy_16k: bool = False, lut_walk: bool = False):
         import torch
 
         self._lib = _lib.load()
@@ -42,7 +42,8 @@ class SpectrogramEngine:
         cfg.device = -1 if device is None else int(device)
         cfg.flags = (_lib.FLAG_FORCE_GENERIC if force_generic else 0) | (_lib.FLAG_WAVE_KERNEL if wave_kernel else 0) \
             | (0 if fused_render else _lib.FLAG_NO_FUSED_RENDER) | (_lib.FLAG_PACKED_KERNEL if packed_kernel else 0) \
-            | (_lib.FLAG_INDEPENDENT_FRAMES if independent_frames else 0) | (_lib.FLAG_LEGACY_16K if legacy_16k else 0)
+            | (_lib.FLAG_INDEPENDENT_FRAMES if independent_frames else 0) | (_lib.FLAG_LEGACY_16K if legacy_16k else 0) \
+            | (_lib.FLAG_LUT_WALK if lut_walk else 0)
         if device is not None and torch.cuda.is_available():
             torch.cuda.set_device(int(device))
         rc = self._lib.sgx_create(C.byref(cfg), C.byref(self._ctx))
@@ -50,9 +51,7 @@ class SpectrogramEngine:
             msg = self._lib.sgx_last_error(None).decode()
             self._ctx = C.c_void_p()
             raise SgxError(rc, msg)
-        info = sgx_info()
-        self._check(self._lib.sgx_query(self._ctx, C.byref(info)))
-        self.info = info
+        info = self._query()
         self.W, self.P, self.M, self.H = info.window_samples, info.fft_length, info.num_frequencies, info.hop_samples
         self.channels, self.pairs, self.R = info.channels, info.pairs, info.rows
         self.sample_rate = float(sample_rate)
@@ -63,6 +62,13 @@ class SpectrogramEngine:
             self.set_builtin_gradient(gradient)
 
     # ---- plumbing --------------------------------------------------------------------------
+    def _query(self):
+        """sgx_query into self.info (again after a palette change: render_path depends on the colour scheme)"""
+        info = sgx_info()
+        self._check(self._lib.sgx_query(self._ctx, C.byref(info)))
+        self.info = info
+        return info
+
     def _check(self, rc: int) -> int:
         if rc < 0:
             raise SgxError(rc, self._lib.sgx_last_error(self._ctx).decode())
@@ -238,6 +244,7 @@ class SpectrogramEngine:
     def set_gradient(self, rgb: np.ndarray, stereo: bool = False):
         rgb = np.ascontiguousarray(rgb, np.uint8).reshape(-1, 3)
         self._check(self._lib.sgx_set_gradient(self._ctx, rgb.ctypes.data_as(C.c_void_p), rgb.shape[0], int(stereo)))
+        self._query()
 
     def set_gradient_fn(self, fn, stereo: bool = False):
         """Continuous gradient: `fn(t) -> (r, g, b)` stands in for colorous' eval_continuous(t).  It is
@@ -247,9 +254,11 @@ class SpectrogramEngine:
             out[0], out[1], out[2] = int(r), int(g), int(b)
         self._gradient_cb = _lib.GRADIENT_FN(thunk)  # keep alive: lookup_table calls it again
         self._check(self._lib.sgx_set_gradient_fn(self._ctx, C.cast(self._gradient_cb, C.c_void_p), None, int(stereo)))
+        self._query()
 
     def set_builtin_gradient(self, name: str):
         self._check(self._lib.sgx_set_builtin_gradient(self._ctx, name.encode()))
+        self._query()
 
     def lookup_table(self, resolution: int = 32) -> np.ndarray:
         out = np.empty((resolution, resolution, 4), np.float32)

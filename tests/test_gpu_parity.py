@@ -502,6 +502,21 @@ def test_fused_kernel_equals_two_kernel_path(torch_cuda, channels, frames, inter
     # sub-ranges and odd counts (a mono transform carries two frames)
     c = fused.render_batch(pcm, first_frame=5, max_frames=7).cpu().numpy()
     assert np.array_equal(c, a[5:12])
+    # the fused kernel's LUT index is its log2 seed plus ONE compare pair (the host has shown the seed is never off by
+    # more than one -- also where the dB range starts below the 1e-7 power floor, min_db < -70); SGX_FLAG_LUT_WALK
+    # makes it walk the thresholds from the seed instead, as it does where that proof fails -- the same bytes either
+    # way, over the whole level range
+    assert fused.info.render_path == 3 and split.info.render_path == 0
+    kw = dict(window_samples=W, hop_samples=H, channels=channels, interp=interp, gradient="magma")
+    walk = engine(lut_walk=True, **kw)
+    low = engine(min_db=-110.0, max_db=-20.0, **kw)
+    low_split = engine(min_db=-110.0, max_db=-20.0, fused_render=False, **kw)
+    assert walk.info.render_path == 1 and low.info.render_path == 3
+    for amp in (1.0, 1e-2, 1e-4, 0.0):       # every LUT index from the top of the ramp down to silence
+        x = pcm * amp
+        want = split.render_batch(x)
+        assert torch.equal(fused.render_batch(x), want) and torch.equal(walk.render_batch(x), want)
+        assert torch.equal(low.render_batch(x), low_split.render_batch(x))
     # a diverging scheme is not fused: still correct through the same entry point
     fused.set_gradient(np.load(os.path.join(os.path.dirname(__file__), "golden", "gradients.npz"))["plasma"], stereo=True)
     split.set_gradient(np.load(os.path.join(os.path.dirname(__file__), "golden", "gradients.npz"))["plasma"], stereo=True)

@@ -28,11 +28,13 @@ def main():
     ap.add_argument("--generic", action="store_true")
     ap.add_argument("--render", action="store_true")
     ap.add_argument("--packed", action="store_true")
+    ap.add_argument("--walk", action="store_true", help="fused pixel kernel: walk the LUT thresholds (the first version) instead of seed + one compare pair")
+    ap.add_argument("--interp", type=int, default=0)
     args = ap.parse_args()
     F = args.frames
     for ch in (1, 2):
         eng = SpectrogramEngine(48000.0, window_samples=2048, hop_samples=256, channels=ch, force_generic=args.generic,
-                                gradient="viridis", packed_kernel=args.packed)
+                                gradient="viridis", packed_kernel=args.packed, lut_walk=args.walk, interp=args.interp)
         n = (F - 1) * eng.H + eng.W
         pcm = eng.white_noise(n)
         out = torch.empty((F, 1, eng.M, 2), dtype=torch.float32, device="cuda")
