@@ -34,8 +34,11 @@
 // a 128-byte line for each 32 useful bytes.
 #include <type_traits>
 
-#if !defined(Q_HOLD) && !defined(Q_NO_HOLD)
-#define Q_NO_HOLD 1   // see the store loop
+#if !defined(Q_HOLD) && !defined(Q_NO_HOLD) && !defined(Q_STAGE)
+#define Q_STAGE 1     // see the store loop
+#endif
+#if defined(Q_STAGE) && !defined(Q_NO_HOLD)
+#define Q_NO_HOLD 1   // (the staged variant holds nothing in registers either)
 #endif
 #ifndef Q_NO_PRIO
 #define Q_PRIO 1
@@ -70,6 +73,7 @@ struct Params {
     const float2 *tw0;       // [4][16]    sign_c / W * w_64^{c a}   (sign_2 = -1: the butterfly leaves -(z0 - z1) in the odd lane)
     const float *win4;       // [4][512][4]  the Hann table of fft.rs:61 as lanes read it: [a / 4][tid][a % 4] = hann[col + 256 a + 4096 b]
     float *mags;
+    float *stage;            // [workgroups][4][512][4]: the even bins' magnitudes of the job in flight (Q_STAGE)
     unsigned long long first_frame, n_frames, total_frames, pair_base, n_jobs;
     uint32_t H, pairs;
 };
@@ -378,11 +382,11 @@ __global__ void __launch_bounds__(512, 4) stft16384_q_kernel(Params p)
                 const float qr_ = ar - pv.x, qi_ = ai + pv.y;   // a - conj(b) = 2i R^
                 ml[q3] = __builtin_amdgcn_sqrtf(fmaf(pr_, pr_, pi_ * pi_));  // the scale 1 / W rides on tw0
                 mr[q3] = __builtin_amdgcn_sqrtf(fmaf(qr_, qr_, qi_ * qi_));
-#ifdef Q_NO_HOLD
-                // every pass stores its own bins: 8 bytes per lane at a 16-byte stride; the other half of each line
-                // follows from the other pass and L2 merges them.  (Holding the even bins' magnitudes for one 16-byte
-                // store per lane costs 16 registers the software pipeline needs: with them the kernel spills, and a
-                // spill reload behind the stores drains the store stream.)
+#if defined(Q_NO_HOLD) && !defined(Q_STAGE)
+                // (variant) every pass stores its own bins: 8 bytes per lane at a 16-byte stride; the other half of each
+                // line follows from the other pass.  Measured (profiles/r02_hbm_traffic.json, first version): L2 does NOT
+                // merge the two halves -- WRITE_SIZE 2.0x the bytes written plus read-for-ownership fetches, 2.7x the
+                // algorithmic traffic in all.
                 const bool dc = q3 == 0 && S == 0 && tid == 0;   // k = 0 (DC) is not an output (fft.rs:81)
                 if (!dc && Q_STORE_OK(ml[q3])) {
                     if (MONO) {
@@ -394,6 +398,46 @@ __global__ void __launch_bounds__(512, 4) stft16384_q_kernel(Params p)
                 }
 #endif
             }
+#ifdef Q_STAGE
+            // A lane's 16 output bytes per (row, j) are the even bin of pass S = 0 and the odd bin of pass S = 1.  Holding
+            // the first in 16 registers across the second pass does not fit beside the software pipeline (spills, and a
+            // spill reload behind the stores drains the store stream); storing each pass's 8 bytes at a 16-byte stride
+            // doubles the HBM write traffic (measured).  So the even bins' magnitudes are parked in this workgroup's own
+            // 32 KB slot of a small buffer that lives in L2 (every job overwrites it; each lane reads back only what it
+            // wrote: no cross-lane ordering), and the second pass stores whole 16-byte pieces, consecutive lanes
+            // consecutive addresses.
+            {
+                const __amdgpu_buffer_rsrc_t rg = uniform_rsrc(p.stage + (size_t)blockIdx.x * (4 * 512 * 4));
+                if (S == 0) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) st_f4(rg, lane_out, g * (512 * 16), ml[2 * g], mr[2 * g], ml[2 * g + 1], mr[2 * g + 1]);
+                } else {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const u32x4 e = __builtin_amdgcn_raw_buffer_load_b128(rg, lane_out, g * (512 * 16), 17 /* sc0 sc1: served by L2 */);
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const int q3 = 2 * g + h;
+                            const float el = __uint_as_float(h ? e.z : e.x), er = __uint_as_float(h ? e.w : e.y);
+                            if (!Q_STORE_OK(ml[q3])) continue;
+                            const bool dc = q3 == 0 && tid == 0;   // k = 0 (DC) is not an output (fft.rs:81)
+                            if (MONO) {
+                                if (!dc) {
+                                    if (have_first) st_f4(r0, lane_out, 8192 * q3, el, el, ml[q3], ml[q3]);
+                                    if (have_second) st_f4(r1, lane_out, 8192 * q3, er, er, mr[q3], mr[q3]);
+                                } else {
+                                    if (have_first) st_f2(r0, lane_out, 8, ml[q3], ml[q3]);
+                                    if (have_second) st_f2(r1, lane_out, 8, mr[q3], mr[q3]);
+                                }
+                            } else {
+                                if (!dc) st_f4(r0, lane_out, 8192 * q3, el, er, ml[q3], mr[q3]);
+                                else st_f2(r0, lane_out, 8, ml[q3], mr[q3]);
+                            }
+                        }
+                    }
+                }
+            }
+#endif
 #ifndef Q_NO_HOLD
             if (S == 0) {
 #pragma unroll
@@ -439,6 +483,8 @@ __global__ void __launch_bounds__(256) deinterleave_pairs_kernel(const float *pc
 struct TablesQ {
     float2 *d_T = nullptr, *d_tw2 = nullptr, *d_tw0 = nullptr;
     float *d_win4 = nullptr;
+    float *d_stage = nullptr;    // [workgroups][4][512][4] floats: the L2-resident slots of the even bins' magnitudes
+    size_t stage_blocks = 0;
     float *d_planes = nullptr;   // de-interleave workspace, grown on demand
     size_t planes_floats = 0;
 };
@@ -517,6 +563,7 @@ void q16384_destroy(void *tables)
     if (t->d_tw0) (void)hipFree(t->d_tw0);
     if (t->d_win4) (void)hipFree(t->d_win4);
     if (t->d_planes) (void)hipFree(t->d_planes);
+    if (t->d_stage) (void)hipFree(t->d_stage);
     delete t;
 }
 
@@ -572,6 +619,15 @@ hipError_t launch_stft_q16384(const sgx_ctx *c, void *tables, const float *d_pcm
     // persistent workgroups, two per CU (72 KB of LDS each); jobs are dealt round-robin in output-row order
     unsigned long long blocks = (unsigned long long)n_cu * 2;
     if (blocks > p.n_jobs) blocks = p.n_jobs;
+    if (blocks > t->stage_blocks) {
+        hipError_t e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) return e;
+        if (t->d_stage) { (void)hipFree(t->d_stage); t->d_stage = nullptr; t->stage_blocks = 0; }
+        e = hipMalloc(reinterpret_cast<void **>(&t->d_stage), (size_t)blocks * 4 * 512 * 4 * sizeof(float));
+        if (e != hipSuccess) return e;
+        t->stage_blocks = (size_t)blocks;
+    }
+    p.stage = t->d_stage;
     const dim3 grid((unsigned)blocks), block(512);
     if (mono) hipLaunchKernelGGL((stft16384_q_kernel<true>), grid, block, kLdsBytes, c->stream, p);
     else hipLaunchKernelGGL((stft16384_q_kernel<false>), grid, block, kLdsBytes, c->stream, p);

@@ -1,8 +1,12 @@
 #!/bin/bash
-# usage: tools/pmc_bench.sh <outdir> <counter>  -- one rocprofv3 --pmc pass over bench.py (short) and the microbench
+# usage: tools/pmc_bench.sh <outdir> <counters...>  -- one rocprofv3 --pmc pass over bench.py (short: 3 timed steps, no sustain
+# window, no CPU leg; configs 2, 3 and 4 all run) and one over the microbench (known byte counts: the calibration)
 out=$1; shift
+repo=$(cd "$(dirname "$0")/.." && pwd)
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --pmc "$@" --output-format csv -d /root/repo/gpurun_out/${out}_bench -- python3 /root/repo/bench.py --steps 3 --warmup 1 --cpu-frames 0 --pixel-frames 65536 > /root/repo/gpurun_out/${out}_bench.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc "$@" --output-format csv -d $repo/gpurun_out/${out}_bench -- python3 $repo/bench.py --steps 3 --warmup 1 --sustain-s 0 --cpu-frames 0 > $repo/gpurun_out/${out}_bench.log 2>&1
 echo "pmc bench $out rc=$?"
-timeout -k 10 300 rocprofv3 --pmc "$@" --output-format csv -d /root/repo/gpurun_out/${out}_micro -- /root/repo/tools/bin/microbench > /root/repo/gpurun_out/${out}_micro.log 2>&1
-echo "pmc micro $out rc=$?"
+if [ -x $repo/tools/bin/microbench ]; then
+  timeout -k 10 300 rocprofv3 --pmc "$@" --output-format csv -d $repo/gpurun_out/${out}_micro -- $repo/tools/bin/microbench > $repo/gpurun_out/${out}_micro.log 2>&1
+  echo "pmc micro $out rc=$?"
+fi

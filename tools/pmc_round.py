@@ -1,0 +1,102 @@
+#!/usr/bin/env python3
+"""Turn one round's rocprofv3 --pmc passes over bench.py into the two summaries bench.py quotes:
+  profiles/<round>_hbm_traffic.json  -- HBM bytes per unit for the kernels of configs 2, 3 and 4 (FETCH_SIZE x 2 + WRITE_SIZE,
+                                        the gfx950 corrections of MI355X_MICROARCH.md section HBM, calibrated on known byte counts)
+  profiles/<round>_pixel_pipes.json  -- which pipe the fused pixel kernel keeps busy (SQ counters per launch)
+usage: tools/pmc_round.py <round> <fetch_bench> <fetch_micro> <write_bench> <write_micro> <sq1_bench> <sq2_bench>
+(directories under gpurun_out/ written by tools/pmc_bench.sh)"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+rnd, fb_d, fm_d, wb_d, wm_d, s1_d, s2_d = sys.argv[1:8]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def load(d):
+    acc = collections.defaultdict(list)
+    paths = sorted(glob.glob(d + "/**/*counter_collection.csv", recursive=True), key=os.path.getmtime)
+    for path in paths[-1:]:   # the newest run only (gpurun_out/ keeps earlier rounds' files beside it)
+        for r in csv.DictReader(open(path)):
+            acc[(r["Kernel_Name"], int(r["Grid_Size"]), r["Counter_Name"])].append(float(r["Counter_Value"]))
+    return acc
+
+
+def pick(acc, name_part, counter):
+    """mean counter value over the dispatches of the LARGEST grid whose kernel name contains name_part"""
+    c = [(k, v) for k, v in acc.items() if name_part in k[0] and k[2] == counter]
+    if not c:
+        return None
+    k, v = max(c, key=lambda kv: kv[0][1])
+    return sum(v) / len(v)
+
+
+fb, fm, wb, wm, s1, s2 = [load(d) for d in (fb_d, fm_d, wb_d, wm_d, s1_d, s2_d)]
+KIB = 1024.0
+out = {"how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes over `bench.py --steps 3 --warmup 1 --sustain-s 0 "
+              "--cpu-frames 0` (tools/pmc_bench.sh); counters are KiB; FETCH_SIZE x 2 (gfx950 tallies 128-B requests at 64 B), WRITE_SIZE x 1",
+       "calibration": {}}
+f = pick(fm, "copy_kernel", "FETCH_SIZE")
+if f:
+    out["calibration"]["fetch_float4_copy_ratio_raw"] = f * KIB / (262144 * 4096 * 4.0)
+vals = [sum(v) / len(v) * KIB for kk, v in wm.items() if "store_kernel<2>" in kk[0] and kk[2] == "WRITE_SIZE"]
+if vals:
+    out["calibration"]["write_float2_rows_ratio"] = (sum(vals) / len(vals)) / (262144 * 4095 * 4.0)
+
+
+def traffic(name, units, algorithmic):
+    w, f = pick(wb, name, "WRITE_SIZE"), pick(fb, name, "FETCH_SIZE")
+    if w is None or f is None:
+        return None
+    total = w * KIB + 2.0 * f * KIB
+    return {"kernel": name, "units_per_launch": units, "WRITE_SIZE_bytes": w * KIB, "FETCH_SIZE_bytes_raw": f * KIB,
+            "bytes_per_launch": total, "bytes_per_unit": total / units, "algorithmic_bytes_per_unit": algorithmic,
+            "traffic_over_algorithmic": total / units / algorithmic}
+
+
+F = 1_000_000
+t2 = traffic("stft4096_wg_kernel<true, 0, false, false>", F, 17400)
+t3 = traffic("stft4096_wg_kernel<true, 0, false, true>", F, 5120)
+hops = 20_000
+t4a = traffic("stft16384_q_kernel<false>", hops, 278496)
+t4b = traffic("deinterleave_pairs_kernel", hops, 278496)
+out["config2_stft"] = t2
+out["config3_fused_pixel"] = t3
+out["config4_transform"] = t4a
+out["config4_deinterleave"] = t4b
+if t2:
+    out["stft_bytes_per_frame"] = t2["bytes_per_unit"]
+if t3:
+    out["pixel_bytes_per_frame"] = t3["bytes_per_unit"]
+if t4a:
+    out["config4_bytes_per_hop"] = t4a["bytes_per_unit"] + (t4b["bytes_per_unit"] if t4b else 0.0)
+    out["config4_traffic_over_algorithmic"] = out["config4_bytes_per_hop"] / 278496
+json.dump(out, open(os.path.join(root, "profiles", f"{rnd}_hbm_traffic.json"), "w"), indent=1)
+
+# ---- pipes of the fused pixel kernel -------------------------------------------------------------------------------
+name = "stft4096_wg_kernel<true, 0, false, true>"
+g = lambda acc, c: pick(acc, name, c)  # noqa: E731
+pipes = {"how": "rocprofv3 --pmc SQ counters (two passes) over the same bench.py command; per launch of 1e6 frames = 5e5 transforms; "
+                "SQ_*_CYCLES / ACTIVE counters are in units of 4 clocks summed over waves; GRBM_GUI_ACTIVE summed over the 8 XCDs",
+         "kernel": name}
+for c in ("SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "GRBM_GUI_ACTIVE"):
+    pipes[c] = g(s1, c)
+for c in ("SQ_INSTS_LDS", "SQ_ACTIVE_INST_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_INSTS_VMEM_WR", "SQ_INSTS_VMEM_RD", "SQ_INSTS_SALU", "SQ_WAIT_INST_LDS"):
+    pipes[c] = g(s2, c)
+if pipes.get("GRBM_GUI_ACTIVE") and pipes.get("SQ_INSTS_VALU"):
+    cyc_per_cu = pipes["GRBM_GUI_ACTIVE"] / 8.0                 # clocks the launch lasted
+    n_simd = 256 * 4
+    pipes["launch_clocks"] = cyc_per_cu
+    # a wave64 VALU instruction occupies its SIMD for 2 clocks at full rate (SIMD-32)
+    pipes["valu_issue_fraction"] = pipes["SQ_INSTS_VALU"] * 2.0 / n_simd / cyc_per_cu
+    if pipes.get("SQ_LDS_IDX_ACTIVE"):
+        pipes["lds_array_fraction"] = pipes["SQ_LDS_IDX_ACTIVE"] / 256.0 / cyc_per_cu
+    if pipes.get("SQ_WAVE_CYCLES"):
+        pipes["wave_time_waiting_fraction"] = (pipes["SQ_WAIT_ANY"] or 0) / pipes["SQ_WAVE_CYCLES"]
+        pipes["wave_time_issue_stalled_fraction"] = (pipes["SQ_WAIT_INST_ANY"] or 0) / pipes["SQ_WAVE_CYCLES"]
+json.dump(pipes, open(os.path.join(root, "profiles", f"{rnd}_pixel_pipes.json"), "w"), indent=1)
+print(json.dumps(out, indent=1))
+print(json.dumps(pipes, indent=1))

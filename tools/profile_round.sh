@@ -1,17 +1,13 @@
 #!/bin/bash
 # usage: tools/profile_round.sh  -- everything profiles/ holds for a round, from ONE device:
 # bench line, rocprofv3 kernel trace + stats of the same command, the two HBM PMC passes, the SQ counter passes
-cd /root/repo
+repo=$(cd "$(dirname "$0")/.." && pwd)
+cd $repo
 timeout -k 10 400 python bench.py > gpurun_out/pr_bench.json 2> gpurun_out/pr_bench.err || exit 1
-(cd /tmp && export TMPDIR=/tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/gpurun_out/pr_trace -- python3 /root/repo/bench.py --cpu-frames 0 > /root/repo/gpurun_out/pr_trace.log 2>&1) || exit 1
+(cd /tmp && export TMPDIR=/tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $repo/gpurun_out/pr_trace -- python3 $repo/bench.py --cpu-frames 0 > $repo/gpurun_out/pr_trace.log 2>&1) || exit 1
 python3 tools/summarize_prof.py gpurun_out/pr_trace > gpurun_out/pr_kernel_trace.txt
 tools/pmc_bench.sh pr_fetch FETCH_SIZE && tools/pmc_bench.sh pr_write WRITE_SIZE || exit 1
-python3 tools/pmc_traffic.py gpurun_out/pr_fetch_bench gpurun_out/pr_fetch_micro gpurun_out/pr_write_bench gpurun_out/pr_write_micro > gpurun_out/pr_hbm_traffic.json  # -> profiles/hbm_traffic.json + profiles/rNN_hbm_traffic.json
-tools/pmc_run.sh pr_sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE
-tools/pmc_run.sh pr_sq2 SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_WAIT_INST_LDS
-python3 tools/pmc_summary.py gpurun_out/pr_sq1 gpurun_out/pr_sq2 > gpurun_out/pr_sq_counters.txt
-timeout -k 10 300 python tools/quick_bench.py --frames 1000000 --render > gpurun_out/pr_other.txt 2>&1
-timeout -k 10 300 python tools/quick_bench.py --extra >> gpurun_out/pr_other.txt 2>&1
-timeout -k 10 300 python tools/quick_bench.py --live >> gpurun_out/pr_other.txt 2>&1
-timeout -k 10 300 python tools/quick_bench.py --generic-sizes >> gpurun_out/pr_other.txt 2>&1
+tools/pmc_bench.sh pr_sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE
+tools/pmc_bench.sh pr_sq2 SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_WAIT_INST_LDS
+python3 tools/pmc_summary.py gpurun_out/pr_sq1_bench gpurun_out/pr_sq2_bench > gpurun_out/pr_sq_counters.txt
 echo profile round done
