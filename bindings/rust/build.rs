@@ -1,6 +1,6 @@
-// Source of the binding shown in INTEGRATION.md (not compiled in this image: no Rust toolchain).
-// build.rs
+// build.rs -- link the reference against libsgx.so (which itself links libamdhip64.so)
 fn main() {
     println!("cargo:rustc-link-search=native={}", std::env::var("SGX_LIB_DIR").unwrap());
-    println!("cargo:rustc-link-lib=dylib=sgx");           // libsgx.so (links libamdhip64.so.7)
+    println!("cargo:rustc-link-lib=dylib=sgx");
+    println!("cargo:rustc-link-lib=dylib=amdhip64");      // hipMalloc / hipMemcpy for the staging buffers of stream_batched.rs
 }

@@ -1,4 +1,3 @@
-// Source of the binding shown in INTEGRATION.md section 5c (not compiled in this image: no Rust toolchain).
 // src/devices/live_ring.rs -- the capture ring with its consumed side on the GPU.
 //
 // Replaces the pair (HeapProd<(f32, f32)>, HeapCons<(f32, f32)>) made at audio_input_list_model.rs:30 and

@@ -1,5 +1,4 @@
-// Source of the binding shown in INTEGRATION.md (not compiled in this image: no Rust toolchain).
-// src/fourier/sgx_sys.rs
+// src/fourier/sgx_sys.rs -- FFI declarations, a mirror of include/sgx.h (the parts the reference's path needs)
 use std::os::raw::{c_char, c_int, c_void};
 
 #[repr(C)]
@@ -32,6 +31,7 @@ extern "C" {
     pub fn sgx_set_gradient(ctx: *mut SgxCtx, h_rgb: *const u8, n: u32, stereo: c_int) -> c_int;
     pub fn sgx_set_gradient_fn(ctx: *mut SgxCtx, eval: extern "C" fn(f64, *mut u8, *mut c_void), user: *mut c_void,
                                stereo: c_int) -> c_int;
+    pub fn sgx_set_builtin_scheme(ctx: *mut SgxCtx, name: *const c_char, stereo: c_int) -> c_int;
     pub fn sgx_lookup_table(ctx: *mut SgxCtx, resolution: u32, h_out: *mut f32) -> c_int;
     pub fn sgx_sync(ctx: *mut SgxCtx) -> c_int;
 }
@@ -40,3 +40,5 @@ extern "C" {   // from libamdhip64, for staging buffers
     pub fn hipFree(p: *mut c_void) -> c_int;
     pub fn hipMemcpy(dst: *mut c_void, src: *const c_void, bytes: usize, kind: c_int) -> c_int;
 }
+pub const HIP_MEMCPY_HOST_TO_DEVICE: c_int = 1;
+pub const HIP_MEMCPY_DEVICE_TO_HOST: c_int = 2;

@@ -111,6 +111,8 @@ SIGNATURES = [
     ("sgx_row_sample_counts", C.c_int, [_ctx, _vp]),
     ("sgx_window", C.c_int, [_ctx, _vp]),
     ("sgx_synth_white_noise", C.c_int, [_ctx, _vp, C.c_uint64, _sz, C.c_uint32, C.c_uint32]),
+    ("sgx_set_builtin_scheme", C.c_int, [_ctx, C.c_char_p, C.c_int]),
+    ("sgx_builtin_gradient_eval", C.c_int, [C.c_char_p, C.c_double, C.POINTER(C.c_uint8)]),
     ("sgx_checksum", C.c_int, [_ctx, _vp, _sz, C.c_uint64, C.POINTER(C.c_uint64)]),
     ("sgx_checksum_add", C.c_int, [_ctx, _vp, _sz, C.c_uint64, _vp]),
 ]

@@ -20,7 +20,8 @@ class ColorScheme:
     """`gradient` is a [n][3] uint8 ramp (one of the 256-entry ramps) or a callable t -> (r, g, b)
     standing in for a continuous colorous gradient (spline ColorBrewer ramps, Turbo, Cividis, ...)."""
 
-    def __init__(self, gradient, name: str, background: Optional[Tuple[int, int, int]] = None):
+    def __init__(self, gradient, name: str, background: Optional[Tuple[int, int, int]] = None, builtin: Optional[str] = None):
+        self.builtin = builtin   # a name sgx_set_builtin_scheme knows: the engine then evaluates the gradient itself
         self.gradient_fn = gradient if callable(gradient) else None
         self.gradient = None if callable(gradient) else np.ascontiguousarray(gradient, np.uint8).reshape(-1, 3)
         self.name = name
@@ -29,12 +30,12 @@ class ColorScheme:
     @classmethod
     def new_mono(cls, gradient, name: str) -> "ColorScheme":
         """colorscheme.rs:24-30"""
-        return cls(_resolve(gradient), name, None)
+        return cls(_resolve(gradient), name, None, _builtin_name(gradient))
 
     @classmethod
     def new_stereo(cls, gradient, background: Sequence[int], name: str) -> "ColorScheme":
         """colorscheme.rs:32-39"""
-        return cls(_resolve(gradient), name, tuple(int(x) for x in background))
+        return cls(_resolve(gradient), name, tuple(int(x) for x in background), _builtin_name(gradient))
 
     @property
     def is_stereo(self) -> bool:
@@ -57,7 +58,9 @@ class ColorScheme:
         return self._eval(1.0) if self._background is None else self._eval(0.5)
 
     def apply(self, engine: SpectrogramEngine) -> None:
-        if self.gradient_fn is not None:
+        if self.builtin is not None:
+            engine.set_builtin_scheme(self.builtin, stereo=self.is_stereo)
+        elif self.gradient_fn is not None:
             engine.set_gradient_fn(self.gradient_fn, stereo=self.is_stereo)
         else:
             engine.set_gradient(self.gradient, stereo=self.is_stereo)
@@ -66,6 +69,10 @@ class ColorScheme:
         """colorscheme.rs:73-92 -- [res][res][4] float32"""
         self.apply(engine)
         return engine.lookup_table(resolution)
+
+
+def _builtin_name(gradient) -> Optional[str]:
+    return gradient if isinstance(gradient, str) and (gradient in _BREWER_ANCHORS or gradient in ("viridis", "magma", "inferno", "plasma")) else None
 
 
 def _resolve(gradient):
@@ -91,6 +98,40 @@ def _poly_gradient(cr, cg, cb):
     return fn
 
 
+def _basis_gradient(anchors):
+    """d3-interpolate's interpolateRgbBasis over ColorBrewer anchors -- what d3-scale-chromatic's ramp(scheme), which
+    colorous ports, evaluates for RED_YELLOW_BLUE ... ORANGES (colorscheme.rs:130-148): a uniform cubic B-spline per
+    channel, end anchors reflected, bytes by rounding to nearest.  The same arithmetic, in the same order, as
+    brewer_eval in csrc/sgx_api.hip (the engine's built-in); anchors generated from matplotlib's ColorBrewer data
+    (tools/gen_gradients.py -> _brewer.py).  PARITY UNPINNED against colorous (crate not vendored)."""
+    import math
+
+    a = [tuple(float(c) for c in rgb) for rgb in anchors]
+    n = len(a) - 1
+
+    def fn(t):
+        if not (t > 0.0):
+            t, i = 0.0, 0
+        elif t >= 1.0:
+            t, i = 1.0, n - 1
+        else:
+            i = int(math.floor(t * float(n)))
+        t1 = (t - float(i) / float(n)) * float(n)
+        t2 = t1 * t1
+        t3 = t2 * t1
+        out = []
+        for ch in range(3):
+            v1, v2 = a[i][ch], a[i + 1][ch]
+            v0 = a[i - 1][ch] if i > 0 else 2.0 * v1 - v2
+            v3 = a[i + 2][ch] if i < n - 1 else 2.0 * v2 - v1
+            v = ((1.0 - 3.0 * t1 + 3.0 * t2 - t3) * v0 + (4.0 - 6.0 * t2 + 3.0 * t3) * v1
+                 + (1.0 + 3.0 * t1 + 3.0 * t2 - 3.0 * t3) * v2 + t3 * v3) / 6.0
+            r = math.floor(v + 0.5)
+            out.append(int(0.0 if r < 0.0 else (255.0 if r > 255.0 else r)))
+        return tuple(out)
+    return fn
+
+
 # coefficient lists c0..c5 of  c0 + t (c1 + t (c2 + t (c3 + t (c4 + t c5))))
 CONTINUOUS = {
     # interpolateTurbo
@@ -104,16 +145,37 @@ CONTINUOUS = {
 }
 
 
+from ._brewer import ANCHORS as _BREWER_ANCHORS  # noqa: E402  (generated)
+
+CONTINUOUS.update({name: _basis_gradient(anchors) for name, anchors in _BREWER_ANCHORS.items()})
+BREWER = tuple(_BREWER_ANCHORS)   # names the engine evaluates itself (sgx_set_builtin_scheme)
+
+
 def default_color_schemes() -> List[ColorScheme]:
-    """colorscheme.rs:125-151, restricted to what this package can evaluate itself: the four 256-entry
-    ramps (tables) and the closed-form Turbo / Cividis polynomials (continuous gradients through the
-    callback route).  Any other colorous gradient -- the spline-interpolated ColorBrewer ramps, Cubehelix,
-    Cool -- is rendered by handing the engine colorous' own eval_continuous as the callback."""
+    """colorscheme.rs:125-151 in the reference's order, restricted to what this package can evaluate itself: the four
+    256-entry ramps (tables), the ColorBrewer B-spline gradients (anchors from ColorBrewer via matplotlib, d3's
+    interpolateRgbBasis) and the closed-form Turbo / Cividis polynomials -- 17 of the 19.  CUBEHELIX and COOL are
+    cubehelix-space interpolations whose parameters cannot be sourced inside this image: they are rendered by handing
+    the engine colorous' own eval_continuous as the callback (ColorScheme(callable, name))."""
+    black = (0, 0, 0)
     return [
+        ColorScheme.new_stereo("red_yellow_blue", black, "Blue-Yellow-Red (Stereo)"),
         ColorScheme.new_mono("magma", "Magma"),
         ColorScheme.new_mono("viridis", "Viridis"),
+        ColorScheme.new_stereo("red_blue", black, "Blue-Red (Stereo)"),
+        ColorScheme.new_stereo("spectral", black, "Spectral (Stereo)"),
+        ColorScheme.new_stereo("red_yellow_green", black, "Green-Yellow-Red (Stereo)"),
+        ColorScheme.new_stereo("pink_green", black, "Green-Pink (Stereo)"),
+        ColorScheme.new_stereo("purple_orange", black, "Orange-Purple (Stereo)"),
         ColorScheme.new_mono("inferno", "Inferno"),
         ColorScheme.new_mono("plasma", "Plasma"),
         ColorScheme.new_mono("cividis", "Cividis"),
+        # ColorScheme.new_mono(CUBEHELIX, "Cube-helix"): callback only
         ColorScheme.new_mono("turbo", "Turbo"),
+        # ColorScheme.new_mono(COOL, "Cool"): callback only
+        ColorScheme.new_mono("reds", "Reds"),
+        ColorScheme.new_mono("blues", "Blues"),
+        ColorScheme.new_mono("greens", "Greens"),
+        ColorScheme.new_mono("greys", "Greys"),
+        ColorScheme.new_mono("oranges", "Oranges"),
     ]

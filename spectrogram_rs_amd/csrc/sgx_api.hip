@@ -62,6 +62,40 @@ const unsigned char *builtin_gradient(const char *name)
     return nullptr;
 }
 
+// colorous' B-spline gradients (RED_YELLOW_BLUE ... ORANGES, colorscheme.rs:130-148).  [third-party] colorous 1.0.12 ports
+// d3-scale-chromatic, whose ramp(scheme) is d3-interpolate's interpolateRgbBasis over the scheme's largest ColorBrewer
+// class: a uniform cubic B-spline per channel, the end anchors reflected (v[-1] = 2 v[0] - v[1]).  The anchors are
+// generated from matplotlib's copy of ColorBrewer (tools/gen_gradients.py); the rounding to bytes (nearest, clamped) is
+// d3's `rgb` formatting and is as unverifiable offline as the rest of colorous: PARITY UNPINNED, and replaceable by the
+// integrator's own eval_continuous through sgx_set_gradient_fn.
+const sgx_brewer *brewer_gradient(const char *name)
+{
+    if (!name) return nullptr;
+    for (const sgx_brewer &g : SGX_BREWER)
+        if (!std::strcmp(name, g.name)) return &g;
+    return nullptr;
+}
+
+void brewer_eval(double t, uint8_t out[3], void *user)
+{
+    const sgx_brewer *g = static_cast<const sgx_brewer *>(user);
+    const int n = g->n - 1;
+    int i;
+    if (!(t > 0.0)) { t = 0.0; i = 0; }          // t <= 0 and NaN
+    else if (t >= 1.0) { t = 1.0; i = n - 1; }
+    else i = (int)std::floor(t * (double)n);
+    const double t1 = (t - (double)i / (double)n) * (double)n, t2 = t1 * t1, t3 = t2 * t1;
+    for (int ch = 0; ch < 3; ++ch) {
+        const double v1 = g->rgb[i][ch], v2 = g->rgb[i + 1][ch];
+        const double v0 = i > 0 ? (double)g->rgb[i - 1][ch] : 2.0 * v1 - v2;
+        const double v3 = i < n - 1 ? (double)g->rgb[i + 2][ch] : 2.0 * v2 - v1;
+        const double v = ((1.0 - 3.0 * t1 + 3.0 * t2 - t3) * v0 + (4.0 - 6.0 * t2 + 3.0 * t3) * v1 +
+                          (1.0 + 3.0 * t1 + 3.0 * t2 - 3.0 * t3) * v2 + t3 * v3) / 6.0;
+        const double r = std::floor(v + 0.5);
+        out[ch] = (uint8_t)(r < 0.0 ? 0.0 : (r > 255.0 ? 255.0 : r));
+    }
+}
+
 int upload_palette(sgx_ctx *c)
 {
     if (c->pal.segments) sgx::build_palette_segments(c->cfg.min_db, c->cfg.max_db, c->pal);
@@ -482,12 +516,26 @@ int sgx_builtin_gradient(const char *name, uint8_t *h_rgb_out)
     return SGX_OK;
 }
 
-int sgx_set_builtin_gradient(sgx_ctx *c, const char *name)
+int sgx_set_builtin_scheme(sgx_ctx *c, const char *name, int stereo)
 {
     if (!c) return SGX_ERR_INVALID_ARG;
-    const unsigned char *g = builtin_gradient(name);
-    if (!g) return fail(c, SGX_ERR_INVALID_ARG, std::string("sgx_set_builtin_gradient: unknown gradient '") + (name ? name : "(null)") + "'");
-    return sgx_set_gradient(c, g, 256, 0);
+    if (const unsigned char *g = builtin_gradient(name)) return sgx_set_gradient(c, g, 256, stereo);
+    if (const sgx_brewer *b = brewer_gradient(name)) return sgx_set_gradient_fn(c, brewer_eval, const_cast<sgx_brewer *>(b), stereo);
+    return fail(c, SGX_ERR_INVALID_ARG, std::string("sgx_set_builtin_scheme: unknown gradient '") + (name ? name : "(null)") + "'");
+}
+
+int sgx_set_builtin_gradient(sgx_ctx *c, const char *name) { return sgx_set_builtin_scheme(c, name, 0); }
+
+int sgx_builtin_gradient_eval(const char *name, double t, uint8_t rgb_out[3])
+{
+    if (!rgb_out) return SGX_ERR_INVALID_ARG;
+    if (const sgx_brewer *b = brewer_gradient(name)) { brewer_eval(t, rgb_out, const_cast<sgx_brewer *>(b)); return SGX_OK; }
+    if (const unsigned char *g = builtin_gradient(name)) {
+        const int idx = sgx::lut_index_host(t, 256, SGX_LUT_FLOOR_N);
+        std::memcpy(rgb_out, g + 3 * idx, 3);
+        return SGX_OK;
+    }
+    return SGX_ERR_INVALID_ARG;
 }
 
 int sgx_lookup_table(sgx_ctx *c, uint32_t res, float *h_out)

@@ -256,6 +256,11 @@ class SpectrogramEngine:
         self._check(self._lib.sgx_set_gradient_fn(self._ctx, C.cast(self._gradient_cb, C.c_void_p), None, int(stereo)))
         self._query()
 
+    def set_builtin_scheme(self, name: str, stereo: bool = False):
+        """ColorScheme::new_mono / new_stereo with a gradient the library evaluates itself (include/sgx.h)"""
+        self._check(self._lib.sgx_set_builtin_scheme(self._ctx, name.encode(), int(stereo)))
+        self._query()
+
     def set_builtin_gradient(self, name: str):
         self._check(self._lib.sgx_set_builtin_gradient(self._ctx, name.encode()))
         self._query()
@@ -361,6 +366,15 @@ class LiveRing:
         got = C.c_size_t(0)
         e._check(self._lib.sgx_live_tick(self._h, code, out.ctypes.data_as(C.c_void_p), max_frames, C.byref(got)))
         return out[:got.value]
+
+
+def builtin_gradient_eval(name: str, t: float):
+    """eval_continuous(t) of a built-in gradient -> (r, g, b)"""
+    lib = _lib.load()
+    out = (C.c_uint8 * 3)()
+    if lib.sgx_builtin_gradient_eval(name.encode(), float(t), out) != 0:
+        raise KeyError(name)
+    return tuple(int(x) for x in out)
 
 
 def builtin_gradient(name: str) -> np.ndarray:

@@ -688,6 +688,37 @@ def test_continuous_gradients_through_a_callback(torch_cuda):
         oracle.set_gradient_fn(None)
 
 
+@pytest.mark.parametrize("name,stereo", [("red_yellow_blue", True), ("spectral", True), ("purple_orange", True), ("reds", False), ("greys", False)])
+def test_builtin_colorbrewer_schemes(torch_cuda, name, stereo):
+    # the reference's first list entry is a diverging ColorBrewer gradient (colorscheme.rs:130): the library evaluates
+    # colorous' B-spline gradients itself (anchors from ColorBrewer, d3's interpolateRgbBasis); bytes equal the oracle
+    # driving the Python restatement of the same spline through its callback, mono and diverging rule alike
+    torch = torch_cuda
+    from spectrogram_rs_amd import ColorScheme
+    from spectrogram_rs_amd.colorscheme import CONTINUOUS, default_color_schemes
+    from spectrogram_rs_amd.engine import builtin_gradient_eval
+    pcm = oracle.white_noise(2 * (W + 15 * H), seed=78).reshape(-1, 2) * np.array([1.0, 0.3], np.float32)
+    mags = oracle.stream_process(pcm, 2, W, H)[:, 0]
+    mags = (mags * np.logspace(-4, 1.5, 16, dtype=np.float32)[:, None, None]).astype(np.float32)
+    mags[3] = 0.0
+    eng = engine(window_samples=W, hop_samples=H, channels=2)
+    eng.set_builtin_scheme(name, stereo=stereo)
+    try:
+        oracle.set_gradient_fn(CONTINUOUS[name])
+        got = eng.render_mags(to_dev(torch, mags)).cpu().numpy()
+        assert np.array_equal(got, oracle.render_columns(mags, SR, None, stereo=stereo))
+        assert np.array_equal(eng.lookup_table(32), oracle.lookup_table(None, 32, stereo=stereo))
+        # PCM to pixels through the same entry point; the ColorScheme mirror picks the built-in by name
+        scheme = [c for c in default_color_schemes() if c.builtin == name][0]
+        assert scheme.is_stereo == stereo and scheme.foreground() == builtin_gradient_eval(name, 0.5 if stereo else 1.0)
+        other = engine(window_samples=W, hop_samples=H, channels=2)
+        scheme.apply(other)
+        x = to_dev(torch, pcm * np.float32(0.05))
+        assert torch.equal(other.render_batch(x), eng.render_batch(x))
+    finally:
+        oracle.set_gradient_fn(None)
+
+
 @pytest.mark.parametrize("interp", [0, 1])
 def test_magnitude_in_over_spectrum_analyzer_bands(torch_cuda, interp):
     # FrequencySample::magnitude_in (the pixel-stage boundary, src/fourier/mod.rs:17-21) over the 128 log-spaced

@@ -114,3 +114,45 @@ def test_mixed_radix_block_index_arithmetic_is_exact_for_every_supported_length(
             ns = m
         assert ns == 1
     assert lengths > 300
+
+
+def test_default_color_schemes_follow_the_reference_list():
+    # colorscheme.rs:125-151: 19 entries; 17 are evaluated by this package (Cubehelix and Cool need colorous' own
+    # eval_continuous), in the reference's order, the diverging ones as stereo schemes on a black background
+    from spectrogram_rs_amd.colorscheme import CONTINUOUS, default_color_schemes
+    ds = default_color_schemes()
+    assert [d.name for d in ds] == ["Blue-Yellow-Red (Stereo)", "Magma", "Viridis", "Blue-Red (Stereo)", "Spectral (Stereo)",
+                                    "Green-Yellow-Red (Stereo)", "Green-Pink (Stereo)", "Orange-Purple (Stereo)", "Inferno", "Plasma",
+                                    "Cividis", "Turbo", "Reds", "Blues", "Greens", "Greys", "Oranges"]
+    assert [d.is_stereo for d in ds] == [True, False, False, True, True, True, True, True] + [False] * 9
+    assert all(d.background() == (0, 0, 0) for d in ds if d.is_stereo)
+    # the spline passes near (not through) its interior anchors and exactly through the reflected ends
+    ryb = CONTINUOUS["red_yellow_blue"]
+    assert ryb(0.0) == (165, 0, 38) and ryb(1.0) == (49, 54, 149) and ryb(0.5) == (250, 248, 193)
+    assert ryb(-3.0) == ryb(0.0) and ryb(7.0) == ryb(1.0) and ryb(float("nan")) == ryb(0.0)
+    greys = CONTINUOUS["greys"]
+    assert greys(0.0) == (255, 255, 255) and greys(1.0) == (0, 0, 0)
+    vals = [greys(i / 512.0)[0] for i in range(513)]
+    assert all(a >= b for a, b in zip(vals, vals[1:]))        # monotone ramp
+
+
+def test_builtin_gradient_eval_matches_the_python_restatement():
+    # the C++ built-in (csrc/sgx_api.hip: brewer_eval) and colorscheme._basis_gradient are the same arithmetic
+    import numpy as np
+    from spectrogram_rs_amd.colorscheme import BREWER, CONTINUOUS
+    from spectrogram_rs_amd.engine import builtin_gradient_eval
+    for name in BREWER:
+        for t in list(np.linspace(-0.05, 1.05, 1501)) + [float("nan")]:
+            assert builtin_gradient_eval(name, t) == CONTINUOUS[name](t), (name, t)
+
+
+def test_integration_md_shows_the_binding_files_verbatim():
+    # INTEGRATION.md's Rust blocks are generated from bindings/rust/*.rs (tools/sync_integration.py): no drift, no stubs
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    assert subprocess.run([sys.executable, os.path.join(root, "tools", "sync_integration.py"), "--check"]).returncode == 0
+    for name in os.listdir(os.path.join(root, "bindings", "rust")):
+        text = open(os.path.join(root, "bindings", "rust", name)).read()
+        assert "todo!" not in text and "unimplemented!" not in text, name

@@ -80,7 +80,7 @@ def app_default(frames=20000):
 
 
 if __name__ == "__main__" and "--config4" in sys.argv:
-    for ch in ((2,) if "--stereo-only" in sys.argv else (8, 2, 1)):
+    for ch in ((2,) if "--stereo-only" in sys.argv else (8,) if "--ch8-only" in sys.argv else (8, 2, 1)):
         if "--new-only" in sys.argv:
             config4(legacy=False, channels=ch)
             continue
@@ -106,7 +106,7 @@ def f16(frames=1_000_000):
 
 
 if __name__ == "__main__" and "--config4" in sys.argv:
-    for ch in ((2,) if "--stereo-only" in sys.argv else (8, 2, 1)):
+    for ch in ((2,) if "--stereo-only" in sys.argv else (8,) if "--ch8-only" in sys.argv else (8, 2, 1)):
         if "--new-only" in sys.argv:
             config4(legacy=False, channels=ch)
             continue
