@@ -177,9 +177,26 @@ __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
         if (MONO && PAIRING == kPairAdjacentRow && kSlideWindow && pending) {
             // this transform = the previous one moved on by two rows.  vmcnt counts in issue order: the two row
             // loads are complete once no more than `issued_since` younger instructions are outstanding.
-            if (issued_since >= 14) asm volatile("s_waitcnt vmcnt(14)" : "+v"(ld0), "+v"(ld1));
-            else if (issued_since >= 7) asm volatile("s_waitcnt vmcnt(7)" : "+v"(ld0), "+v"(ld1));
-            else asm volatile("s_waitcnt vmcnt(0)" : "+v"(ld0), "+v"(ld1));
+            // ONE asm statement chooses among the three waits with a scalar branch of its own.  As three statements in
+            // three C++ branches (round 1) the compiler merged their results in a phi and placed the copies
+            // `v_mov v0, v97` in FRONT of the waits of the two short paths: a read of a register whose load was still
+            // pending (gfx9 has no interlock for it).  tools/isa_check_prefetch.py (run by the Makefile) fails the build
+            // if anything touches the two registers between request and wait again.
+            asm volatile("s_cmp_ge_u32 %2, 14\n\t"
+                         "s_cbranch_scc1 1f\n\t"
+                         "s_cmp_ge_u32 %2, 7\n\t"
+                         "s_cbranch_scc1 2f\n\t"
+                         "s_waitcnt vmcnt(0)\n\t"
+                         "s_branch 3f\n"
+                         "2:\n\t"
+                         "s_waitcnt vmcnt(7)\n\t"
+                         "s_branch 3f\n"
+                         "1:\n\t"
+                         "s_waitcnt vmcnt(14)\n"
+                         "3:"
+                         : "+v"(ld0), "+v"(ld1)
+                         : "s"(__builtin_amdgcn_readfirstlane(issued_since))
+                         : "scc");
 #pragma unroll
             for (int a = 0; a < 7; ++a) sa[a] = sa[a + 2];
             sa[7] = ld0;
