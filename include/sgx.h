@@ -279,6 +279,25 @@ SGX_API int sgx_row_sample_counts(const sgx_ctx *ctx, uint32_t *h_out);
 /* the Hann table (fft.rs:61): h_out [W] */
 SGX_API int sgx_window(const sgx_ctx *ctx, float *h_out);
 
+/* ---- the default widget's variant: F16F16 ring texture + fragment program ---------------------
+ * GPUSpectrogram keeps its frames as rows of a VIEWPORT_FRAMES x (W - 1) F16F16 texture used as a ring
+ * (gpu_spectrogram.rs:21,67,218-226) and draws it with a fragment program (:150-186: log-frequency lookup, dB, pan,
+ * 32 x 32 palette texture).  sgx_view is that texture on the device and that program as a kernel.  Not a parity target:
+ * OpenGL leaves the filtering arithmetic to the implementation; the program text and the sampler state are restated
+ * (GL_LINEAR = two nearest texels per axis weighted by the fractional part, REPEAT for the ring, CLAMP for the
+ * palette; float32; the shader's hard-coded 32 / 22030 Hz, quirk Q9).  Destroy views before sgx_destroy(ctx). */
+typedef struct sgx_view sgx_view;
+SGX_API int sgx_view_create(sgx_ctx *ctx, uint32_t viewport_frames /* 2048 */, sgx_view **out);
+SGX_API void sgx_view_destroy(sgx_view *view);
+/* The upload loop of render() (gpu_spectrogram.rs:255-275): append n_rows rows of [M][2] half -- a DEVICE pointer,
+ * e.g. what sgx_stft_batch_f16 wrote -- at the ring's offset, wrapping at its height; the new offset is returned. */
+SGX_API int sgx_view_write_rows(sgx_view *view, const void *d_rows_f16, size_t n_rows, uint32_t *offset_out);
+SGX_API uint32_t sgx_view_offset(const sgx_view *view);
+/* The fragment program over a width x height viewport: d_rgba_f32 [height][width][4] float = f_color per fragment, row 0
+ * at the BOTTOM (GL).  The palette texture is ColorScheme::lookup_table(32) of the context's current colour scheme,
+ * min_db / max_db the context's. */
+SGX_API int sgx_view_draw(sgx_view *view, uint32_t width, uint32_t height, float *d_rgba_f32);
+
 /* ---- synthetic input + verification helpers (bench / multi-GPU harness, not reference API) -- */
 
 /* Counter-based white noise, identical on CPU and GPU:

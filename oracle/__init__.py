@@ -75,6 +75,8 @@ def lib():
         L.orc_render_column.restype = None
         L.orc_render_column.argtypes = [fp, C.c_size_t, C.c_uint32, C.c_int, C.c_double, C.c_double, C.c_int, u8p,
                                         C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, u8p]
+        L.orc_glsl_fragments.restype = None
+        L.orc_glsl_fragments.argtypes = [C.POINTER(C.c_uint16), C.c_size_t, C.c_size_t, C.c_size_t, fp, C.c_float, C.c_float, C.c_size_t, C.c_size_t, fp]
         L.orc_lookup_table.restype = None
         L.orc_lookup_table.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int, fp]
         L.orc_set_gradient_fn.restype = None
@@ -283,6 +285,19 @@ def lookup_table(gradient: np.ndarray, resolution: int = 32, stereo: bool = Fals
 
 
 # ---- synthetic inputs ----------------------------------------------------------------------
+def glsl_fragments(ring_f16: np.ndarray, offset: int, palette32: np.ndarray, width: int, height: int,
+                   min_db: float = -70.0, max_db: float = -10.0) -> np.ndarray:
+    """The fragment program of GPUSpectrogram (gpu_spectrogram.rs:150-186): ring_f16 [rows][M][2] float16, palette32
+    [32][32][4] float32 = lookup_table(32); returns [height][width][4] float32, row 0 at the bottom."""
+    ring = np.ascontiguousarray(ring_f16, np.float16)
+    rows, M = ring.shape[0], ring.shape[1]
+    pal = np.ascontiguousarray(palette32, np.float32).reshape(32, 32, 4)
+    out = np.empty((height, width, 4), np.float32)
+    lib().orc_glsl_fragments(ring.view(np.uint16).ctypes.data_as(C.POINTER(C.c_uint16)), M, rows, offset, _fp(pal),
+                             min_db, max_db, width, height, _fp(out))
+    return out
+
+
 def white_noise(n: int, first: int = 0, seed: int = 0x5EED0001) -> np.ndarray:
     out = np.empty(n, np.float32)
     lib().orc_white_noise(seed, first, n, _fp(out))

@@ -577,6 +577,101 @@ void orc_lookup_table(const uint8_t *gradient, int n_lut, int lut_mode, int ster
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* GPUSpectrogram's fragment program  (widgets/gpu_spectrogram.rs:150-186)                    */
+/* [third-party] OpenGL leaves GL_LINEAR's arithmetic to the implementation: restated are the  */
+/* program text and the sampler state the reference sets (:282-289): the two nearest texels   */
+/* per axis weighted by the fractional part of s * size - 0.5, REPEAT for the F16F16 ring,     */
+/* CLAMP (to edge) for the 32 x 32 palette; float32.  NaN coordinates sample coordinate 0.     */
+/* Not a parity target: the widget variant's checker.               */
+/* ------------------------------------------------------------------------------------------ */
+
+static float half_to_float(uint16_t h)
+{
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+    uint32_t e = (h >> 10) & 0x1fu, m = h & 0x3ffu, bits;
+    if (e == 0) {
+        if (m == 0) bits = sign;
+        else {                       /* subnormal half: renormalise */
+            e = 127 - 15 + 1;
+            while (!(m & 0x400u)) { m <<= 1; --e; }
+            bits = sign | (e << 23) | ((m & 0x3ffu) << 13);
+        }
+    } else if (e == 31) bits = sign | 0x7f800000u | (m << 13);
+    else bits = sign | ((e + 127 - 15) << 23) | (m << 13);
+    float f;
+    memcpy(&f, &bits, 4);
+    return f;
+}
+
+static int wrap_repeat(float f, int n)
+{
+    int i = (int)fmodf(f, (float)n);
+    return i < 0 ? i + n : i;
+}
+static int clamp_edge(float f, int n) { return f < 0.0f ? 0 : (f > (float)(n - 1) ? n - 1 : (int)f); }
+static float mixf(float u, float v, float w)
+{
+    volatile float d = v - u;
+    volatile float t = d * w;
+    return u + t;
+}
+
+void orc_glsl_fragments(const uint16_t *ring_f16, size_t M, size_t rows, size_t offset, const float *palette32,
+                        float min_db, float max_db, size_t width, size_t height, float *out)
+{
+    const float min_frequency = 32.0f, max_frequency = 22030.0f; /* the locals that shadow the uniforms (:152-153) */
+    for (size_t py = 0; py < height; ++py)
+        for (size_t px = 0; px < width; ++px) {
+            volatile float uvx = ((float)px + 0.5f) / (float)width, uvy = ((float)py + 0.5f) / (float)height;
+            volatile float log_min = logf(min_frequency), log_max = logf(max_frequency);
+            volatile float lrange = log_max - log_min;
+            volatile float lf0 = uvy * lrange;
+            volatile float log_frequency = lf0 + log_min;
+            volatile float s = expf(log_frequency) / max_frequency;            /* log_frequency_mapped */
+            volatile float t0 = uvx * (float)rows;
+            volatile float t1 = t0 + (float)offset;
+            volatile float t = t1 / (float)rows;                                /* time, with offset */
+            /* texture(fft, coord.yx): x = frequency over M texels, y = time over `rows` texels, REPEAT, LINEAR */
+            volatile float xs = s * (float)M, ys = t * (float)rows;
+            volatile float x = xs - 0.5f, y = ys - 0.5f;
+            const float fx0 = floorf(x), fy0 = floorf(y);
+            volatile float ax = x - fx0, ay = y - fy0;
+            const int x0 = wrap_repeat(fx0, (int)M), x1 = wrap_repeat(fx0 + 1.0f, (int)M);
+            const int y0 = wrap_repeat(fy0, (int)rows), y1 = wrap_repeat(fy0 + 1.0f, (int)rows);
+            float mag[2];
+            for (int ch = 0; ch < 2; ++ch) {
+                const float a = half_to_float(ring_f16[((size_t)y0 * M + x0) * 2 + ch]), b = half_to_float(ring_f16[((size_t)y0 * M + x1) * 2 + ch]);
+                const float c = half_to_float(ring_f16[((size_t)y1 * M + x0) * 2 + ch]), d = half_to_float(ring_f16[((size_t)y1 * M + x1) * 2 + ch]);
+                mag[ch] = mixf(mixf(a, b, ax), mixf(c, d, ax), ay);
+            }
+            volatile float p0 = mag[0] * mag[0], p1 = mag[1] * mag[1];
+            volatile float power = p0 + p1;
+            volatile float arg = power + 1e-7f;
+            volatile float l10 = 10.0f * logf(arg);
+            volatile float magnitude_log = l10 / logf(10.0f);
+            volatile float num = magnitude_log - min_db, den = max_db - min_db;
+            volatile float magnitude_db = num / den;
+            volatile float lr = mag[0] + mag[1];
+            volatile float pan = mag[1] / lr;
+            /* texture(palette, vec2(pan, magnitude_db)): 32 x 32, CLAMP, LINEAR */
+            float ps = pan, pt = magnitude_db;
+            if (!(ps == ps)) ps = 0.0f;
+            if (!(pt == pt)) pt = 0.0f;
+            volatile float qx = ps * 32.0f, qy = pt * 32.0f;
+            volatile float cx = qx - 0.5f, cy = qy - 0.5f;
+            const float gx0 = floorf(cx), gy0 = floorf(cy);
+            volatile float bx = cx - gx0, by = cy - gy0;
+            const int u0 = clamp_edge(gx0, 32), u1 = clamp_edge(gx0 + 1.0f, 32), v0 = clamp_edge(gy0, 32), v1 = clamp_edge(gy0 + 1.0f, 32);
+            float *o = out + 4 * (py * width + px);
+            for (int ch = 0; ch < 4; ++ch) {
+                const float a = palette32[(v0 * 32 + u0) * 4 + ch], b = palette32[(v0 * 32 + u1) * 4 + ch];
+                const float c = palette32[(v1 * 32 + u0) * 4 + ch], d = palette32[(v1 * 32 + u1) * 4 + ch];
+                o[ch] = mixf(mixf(a, b, bx), mixf(c, d, bx), by);
+            }
+        }
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* SpectrumAnalyzer  (widgets/spectrum_analyzer.rs)                                           */
 /* ------------------------------------------------------------------------------------------ */
 

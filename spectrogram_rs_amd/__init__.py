@@ -12,14 +12,14 @@ colorscheme::ColorScheme, log_scaling::LogCoordf64, widgets::SimpleSpectrogram's
 device-memory plumbing via torch.  There is no CPU fallback.
 """
 from ._lib import (INTERP_COSINE, INTERP_CUBIC, LIB_PATH, LUT_FLOOR_N, LUT_ROUND_NM1, SgxError)  # noqa: F401
-from .engine import LiveRing, SpectrogramEngine, builtin_gradient  # noqa: F401
+from .engine import LiveRing, SpectrogramEngine, ViewRing, builtin_gradient  # noqa: F401
 from .fourier import AudioStreamTransform, AudioTransform, FastFourierTransform, RingBuffer  # noqa: F401
 from .colorscheme import ColorScheme, default_color_schemes  # noqa: F401
 from .log_scaling import LogCoordf64  # noqa: F401
-from .widgets import SimpleSpectrogram, SpectrumAnalyzer  # noqa: F401
+from .widgets import GPUSpectrogram, SimpleSpectrogram, SpectrumAnalyzer  # noqa: F401
 
 __all__ = [
     "SpectrogramEngine", "builtin_gradient", "AudioTransform", "FastFourierTransform", "AudioStreamTransform",
-    "RingBuffer", "ColorScheme", "default_color_schemes", "LogCoordf64", "SimpleSpectrogram", "SpectrumAnalyzer", "LiveRing", "SgxError",
+    "RingBuffer", "ColorScheme", "default_color_schemes", "LogCoordf64", "SimpleSpectrogram", "GPUSpectrogram", "SpectrumAnalyzer", "LiveRing", "ViewRing", "SgxError",
     "INTERP_CUBIC", "INTERP_COSINE", "LUT_FLOOR_N", "LUT_ROUND_NM1", "LIB_PATH",
 ]

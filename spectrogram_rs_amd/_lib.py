@@ -113,6 +113,11 @@ SIGNATURES = [
     ("sgx_synth_white_noise", C.c_int, [_ctx, _vp, C.c_uint64, _sz, C.c_uint32, C.c_uint32]),
     ("sgx_set_builtin_scheme", C.c_int, [_ctx, C.c_char_p, C.c_int]),
     ("sgx_builtin_gradient_eval", C.c_int, [C.c_char_p, C.c_double, C.POINTER(C.c_uint8)]),
+    ("sgx_view_create", C.c_int, [_ctx, C.c_uint32, C.POINTER(C.c_void_p)]),
+    ("sgx_view_destroy", None, [C.c_void_p]),
+    ("sgx_view_write_rows", C.c_int, [C.c_void_p, _vp, _sz, C.POINTER(C.c_uint32)]),
+    ("sgx_view_offset", C.c_uint32, [C.c_void_p]),
+    ("sgx_view_draw", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, _vp]),
     ("sgx_checksum", C.c_int, [_ctx, _vp, _sz, C.c_uint64, C.POINTER(C.c_uint64)]),
     ("sgx_checksum_add", C.c_int, [_ctx, _vp, _sz, C.c_uint64, _vp]),
 ]

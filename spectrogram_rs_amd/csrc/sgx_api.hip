@@ -110,6 +110,7 @@ int upload_palette(sgx_ctx *c)
     SGX_HIP(c, upload(&c->d_lut_thr, c->pal.lut_thr.data(), c->pal.lut_thr.size()));
     SGX_HIP(c, upload(&c->d_alpha_thr, c->pal.alpha_thr.data(), c->pal.alpha_thr.size()));
     SGX_HIP(c, upload(&c->d_t_thr, c->pal.t_thr.data(), c->pal.t_thr.size()));
+    ++c->palette_gen;
     return SGX_OK;
 }
 

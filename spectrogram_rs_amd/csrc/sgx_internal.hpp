@@ -105,6 +105,8 @@ struct sgx_ctx {
     float *d_levels = nullptr;  // sgx_spectrum_levels: the bands' (l, r) means, grown on demand
     uint32_t levels_cap = 0;
 
+    unsigned long long palette_gen = 0;  // bumped by every palette upload (sgx_view rebuilds its palette texture on a change)
+
     std::string err;
 };
 

@@ -240,6 +240,16 @@ class SpectrogramEngine:
         self._rings = [r for r in self._rings if r() is not None] + [weakref.ref(ring)]
         return ring
 
+    def view(self, viewport_frames: int = 2048) -> "ViewRing":
+        """GPUSpectrogram's F16F16 ring texture + fragment program on the device (include/sgx.h: sgx_view)."""
+        import weakref
+
+        v = ViewRing(self, viewport_frames)
+        if not hasattr(self, "_rings"):
+            self._rings = []
+        self._rings = [r for r in self._rings if r() is not None] + [weakref.ref(v)]
+        return v
+
     # ---- colour scheme ---------------------------------------------------------------------
     def set_gradient(self, rgb: np.ndarray, stereo: bool = False):
         rgb = np.ascontiguousarray(rgb, np.uint8).reshape(-1, 3)
@@ -366,6 +376,55 @@ class LiveRing:
         got = C.c_size_t(0)
         e._check(self._lib.sgx_live_tick(self._h, code, out.ctypes.data_as(C.c_void_p), max_frames, C.byref(got)))
         return out[:got.value]
+
+
+class ViewRing:
+    """sgx_view: the VIEWPORT_FRAMES x (W - 1) F16F16 texture of gpu_spectrogram.rs:218-226 used as a ring (:255-275)
+    and the fragment program of :150-186 as a kernel."""
+
+    def __init__(self, engine: SpectrogramEngine, viewport_frames: int = 2048):
+        self.engine = engine
+        self.rows = int(viewport_frames)
+        self._lib = engine._lib
+        self._h = C.c_void_p()
+        engine._check(self._lib.sgx_view_create(engine._ctx, self.rows, C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.sgx_view_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def offset(self) -> int:
+        return int(self._lib.sgx_view_offset(self._h))
+
+    def write_rows(self, rows_f16) -> int:
+        """append [n][M][2] float16 rows (a device tensor, e.g. stft_batch_f16(...)[:, 0]); returns the new offset"""
+        import torch
+
+        e = self.engine
+        assert rows_f16.is_cuda and rows_f16.device == e.device and rows_f16.dtype == torch.float16 and rows_f16.is_contiguous()
+        n = rows_f16.numel() // (e.M * 2)
+        assert rows_f16.numel() == n * e.M * 2
+        e.use_current_stream()
+        off = C.c_uint32(0)
+        e._check(self._lib.sgx_view_write_rows(self._h, C.c_void_p(rows_f16.data_ptr()), n, C.byref(off)))
+        return int(off.value)
+
+    def draw(self, width: int, height: int, out=None):
+        """the fragment program over a width x height viewport -> [height][width][4] float32, row 0 at the bottom"""
+        import torch
+
+        e = self.engine
+        out = e._out(out, (height, width, 4), torch.float32)
+        e._check(self._lib.sgx_view_draw(self._h, width, height, C.c_void_p(out.data_ptr())))
+        return out
 
 
 def builtin_gradient_eval(name: str, t: float):

@@ -104,6 +104,59 @@ class SimpleSpectrogram:
         return torch.cat([self.buffer[:, self.offset:], self.buffer[:, :self.offset]], dim=1)
 
 
+VIEWPORT_FRAMES = 2048                                                        # gpu_spectrogram.rs:20
+VIEWPORT_SECONDS = np.float32(2.5)                                            # :21
+FRAMES_PER_SECOND = np.float32(np.float32(VIEWPORT_FRAMES) / VIEWPORT_SECONDS)  # :22 (f32: 819.2)
+
+
+class GPUSpectrogram:
+    """Mirror of the reference's DEFAULT visualiser (src/widgets/gpu_spectrogram.rs): frames go, as F16F16 rows, into a
+    VIEWPORT_FRAMES-row ring texture (:255-275); the picture is made per fragment from that texture and the 32 x 32
+    palette texture (:150-186).  Texture and fragment program live in the engine (sgx_view); the capture ring is the
+    engine's LiveRing (fed through `push`), ticked for half-precision rows."""
+
+    def __init__(self, *, sample_rate: int = 48000, period: float = 0.05, device: Optional[int] = None,
+                 viewport_frames: int = VIEWPORT_FRAMES):
+        self._period, self._device, self._viewport = period, device, viewport_frames
+        self.palette = ColorScheme.new_mono("magma", "magma")          # :40 (ColorScheme::new_mono(MAGMA, "magma"))
+        self.stride = np.float32(np.float32(1.0) / FRAMES_PER_SECOND)      # :81: 1f32 / FRAMES_PER_SECOND (58 samples at 48 kHz)
+        self.engine: Optional[SpectrogramEngine] = None
+        self.live = None
+        self.texture = None
+        self.set_sample_rate(sample_rate)
+
+    def set_sample_rate(self, sample_rate: int) -> None:
+        """:320-327 -- the transform is replaced and the texture is rebuilt (fft_texture.set(None))"""
+        sr = np.float32(sample_rate)
+        for h in (self.texture, self.live):
+            if h is not None:
+                h.close()
+        if self.engine is not None:
+            self.engine.close()
+        hop = max(int(np.float32(self.stride) * sr), 1)
+        self.engine = SpectrogramEngine(float(sr), period=self._period, hop_samples=hop, channels=2, device=self._device)
+        self.palette.apply(self.engine)
+        self.live = self.engine.live(max(4096, 2 * self.engine.W), reference_skip=True)
+        self.texture = self.engine.view(self._viewport)
+
+    def set_palette(self, palette: ColorScheme) -> None:
+        """:329-333"""
+        self.palette = palette
+        palette.apply(self.engine)
+
+    def push(self, data, channels: int) -> int:
+        return self.live.push(data, channels)
+
+    def render(self, width: int, height: int):
+        """:208-316 without the GL frame: upload this tick's frames, run the fragment program; [height][width][4] float32"""
+        import torch
+
+        rows = self.live.tick("mags_f16")
+        if rows.shape[0]:
+            self.texture.write_rows(torch.from_numpy(np.ascontiguousarray(rows)).to(self.engine.device))
+        return self.texture.draw(width, height)
+
+
 class SpectrumAnalyzer:
     """spectrum_analyzer.rs:38-68: `level_bars` LevelBar values (a fresh bar holds 0.3, :92); push_frequencies
     takes one frame of magnitudes ([M][2] on the engine's device) and raises / decays every bar."""

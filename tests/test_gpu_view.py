@@ -1,0 +1,96 @@
+"""The default widget's variant of the pixel path: GPUSpectrogram's F16F16 ring texture and
+fragment program (src/widgets/gpu_spectrogram.rs:150-186,218-226,255-275) as sgx_view.  Checked against the oracle's
+restatement of the same program text and sampler state; float tolerance, not bits: OpenGL leaves the filtering
+arithmetic to the implementation, so this variant is not a parity target."""
+import numpy as np
+import pytest
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+SR = 48000
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the GPU"
+    return torch
+
+
+def engine(**kw):
+    from spectrogram_rs_amd import SpectrogramEngine
+    return SpectrogramEngine(48000.0, **kw)
+
+
+def test_ring_texture_upload_wraps_like_the_reference(torch_cuda):
+    # the upload loop (:255-275): rows land at `offset`, a block that reaches the top of the texture is split,
+    # offset = (offset + block) % height
+    torch = torch_cuda
+    eng = engine(window_samples=64, hop_samples=16, channels=2, gradient="magma")
+    view = eng.view(8)
+    ring = np.zeros((8, eng.M, 2), np.float16)
+    rng = np.random.default_rng(1)
+    off = 0
+    for n in (3, 4, 6, 8, 1, 11):       # 11 > height: the texture is overwritten more than once in one call
+        rows = rng.uniform(0.0, 0.3, (n, eng.M, 2)).astype(np.float16)
+        new_off = view.write_rows(torch.from_numpy(rows).cuda())
+        for r in rows:
+            ring[off] = r
+            off = (off + 1) % 8
+        assert new_off == off == view.offset
+        got = view.draw(5, 3).cpu().numpy()
+        pal = eng.lookup_table(32)
+        assert np.allclose(got, oracle.glsl_fragments(ring, off, pal, 5, 3), atol=2e-4)
+
+
+@pytest.mark.parametrize("scheme,stereo", [("magma", False), ("red_yellow_blue", True)])
+def test_fragment_program_matches_its_restatement(torch_cuda, scheme, stereo):
+    # the application's own sizes: W 2400 (M 2399 texels wide), a 2048-row ring, real frames (half precision rows from
+    # the transform itself), a viewport whose pixel grid does not line up with the texels; mono and diverging palettes
+    torch = torch_cuda
+    eng = engine(period=0.05, hop_samples=58, channels=2)
+    eng.set_builtin_scheme(scheme, stereo=stereo)
+    n = eng.W + 58 * 299
+    t = np.arange(n) / SR
+    lr = np.stack([0.3 * np.sin(2 * np.pi * 440.0 * t) + 0.01 * oracle.white_noise(n, seed=1),
+                   0.1 * np.sin(2 * np.pi * 3000.0 * t) + 0.01 * oracle.white_noise(n, seed=2)], 1).astype(np.float32)
+    rows = eng.stft_batch_f16(torch.from_numpy(lr).cuda().reshape(-1))[:, 0].contiguous()     # [300][M][2] half
+    view = eng.view(2048)
+    assert view.write_rows(rows) == 300
+    ring = np.zeros((2048, eng.M, 2), np.float16)
+    ring[:300] = rows.cpu().numpy()
+    got = view.draw(317, 211).cpu().numpy()
+    ref = oracle.glsl_fragments(ring, 300, eng.lookup_table(32), 317, 211)
+    assert got.shape == ref.shape == (211, 317, 4)
+    # device logf / expf and the host's differ in the last bit or two: a palette coordinate moves by ~1e-6, a colour
+    # by ~1e-5; one texel boundary crossed by such a move shows up as a (rare) larger step along an edge
+    err = np.abs(got - ref)
+    assert np.quantile(err, 0.999) < 2e-4 and err.max() < 2e-2
+    # the picture is not trivial: the 440 Hz line of the left channel is visible where the ring holds frames
+    assert got[..., :3].std() > 0.01
+    # a palette change rebuilds the palette texture (set_palette, :329-333)
+    eng.set_builtin_scheme("viridis")
+    again = view.draw(317, 211).cpu().numpy()
+    assert not np.allclose(again, got, atol=1e-3)
+    assert np.quantile(np.abs(again - oracle.glsl_fragments(ring, 300, eng.lookup_table(32), 317, 211)), 0.999) < 2e-4
+
+
+def test_default_widget_mirror(torch_cuda):
+    # GPUSpectrogram: 1 / FRAMES_PER_SECOND stride (58 samples at 48 kHz), frames uploaded as half rows every render,
+    # transform + texture rebuilt on a device change (:320-327)
+    from spectrogram_rs_amd import ColorScheme, GPUSpectrogram
+    w = GPUSpectrogram(sample_rate=SR)
+    assert w.engine.H == 58 and w.engine.W == 2400 and w.texture.rows == 2048
+    tone = (0.25 * np.sin(2 * np.pi * 1000.0 * np.arange(4000) / SR)).astype(np.float32)
+    assert w.push(tone, 1) == 4000
+    frames = w.engine.num_frames(4000)
+    img = w.render(64, 48)
+    assert img.shape == (48, 64, 4) and w.texture.offset == frames and bool(torch_cuda.isfinite(img).all())
+    w.set_palette(ColorScheme.new_stereo("spectral", (0, 0, 0), "Spectral (Stereo)"))
+    img2 = w.render(64, 48)
+    assert not torch_cuda.allclose(img, img2)
+    w.set_sample_rate(44100)
+    assert w.engine.W == 2205 and w.texture.offset == 0
+    assert w.render(16, 16).shape == (16, 16, 4)
