@@ -482,6 +482,9 @@ def config5_leg(args, torch, dist, eng, rank, world, backend, barrier, max_over_
     dist.all_gather(seen, torch.tensor([rank], dtype=torch.int64, device=seen[0].device))
     ranks_seen = sorted(int(t[0]) for t in seen)
 
+    # one small untimed round first: RCCL builds its point-to-point connections lazily on first use
+    stream_columns([min(1024, c) for c in counts], 1024, produce, lambda g0, p: None, like=like, dst=0)
+    acc.zero_()
     t_over, arrived = run(produce, consume)                       # the run that counts: render + gather, overlapped
     t_comp, _ = run(produce, None, send=False)                    # render only
     t_xfer, _ = run(None, lambda g0, p: None)                     # gather only (re-sends the ring's last contents)
