@@ -414,7 +414,7 @@ __global__ void __launch_bounds__(512, 4) stft16384_q_kernel(Params p)
                 } else {
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        const u32x4 e = __builtin_amdgcn_raw_buffer_load_b128(rg, lane_out, g * (512 * 16), 17 /* sc0 sc1: served by L2 */);
+                        const u32x4 e = __builtin_amdgcn_raw_buffer_load_b128(rg, lane_out, g * (512 * 16), 2 /* nt: not from this CU's L1 (it may still hold the previous job's line), served by L2 */);
 #pragma unroll
                         for (int h = 0; h < 2; ++h) {
                             const int q3 = 2 * g + h;
