@@ -59,16 +59,13 @@ __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
     float2 *buf = reinterpret_cast<float2 *>(smem_raw);
     float2 *tw2 = buf + kBufComplex;
 
-    float *thr = reinterpret_cast<float *>(tw2 + 256);          // RENDER only: thrx[kThrFloats] (pixel_for)
-    uchar4 *lut = reinterpret_cast<uchar4 *>(thr + kThrFloats); // RENDER only: [256]
+    uint2 *pal = reinterpret_cast<uint2 *>(tw2 + 256);          // RENDER only: [256] {threshold, RGBA} (pixel_for)
 
     const int tid = threadIdx.x;
     tw2[tid] = p.tw2[tid];
     uint32_t row_words[4] = {0u, 0u, 0u, 0u};  // RENDER: the table words of this thread's rows tid + 256 i
     if (RENDER) {
-        thr[1 + tid] = tid < 255 ? p.lut_thr[tid] : __builtin_nanf("");
-        if (tid == 0) thr[0] = -__builtin_inff();
-        lut[tid] = p.lut_rgba[tid];
+        pal[tid] = make_uint2(__float_as_uint(tid < 255 ? p.lut_thr[tid] : __builtin_nanf("")), *reinterpret_cast<const uint32_t *>(&p.lut_rgba[tid]));
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             if ((uint32_t)tid + 256u * i < p.R) row_words[i] = p.rows[tid + 256 * i];
@@ -347,7 +344,7 @@ __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
             uchar4 *dst_a = rgba + ((size_t)(have_first ? f0 : 0) * p.pairs + p.pair) * (size_t)p.R;
             uchar4 *dst_b = rgba + ((size_t)f1 * p.pairs + p.pair) * (size_t)p.R;
             __builtin_amdgcn_s_setprio(3);
-            row_pass<MONO>(p, row_words, vbuf, dst_a, dst_b, have_first, have_second, thr, lut, tid);
+            row_pass<MONO>(p, row_words, vbuf, dst_a, dst_b, have_first, have_second, pal, tid);
         }
     }
 }
@@ -371,9 +368,9 @@ bool seed_within_one(const std::vector<float> &lut_thr, double guess_a, double g
         if (e > 0 && t < lut_thr[e - 1]) return false;
         if (t == 0.0f) { zeros = e + 1; continue; }
         const double ue = u((double)t);
-        if (!(ue > (double)e + 0.5 && ue < (double)e + 1.5)) return false;
+        if (!(ue > (double)e + 0.51 && ue < (double)e + 1.49)) return false;   // (the device's log, add and fma move u by < 1e-3)
     }
-    return u(0.0) > (double)zeros - 0.5;
+    return u(0.0) > (double)zeros - 0.49;
 }
 
 }  // namespace wg

@@ -21,8 +21,7 @@ constexpr int kS1 = 272;            // row stride (complex) of the pass-1 -> pas
 constexpr int kS2 = 257;            // row stride (complex) of the pass-2 -> pass-3 image [t0][q1 + 16 q2]
 constexpr int kBufComplex = 16 * kS1;  // 4352 complex = 34 816 B (also holds 16*257 and 9*256)
 constexpr size_t kLdsBytes = (size_t)(kBufComplex + 256) * sizeof(float2);
-constexpr int kThrFloats = 260;        // thrx[0] = -inf, thrx[1 + i] = threshold i (i < 255), thrx[256] = NaN, padding
-constexpr size_t kLdsBytesRender = kLdsBytes + kThrFloats * sizeof(float) + 256 * sizeof(uchar4);
+constexpr size_t kLdsBytesRender = kLdsBytes + 256 * sizeof(uint2);   // + the palette table of pixel_for: {threshold to leave index i, RGBA of index i}
 
 struct PackedSample {
     int32_t i0;   // cubic: floor(index); cosine: low
@@ -176,25 +175,33 @@ __device__ __forceinline__ void sample_pass(const Params &p, const float2 *m2, f
 
 // colorscheme.rs:59-61 as a threshold count: the LUT index is the number of thresholds the power has reached, the
 // thresholds being the exact switch points of the host's float32 evaluation (sgx_tables.cpp).  v_log_f32 only SEEDS the
-// count.  thrx[0] = -inf, thrx[1 + i] = threshold i, thrx[256] = NaN (no power reaches it).
-//   seed_pm1 (the usual case): the host has checked, threshold by threshold, that the exact value the seed approximates
-//     lies within half an index of the count at every switch point (seed_within_one), so the seed is the count or one
-//     off and ONE pair of compares -- both table words fetched together -- settles it: no loop, no dependent LDS reads.
-//     (A NaN power: the seed is 0 and neither compare holds -> index 0, as the loops below give.)
-//   otherwise (dB ranges below the 1e-7 floor, unreachable levels): walk, as the first version of this kernel did.
-__device__ __forceinline__ uchar4 pixel_for(const Params &p, float l, float r, const float *thrx, const uchar4 *lut)
+// count.  pal[i] = {the smallest power whose index is i + 1 (NaN for i = 255: no power leaves the last index), RGBA of i}.
+//   seed_pm1 (the usual case): the host has checked, threshold by threshold, that the exact value u the seed approximates
+//     lies within half an index of the count at every switch point (seed_within_one), so floor(u - 1/2) is the count or
+//     one below it: ONE 16-byte LDS access brings that entry's threshold and both candidate colours, one compare picks.
+//     No loop, no second (dependent) LDS access for the colour.  (A NaN power: the seed is 0 and the compare fails ->
+//     index 0, as the walk below gives.)
+//   otherwise (unreachable levels, SGX_FLAG_LUT_WALK): walk from the seed, as the first version of this kernel did.
+__device__ __forceinline__ uchar4 pixel_for(const Params &p, float l, float r, const uint2 *pal)
 {
     const float power = (l * l) + (r * r);
-    int idx = (int)floorf(fmaf(__builtin_amdgcn_logf(power + 1e-7f), p.guess_a, p.guess_b));
-    idx = idx < 0 ? 0 : (idx > 255 ? 255 : idx);
+    const float u = fmaf(__builtin_amdgcn_logf(power + 1e-7f), p.guess_a, p.guess_b);
+    uint32_t rgba;
     if (p.seed_pm1) {
-        const float lo = thrx[idx], hi = thrx[idx + 1];
-        idx += (power >= hi ? 1 : 0) - (power < lo ? 1 : 0);
+        int idx = (int)floorf(u - 0.5f);
+        idx = idx < 0 ? 0 : (idx > 254 ? 254 : idx);
+        const uint2 e0 = pal[idx], e1 = pal[idx + 1];
+        rgba = power >= __uint_as_float(e0.x) ? e1.y : e0.y;
     } else {
-        while (idx < 255 && power >= thrx[idx + 1]) ++idx;
-        while (idx > 0 && !(power >= thrx[idx])) --idx;
+        int idx = (int)floorf(u);
+        idx = idx < 0 ? 0 : (idx > 255 ? 255 : idx);
+        while (idx < 255 && power >= __uint_as_float(pal[idx].x)) ++idx;
+        while (idx > 0 && !(power >= __uint_as_float(pal[idx - 1].x))) --idx;
+        rgba = pal[idx].y;
     }
-    return lut[idx];  // alpha = 1.0 -> 255
+    uchar4 c;
+    c.x = rgba & 0xff; c.y = (rgba >> 8) & 0xff; c.z = (rgba >> 16) & 0xff; c.w = rgba >> 24;   // alpha = 1.0 -> 255
+    return c;
 }
 
 bool seed_within_one(const std::vector<float> &lut_thr, double guess_a, double guess_b);
@@ -205,7 +212,7 @@ bool seed_within_one(const std::vector<float> &lut_thr, double guess_a, double g
 // kernels sit at the 128-VGPR cap of four waves per SIMD and every extra live value becomes scratch traffic.)
 template <bool MONO>
 __device__ __forceinline__ void row_pass(const Params &p, const uint32_t (&row_words)[4], const float2 *vbuf, uchar4 *dst_a, uchar4 *dst_b,
-                                         bool have_a, bool have_b, const float *thr, const uchar4 *lut, int tid)  // thr: the thrx table of pixel_for
+                                         bool have_a, bool have_b, const uint2 *pal, int tid)
 {
     int i_row = 0;
     for (uint32_t py = tid; py < p.R; py += 256, ++i_row) {
@@ -226,10 +233,10 @@ __device__ __forceinline__ void row_pass(const Params &p, const uint32_t (&row_w
         }
         const uint32_t y = p.R - 1 - py;  // simple_spectrogram.rs:150
         if (MONO) {  // mono -> (s, s): both channels carry the same magnitude
-            if (have_a) dst_a[y] = pixel_for(p, l, l, thr, lut);
-            if (have_b) dst_b[y] = pixel_for(p, r, r, thr, lut);
+            if (have_a) dst_a[y] = pixel_for(p, l, l, pal);
+            if (have_b) dst_b[y] = pixel_for(p, r, r, pal);
         } else {
-            dst_a[y] = pixel_for(p, l, r, thr, lut);
+            dst_a[y] = pixel_for(p, l, r, pal);
         }
     }
 }
