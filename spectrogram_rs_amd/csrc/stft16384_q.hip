@@ -68,6 +68,8 @@ struct Params {
     const float *pcm;        // MONO: [n] floats; else per-pair planes of (l, r): plane p starts at pcm + p * plane_floats
     size_t plane_floats;
     long long sample_base;   // absolute sample index of pcm[0] (the de-interleaved workspace holds a sub-range)
+    uint32_t paired_rows;    // the planes are stored with the two 256-sample halves of every 512-sample block interleaved
+                             // (sample 512 B + 256 h + r at 512 B + 2 r + h): a lane reads (a, a + 1) as ONE 16-byte word
     const float2 *T;         // [2][8][512][2]  pass S, lane tid = 2 col + b (residue c = S + 2 b): [S][q1 / 2][tid][q1 % 2] = w_16384^{col (4 q1 + c)}
     const float2 *tw2;       // [16][16]   w_256^{t0 q2} at [q2][t0]
     const float2 *tw0;       // [4][16]    sign_c / W * w_64^{c a}   (sign_2 = -1: the butterfly leaves -(z0 - z1) in the odd lane)
@@ -134,7 +136,7 @@ __device__ __forceinline__ void st_f4(__amdgpu_buffer_rsrc_t r, int voff, int so
 #endif
 
 
-template <bool MONO>
+template <bool MONO, bool PAIRED>
 __global__ void __launch_bounds__(512, 4) stft16384_q_kernel(Params p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -189,6 +191,12 @@ __global__ void __launch_bounds__(512, 4) stft16384_q_kernel(Params p)
             if (MONO) {
                 pl[a] = ld_f1(rs, n0_4, 1024 * a);
                 pr[a] = ld_f1(rs, n0_4, 1024 * a + sec);
+            } else if (PAIRED) {
+                if ((a & 1) == 0) {   // rows a and a + 1 of this lane sit side by side: col + 256 (a + h) -> 512 (a / 2) + 2 col + h
+                    const u32x4 v = ld_u4(rs, 16 * (t >> 1) + 32768 * (t & 1), 2048 * a);
+                    pl[a] = __uint_as_float(v.x); pr[a] = __uint_as_float(v.y);
+                    pl[a + 1] = __uint_as_float(v.z); pr[a + 1] = __uint_as_float(v.w);
+                }
             } else {
                 const float2 v = ld_f2(rs, n0_8, 2048 * a);
                 pl[a] = v.x; pr[a] = v.y;
@@ -470,13 +478,16 @@ __global__ void __launch_bounds__(512, 4) stft16384_q_kernel(Params p)
 }
 
 // [n][C] interleaved -> per-pair planes of (l, r): plane p holds samples [first, first + n) of channels (2p, 2p + 1)
+// paired: sample i = 512 B + 256 h + r of the range goes to position 512 B + 2 r + h (the transform kernel then reads the two
+// rows a, a + 1 of a lane as one 16-byte word); needs `first` and the hop to be multiples of 512
 __global__ void __launch_bounds__(256) deinterleave_pairs_kernel(const float *pcm, float *planes, size_t plane_floats,
-                                                                 size_t first, size_t n, uint32_t C, uint32_t pairs)
+                                                                 size_t first, size_t n, uint32_t C, uint32_t pairs, uint32_t paired)
 {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const float2 *row = reinterpret_cast<const float2 *>(pcm + (first + i) * C);
+        const size_t pos = paired ? (i & ~(size_t)511) + 2 * (i & 255) + ((i >> 8) & 1) : i;
         for (uint32_t pr = 0; pr < pairs; ++pr)
-            reinterpret_cast<float2 *>(planes + (size_t)pr * plane_floats)[i] = row[pr];
+            reinterpret_cast<float2 *>(planes + (size_t)pr * plane_floats)[pos] = row[pr];
     }
 }
 
@@ -543,9 +554,11 @@ hipError_t q16384_init(sgx_ctx *c, void **out)
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&t->d_win4), win4.size() * sizeof(float));
     if (e == hipSuccess) e = hipMemcpy(t->d_win4, win4.data(), win4.size() * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(stft16384_q_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(stft16384_q_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
     if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(stft16384_q_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(stft16384_q_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(stft16384_q_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
     if (e != hipSuccess) {
         q16384_destroy(t);
         return e;
@@ -594,7 +607,8 @@ hipError_t launch_stft_q16384(const sgx_ctx *c, void *tables, const float *d_pcm
         // per-pair planes of the sample range these frames read: [first_frame H, (first_frame + n - 1) H + W)
         const size_t first_sample = first_frame * (size_t)c->H;
         const size_t n_samp = (n_frames - 1) * (size_t)c->H + kW;
-        const size_t plane = (2 * n_samp + 63) & ~(size_t)63;  // floats per plane, 256-byte multiples
+        const uint32_t paired = (c->H % 512 == 0) ? 1u : 0u;     // (first_sample = first_frame H is then a multiple of 512 too)
+        const size_t plane = (2 * ((n_samp + 511) & ~(size_t)511) + 63) & ~(size_t)63;  // floats per plane: whole 512-sample blocks
         if (plane * pairs > t->planes_floats) {
             hipError_t e = hipStreamSynchronize(c->stream);  // a previous launch may still read the old planes
             if (e != hipSuccess) return e;
@@ -605,12 +619,13 @@ hipError_t launch_stft_q16384(const sgx_ctx *c, void *tables, const float *d_pcm
         }
         const unsigned blocks = (unsigned)std::min<size_t>((n_samp + 255) / 256, (size_t)n_cu * 16);
         hipLaunchKernelGGL(deinterleave_pairs_kernel, dim3(blocks), dim3(256), 0, c->stream, d_pcm, t->d_planes, plane, first_sample,
-                           n_samp, channels, pairs);
+                           n_samp, channels, pairs, paired);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
         p.pcm = t->d_planes;
         p.plane_floats = plane;
         p.sample_base = (long long)first_sample;
+        p.paired_rows = paired;
     } else {
         p.pcm = d_pcm;
         p.plane_floats = 0;
@@ -629,8 +644,9 @@ hipError_t launch_stft_q16384(const sgx_ctx *c, void *tables, const float *d_pcm
     }
     p.stage = t->d_stage;
     const dim3 grid((unsigned)blocks), block(512);
-    if (mono) hipLaunchKernelGGL((stft16384_q_kernel<true>), grid, block, kLdsBytes, c->stream, p);
-    else hipLaunchKernelGGL((stft16384_q_kernel<false>), grid, block, kLdsBytes, c->stream, p);
+    if (mono) hipLaunchKernelGGL((stft16384_q_kernel<true, false>), grid, block, kLdsBytes, c->stream, p);
+    else if (p.paired_rows) hipLaunchKernelGGL((stft16384_q_kernel<false, true>), grid, block, kLdsBytes, c->stream, p);
+    else hipLaunchKernelGGL((stft16384_q_kernel<false, false>), grid, block, kLdsBytes, c->stream, p);
     return hipGetLastError();
 }
 

@@ -78,9 +78,10 @@ def test_golden_frames_through_the_abi(torch_cuda, gold, mags_err):
             assert mags_err(got[0, 0], exp) <= 1.0
 
 
-@pytest.mark.parametrize("Wt,Ht,ch", [(8192, 512, 8), (1024, 93, 2), (64, 16, 1), (4, 1, 2), (2048, 58, 2)])
+@pytest.mark.parametrize("Wt,Ht,ch", [(8192, 512, 8), (8192, 300, 4), (8192, 1024, 6), (1024, 93, 2), (64, 16, 1), (4, 1, 2), (2048, 58, 2)])
 def test_other_sizes_and_channel_pairs(torch_cuda, mags_err, Wt, Ht, ch):
-    # config 4 (16384-point, 8 interleaved channels = 4 pairs) and assorted power-of-two windows
+    # config 4 (16384-point, 8 interleaved channels = 4 pairs; hops that are / are not multiples of 512: the de-interleaved
+    # planes are stored row-paired for 16-byte sample reads only for the former) and assorted power-of-two windows
     torch = torch_cuda
     eng = engine(window_samples=Wt, hop_samples=Ht, channels=ch)
     n = Wt + Ht * 9 + 3
