@@ -129,10 +129,10 @@ int ensure_workspace(sgx_ctx *c, size_t frames)
 hipError_t run_stft(const sgx_ctx *c, const float *d_pcm, uint32_t channels, uint32_t pairs, size_t first, size_t n,
                     size_t total, float *d_mags)
 {
-    // W = 8192: the four-residue kernel for (l, r) streams; mono frame pairs are (measured) 14 % faster on the first design
-    if (c->stft_kernel == 5 && channels != 1)
+    // W = 8192: the four-residue kernel, (l, r) streams and mono frame pairs alike (independent mono frames: generic)
+    if (c->stft_kernel == 5 && (channels != 1 || !(c->cfg.flags & SGX_FLAG_INDEPENDENT_FRAMES)))
         return sgx::launch_stft_q16384(c, c->d_q16k, d_pcm, channels, pairs, first, n, total, d_mags);
-    if ((c->stft_kernel == 7 || c->stft_kernel == 5) && (channels != 1 || !(c->cfg.flags & SGX_FLAG_INDEPENDENT_FRAMES)))
+    if (c->stft_kernel == 7 && (channels != 1 || !(c->cfg.flags & SGX_FLAG_INDEPENDENT_FRAMES)))
         return sgx::launch_stft_wg16384(c, c->d_fast_16k, d_pcm, channels, pairs, first, n, total, d_mags);
     if (c->stft_kernel == 6) return sgx::launch_stft_mixed(c, c->d_mix, d_pcm, channels, pairs, first, n, total, d_mags);
     if (c->stft_kernel == 4) return sgx::launch_stft_bluestein(c, c->d_blu, d_pcm, channels, pairs, first, n, total, d_mags);
@@ -268,7 +268,6 @@ int sgx_create(const sgx_config *cfg, sgx_ctx **out_ctx)
         c->stft_kernel = 7;
     } else if (!(cfg->flags & SGX_FLAG_FORCE_GENERIC) && sgx::q16384_supported(c)) {
         e = sgx::q16384_init(c, &c->d_q16k);
-        if (e == hipSuccess) e = sgx::wg16384_init(c, &c->d_fast_16k);  // serves mono frame pairs and sgx_process_one's mono contexts
         if (e != hipSuccess) return bail(SGX_ERR_HIP, std::string("sgx_create: 16384-point kernel tables: ") + hipGetErrorString(e));
         c->stft_kernel = 5;
     }
