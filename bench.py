@@ -285,6 +285,10 @@ def main_rank(args):
     def frac_of(ms):
         return F * ALGO_BYTES_STFT / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
 
+    # the fraction of a MEASURED streaming rate next to the fraction of the vendor peak -- the same 16 GB
+    # output buffer filled (write only) and copied half to half (read + write) by the runtime's own kernels, hot device
+    probe = device_streaming_rates(torch, mags) if rank == 0 else None
+
     def build_line(extra):
         total_frames = world * F * args.steps
         value = total_frames / elapsed
@@ -321,6 +325,8 @@ def main_rank(args):
                 "launch_ms": kernel_ms, "bytes_per_frame": ALGO_BYTES_STFT, "frames_per_launch": F,
                 "launch_ms_burst": stats_ms(burst), "launch_ms_sustained": stats_ms(steady),
                 "sustain_s": sustain_wall, "sclk_mhz_after_run": sclk,
+                "measured_device": None if probe is None else dict(
+                    probe, frac_of_fill=achieved / probe["fill_GBps"], frac_of_copy=achieved / probe["copy_GBps"]),
                 "note": "frac / launch_ms: the K timed steps (device hot); *_burst: the first K steps after warm-up; "
                         "*_sustained: launches of the last two thirds of the sustain window; max over ranks",
             },
@@ -368,6 +374,22 @@ def main_rank(args):
     if world > 1:
         dist.destroy_process_group()
     return 0
+
+
+def device_streaming_rates(torch, buf):
+    flat = buf.view(-1)
+    half = flat.numel() // 2
+    a, b = flat[:half], flat[half:2 * half]
+    keep = flat[:4096 * 2047 * 2].clone()   # the frames the checksum is taken over
+    fill = event_times(torch, lambda: flat.zero_(), 5)
+    copy = event_times(torch, lambda: a.copy_(b), 5)
+    flat[:keep.numel()].copy_(keep)
+    torch.cuda.synchronize()
+    nbytes = flat.numel() * 4
+    med = lambda v: sorted(v)[len(v) // 2]
+    return {"fill_GBps": nbytes / (med(fill) * 1e-3) / 1e9, "copy_GBps": 2 * half * 4 / (med(copy) * 1e-3) / 1e9,
+            "how": f"torch zero_() over the {nbytes / 1e9:.1f} GB output buffer (bytes written) and copy_() of one half onto the other "
+                   "(bytes read + written), median of 5, HIP events, after the timed steps"}
 
 
 def event_times(torch, fn, reps, warm=1):
