@@ -481,13 +481,37 @@ __global__ void __launch_bounds__(512, 4) stft16384_q_kernel(Params p)
 // paired: sample i = 512 B + 256 h + r of the range goes to position 512 B + 2 r + h (the transform kernel then reads the two
 // rows a, a + 1 of a lane as one 16-byte word); needs `first` and the hop to be multiples of 512
 __global__ void __launch_bounds__(256) deinterleave_pairs_kernel(const float *pcm, float *planes, size_t plane_floats,
-                                                                 size_t first, size_t n, uint32_t C, uint32_t pairs, uint32_t paired)
+                                                                 size_t first, size_t n, uint32_t C, uint32_t pairs)
 {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const float2 *row = reinterpret_cast<const float2 *>(pcm + (first + i) * C);
-        const size_t pos = paired ? (i & ~(size_t)511) + 2 * (i & 255) + ((i >> 8) & 1) : i;
         for (uint32_t pr = 0; pr < pairs; ++pr)
-            reinterpret_cast<float2 *>(planes + (size_t)pr * plane_floats)[pos] = row[pr];
+            reinterpret_cast<float2 *>(planes + (size_t)pr * plane_floats)[i] = row[pr];
+    }
+}
+
+// row-paired planes (hop a multiple of 512): sample 512 B + 256 h + r of a plane is stored at 512 B + 2 r + h, so the
+// transform kernel reads rows r and 256 + r of a block with one 16-byte load.  One thread moves BOTH samples of a
+// 16-byte piece: every store is a whole piece (8-byte stores at a 16-byte stride double the write traffic -- measured
+// here as on the transform kernel's output).  WIDE: the stream is 16-byte aligned and C a multiple of 4.
+template <bool WIDE>
+__global__ void __launch_bounds__(256) deinterleave_paired_kernel(const float *pcm, float *planes, size_t plane_floats,
+                                                                  size_t first, size_t n_half, uint32_t C, uint32_t pairs)
+{
+    for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < n_half; j += (size_t)gridDim.x * blockDim.x) {
+        const float *s0 = pcm + (first + 512 * (j >> 8) + (j & 255)) * C, *s1 = s0 + 256 * (size_t)C;
+        if (WIDE) {
+            for (uint32_t q = 0; q < pairs / 2; ++q) {
+                const float4 a = reinterpret_cast<const float4 *>(s0)[q], b = reinterpret_cast<const float4 *>(s1)[q];
+                reinterpret_cast<float4 *>(planes + (size_t)(2 * q) * plane_floats)[j] = make_float4(a.x, a.y, b.x, b.y);
+                reinterpret_cast<float4 *>(planes + (size_t)(2 * q + 1) * plane_floats)[j] = make_float4(a.z, a.w, b.z, b.w);
+            }
+        } else {
+            for (uint32_t pr = 0; pr < pairs; ++pr) {
+                const float2 a = reinterpret_cast<const float2 *>(s0)[pr], b = reinterpret_cast<const float2 *>(s1)[pr];
+                reinterpret_cast<float4 *>(planes + (size_t)pr * plane_floats)[j] = make_float4(a.x, a.y, b.x, b.y);
+            }
+        }
     }
 }
 
@@ -617,9 +641,20 @@ hipError_t launch_stft_q16384(const sgx_ctx *c, void *tables, const float *d_pcm
             if (e != hipSuccess) return e;
             t->planes_floats = plane * pairs;
         }
-        const unsigned blocks = (unsigned)std::min<size_t>((n_samp + 255) / 256, (size_t)n_cu * 16);
-        hipLaunchKernelGGL(deinterleave_pairs_kernel, dim3(blocks), dim3(256), 0, c->stream, d_pcm, t->d_planes, plane, first_sample,
-                           n_samp, channels, pairs, paired);
+        if (paired) {
+            // n_samp = (n - 1) H + 8192 is a whole number of 512-sample blocks here
+            const size_t n_half = n_samp / 2;
+            const unsigned blocks = (unsigned)std::min<size_t>((n_half + 255) / 256, (size_t)n_cu * 16);
+            const bool wide = (channels % 4 == 0) && (reinterpret_cast<uintptr_t>(d_pcm) % 16 == 0);
+            if (wide) hipLaunchKernelGGL(deinterleave_paired_kernel<true>, dim3(blocks), dim3(256), 0, c->stream, d_pcm, t->d_planes, plane,
+                                         first_sample, n_half, channels, pairs);
+            else hipLaunchKernelGGL(deinterleave_paired_kernel<false>, dim3(blocks), dim3(256), 0, c->stream, d_pcm, t->d_planes, plane,
+                                    first_sample, n_half, channels, pairs);
+        } else {
+            const unsigned blocks = (unsigned)std::min<size_t>((n_samp + 255) / 256, (size_t)n_cu * 16);
+            hipLaunchKernelGGL(deinterleave_pairs_kernel, dim3(blocks), dim3(256), 0, c->stream, d_pcm, t->d_planes, plane, first_sample,
+                               n_samp, channels, pairs);
+        }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
         p.pcm = t->d_planes;

@@ -112,6 +112,12 @@ def test_config4_16384_point_kernel(torch_cuda, mags_err, ch, force_generic):
     assert mags_err(got[5, 0], truth) <= 1.0
     for first, cnt in ((1, 4), (6, 3), (21, 1)):   # sub-ranges give the same bytes (mono pairs by global index)
         assert np.array_equal(eng.stft_batch(dev, first_frame=first, max_frames=cnt).cpu().numpy(), got[first:first + cnt])
+    if ch == 8:
+        # a stream that is 8- but not 16-byte aligned takes the narrow de-interleave: same bytes
+        shifted = torch.empty(dev.numel() + 2, dtype=dev.dtype, device=dev.device)
+        shifted[2:] = dev
+        assert shifted[2:].data_ptr() % 16 == 8
+        assert np.array_equal(eng.stft_batch(shifted[2:]).cpu().numpy(), got)
     # the pixel path rides on it through the two-kernel route
     eng.set_builtin_gradient("viridis")
     rg = eng.render_batch(dev).cpu().numpy()
