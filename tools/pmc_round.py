@@ -62,7 +62,7 @@ t2 = traffic("stft4096_wg_kernel<true, 0, false, false>", F, 17400)
 t3 = traffic("stft4096_wg_kernel<true, 0, false, true>", F, 5120)
 hops = 20_000
 t4a = traffic("stft16384_q_kernel<false", hops, 278496)   # <MONO = false, PAIRED = either>
-t4b = traffic("deinterleave_pairs_kernel", hops, 278496)
+t4b = traffic("deinterleave_pa", hops, 278496)   # deinterleave_pairs_kernel or deinterleave_paired_kernel<WIDE>
 out["config2_stft"] = t2
 out["config3_fused_pixel"] = t3
 out["config4_transform"] = t4a
@@ -74,14 +74,18 @@ if t3:
 if t4a:
     out["config4_bytes_per_hop"] = t4a["bytes_per_unit"] + (t4b["bytes_per_unit"] if t4b else 0.0)
     out["config4_traffic_over_algorithmic"] = out["config4_bytes_per_hop"] / 278496
-out["note_config4"] = (
-    "config 4: FETCH_SIZE / WRITE_SIZE count requests between L2 and the fabric, Infinity-Cache hits included. Of the bytes per hop "
-    "position of the transform kernel, 262 KB are algorithmic output, ~35 KB input (each pair plane is read by the two XCDs that share "
-    "its hops), and 2 x 131 KB are the even bins' magnitudes parked in and read back from the workgroups' slots of a 16 MB buffer "
-    "(csrc/stft16384_q.hip, Q_STAGE): L2 is write-through and the output stream turns a 4 MB L2 over between a slot's write and its "
-    "read, so both directions reach the fabric -- the buffer itself lives in the 256 MB Infinity Cache, not in HBM.  The alternative "
-    "without staging (8-byte stores at a 16-byte stride) measured 2.7x algorithmic with the excess going to HBM (write amplification "
-    "2.0x) and ran 13 % slower.")
+if t4a:
+    fetch_kb = 2.0 * t4a["FETCH_SIZE_bytes_raw"] / hops / 1e3
+    write_kb = t4a["WRITE_SIZE_bytes"] / hops / 1e3
+    out["note_config4"] = (
+        "config 4: FETCH_SIZE / WRITE_SIZE count requests between L2 and the fabric, Infinity-Cache hits included. Per hop position the "
+        f"transform kernel writes {write_kb:.0f} KB = 262 KB of algorithmic output + 131 KB of the even bins' magnitudes parked in the "
+        f"workgroups' slots of a 16 MB buffer (csrc/stft16384_q.hip, Q_STAGE), and fetches {fetch_kb:.0f} KB = those 131 KB read back + "
+        f"{fetch_kb - 131:.0f} KB of input (16 KB algorithmic; each pair plane is read through the L2s of the XCDs that share its hops). "
+        "L2 is write-through and the output stream turns a 4 MB L2 over between a slot's write and its read, so both directions of the "
+        "parked data reach the fabric -- the buffer itself lives in the 256 MB Infinity Cache, not in HBM.  The alternative without "
+        "staging (8-byte stores at a 16-byte stride) measured 2.7x algorithmic with the excess going to HBM (write amplification 2.0x) "
+        "and ran 13 % slower.")
 json.dump(out, open(os.path.join(root, "profiles", f"{rnd}_hbm_traffic.json"), "w"), indent=1)
 
 # ---- pipes of the fused pixel kernel -------------------------------------------------------------------------------
