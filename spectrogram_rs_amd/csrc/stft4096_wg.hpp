@@ -94,6 +94,12 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t row_rsrc(char *mags, long long
 }
 
 // one row of [M][2] floats; row_byte = byte offset of the row's (absent) bin 0, bin k lives 8 k bytes on
+// Cache policy of the magnitude stores (A/B on one device, 1e6 frames): an (l, r) stream re-reads 7/8 of every frame's
+// samples through L2, and marking the output non-temporal keeps them there: 6.00 -> 5.57 ms.  A mono stream slides its
+// window in registers and re-reads nothing: there the same bit costs 10-40 %, sc1 30 %.
+#ifndef SGX_OUT_AUX
+#define SGX_OUT_AUX (DUP ? 0 : 2 /* nt */)
+#endif
 template <bool DUP>  // DUP: mono, the row holds (m, m); else (va, vb) = (left, right)
 __device__ __forceinline__ void store_row(char *mags, long long row_byte, int col, const float (&va)[8], const float (&vb)[8])
 {
@@ -103,7 +109,7 @@ __device__ __forceinline__ void store_row(char *mags, long long row_byte, int co
     for (int q3 = 0; q3 < 8; ++q3)
         if ((q3 > 0 || col != 0) && q3 < SGX_ABL_NSTORE) {  // k = 0 (DC) is not part of the output (fft.rs:81)
             const u32x2 d = {__float_as_uint(va[q3]), __float_as_uint(DUP ? va[q3] : vb[q3])};
-            __builtin_amdgcn_raw_buffer_store_b64(d, r, lane_off + 2048 * (q3 & 1), 4096 * (q3 >> 1), 0);
+            __builtin_amdgcn_raw_buffer_store_b64(d, r, lane_off + 2048 * (q3 & 1), 4096 * (q3 >> 1), SGX_OUT_AUX);
         }
 }
 
