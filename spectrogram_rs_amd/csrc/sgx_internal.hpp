@@ -163,3 +163,16 @@ hipError_t launch_checksum(const sgx_ctx *c, const uint32_t *d_words, size_t n_w
                            unsigned long long *d_acc);
 
 }  // namespace sgx
+
+#ifdef __HIPCC__
+// a (left, right) magnitude pair of an output row: written once, never read by the kernel
+__device__ __forceinline__ void st_stream(float2 *p, float a, float b)
+{
+#ifdef SGX_GEN_NT
+    typedef float f2s __attribute__((ext_vector_type(2)));
+    __builtin_nontemporal_store(f2s{a, b}, reinterpret_cast<f2s *>(p));
+#else
+    *p = make_float2(a, b);
+#endif
+}
+#endif

@@ -199,10 +199,10 @@ __global__ void __launch_bounds__(1024) stft_mixed_kernel(Params p)
         const float left = sqrtf(fmaf(sre, sre, sim * sim)) * 0.5f * p.scale;
         const float right = sqrtf(fmaf(dre, dre, dim * dim)) * 0.5f * p.scale;
         if (p.mono_pairs) {
-            if (st_a) out_a[j] = make_float2(left, left);
-            if (st_b) out_b[j] = make_float2(right, right);
+            if (st_a) st_stream(out_a + j, left, left);
+            if (st_b) st_stream(out_b + j, right, right);
         } else {
-            out_a[j] = make_float2(left, right);
+            st_stream(out_a + j, left, right);
         }
     }
 }

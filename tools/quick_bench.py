@@ -50,7 +50,7 @@ def main():
             print(f"render_mags only: median {med:.3f} ms -> {F / med / 1e3:.1f} M columns/s", flush=True)
 
 
-if __name__ == "__main__" and not any(f in sys.argv for f in ("--extra", "--live", "--generic-sizes", "--config4")):
+if __name__ == "__main__" and not any(f in sys.argv for f in ("--extra", "--live", "--generic-sizes", "--config4", "--others")):
     main()
 
 
@@ -105,17 +105,6 @@ def f16(frames=1_000_000):
     print(f"stft f16 ring rows F={frames}: median {med:.3f} ms -> {frames / med / 1e3:.1f} M frames/s, {byts / med / 1e6:.1f} GB/s algorithmic", flush=True)
 
 
-if __name__ == "__main__" and "--config4" in sys.argv:
-    for ch in ((2,) if "--stereo-only" in sys.argv else (8,) if "--ch8-only" in sys.argv else (8, 2, 1)):
-        if "--new-only" in sys.argv:
-            config4(legacy=False, channels=ch)
-            continue
-        a = config4(legacy=True, channels=ch)
-        b = config4(legacy=False, channels=ch)
-        d = (a - b).abs().max().item()
-        print(f"  ch={ch}: max |legacy - new| = {d:.3e} (peak {a.abs().max().item():.3e})", flush=True)
-        del a, b
-
 if __name__ == "__main__" and "--extra" in sys.argv:
     f16()
 
@@ -164,3 +153,17 @@ def generic_sizes(frames=200_000):
 
 if __name__ == "__main__" and "--generic-sizes" in sys.argv:
     generic_sizes()
+
+
+def others(frames=100_000):
+    """the kernels beside the tuned ones: mixed radix (the app's window), chirp-z, generic power of two"""
+    for W, H, ch in ((2400, 93, 2), (2400, 93, 1), (2205, 86, 2), (1102, 100, 2), (1024, 128, 2), (1024, 128, 1), (512, 64, 2)):
+        eng = SpectrogramEngine(48000.0, window_samples=W, hop_samples=H, channels=ch)
+        pcm = eng.white_noise((frames - 1) * eng.H + eng.W)
+        out = torch.empty((frames, 1, eng.M, 2), dtype=torch.float32, device="cuda")
+        med, best = timeit(lambda: eng.stft_batch(pcm, out=out), iters=5)
+        print(f"W={W} H={H} ch={ch} kernel={eng.info.stft_kernel} F={frames}: median {med:.3f} ms best {best:.3f} -> {frames / med / 1e3:.1f} M frames/s", flush=True)
+
+
+if __name__ == "__main__" and "--others" in sys.argv:
+    others()
