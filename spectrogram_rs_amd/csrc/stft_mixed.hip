@@ -7,36 +7,50 @@
 // (stft_bluestein.hip) serves every length with two power-of-two transforms of >= 3W points; for the smooth
 // lengths the application actually produces, this kernel does a quarter of that arithmetic.
 //
-// Decimation in frequency, one stage per factor r of the current block length Ns (m = Ns / r):
-//   y_k = (sum_q x[q m + j] w_r^{q k}) * w_Ns^{j k},  stored at k m + j      (k < r, j < m)
-// after which sub-block k is the length-m problem of the bins = k (mod r).  Bin K ends at pos[K] (mixed-radix
-// digit reversal, a host table); the split reads F[k] and F[P - k] through it.  Twiddles come from the context's
-// full-circle table e^{-2 pi i j / P}: the index j k P / Ns never leaves [0, P).
+// Decimation in frequency, one stage per radix R of the current block length Ns (m = Ns / R):
+//   y_k = (sum_q x[q m + j] w_R^{q k}) * w_Ns^{j k},  stored at k m + j      (k < R, j < m)
+// after which sub-block k is the length-m problem of the bins = k (mod R).  Bin K ends at pos[K] (mixed-radix
+// digit reversal, a host table); the split reads F[k] and F[P - k] through it.
+//
+// Round 2: a stage's radix is a PRODUCT of two prime-ish factors (R = RA RB <= 28: 4800 = 20 x 15 x 16, 4410 =
+// 21 x 21 x 10), its R-point DFT done in registers (RB transforms of RA points, constant twiddles, RA transforms of
+// RB points), so a transform makes three trips through LDS instead of six; the first stage reads the windowed
+// samples straight from the stream (no staging trip for the input), the last (m = 1) has no twiddles; a stage's
+// twiddles w_Ns^{j k}, k = 1 .. R-1, lie side by side in a per-stage table (16-byte reads instead of R-1 gathers
+// from the full circle); the LDS image is padded by one point in 32 (the last stage reads at a lane stride of R
+// points); the split reads both positions of a bin from one packed word.  Measured at W = 2400, hop 93, stereo
+// (SQ counters, profiles/r02_mixed_radix.txt): the first version kept the LDS array busy 62 % of the launch, 58 %
+// of that in bank conflicts, and the address unit 58 %.
+#include <algorithm>
+#include <vector>
+
 #include "sgx_internal.hpp"
 
 namespace sgx {
 
 namespace mix {
 
-constexpr int kMaxStages = 16;
+constexpr int kMaxStages = 8;
+constexpr uint32_t kMaxRadix = 28;
 
 struct MixTables {
-    uint32_t *d_pos = nullptr;  // [P] position of bin k after the stages
-    uint32_t n_stages = 0;
-    uint32_t radix[kMaxStages] = {}, m[kMaxStages] = {}, tws[kMaxStages] = {};
+    uint32_t *d_split = nullptr;  // [M] padded position of bin k | padded position of bin P - k << 16   (k = j + 1)
+    float2 *d_tw = nullptr;       // per stage: [m][R - 1] w_Ns^{j k}
+    uint32_t n_stages = 0, pad_shift = 31, lds_points = 0, threads = 0;
+    uint32_t ra[kMaxStages] = {}, rb[kMaxStages] = {}, m[kMaxStages] = {}, tw_off[kMaxStages] = {};
     float inv_m[kMaxStages] = {};
 };
 
 struct Params {
     const float *pcm;
     const float *window;
-    const float2 *tw;       // [P] e^{-2 pi i j / P}
-    const uint32_t *pos;    // [P]
+    const float2 *tw;
+    const uint32_t *split;
     float *mags;
     unsigned long long first_frame, pair_base, n_frames, total_frames;
-    uint32_t mono_pairs, W, P, H, C, pairs, n_stages;
+    uint32_t mono_pairs, W, P, H, C, pairs, n_stages, pad_shift, vec2;
     float scale;
-    uint32_t radix[kMaxStages], m[kMaxStages], tws[kMaxStages];
+    uint32_t ra[kMaxStages], rb[kMaxStages], m[kMaxStages], tw_off[kMaxStages];
     float inv_m[kMaxStages];
 };
 
@@ -112,77 +126,137 @@ __device__ __forceinline__ void dft7(float2 *x)
     x[4] = add_i(a3, b3);
 }
 
-template <int R>
-__device__ __forceinline__ void stage(float2 *s, const Params &p, int st, uint32_t tid, uint32_t nt)
+template <int N>
+__device__ __forceinline__ void dft_prime(float2 *x)
 {
-    const uint32_t m = p.m[st], tws = p.tws[st], count = p.P / R;
+    if (N == 2) dft2(x);
+    else if (N == 3) dft3(x);
+    else if (N == 4) dft4(x);
+    else if (N == 5) dft5(x);
+    else dft7(x);
+}
+
+#include "mix_consts.inc"
+
+// forward R-point DFT, R = RA * RB, natural order in and out: input q = RB qa + qb, output k = ka + RA kb
+template <int RA, int RB>
+__device__ __forceinline__ void dft_composite(float2 (&x)[RA * RB])
+{
+    if (RB == 1) {
+        dft_prime<RA>(x);
+        return;
+    }
+    constexpr int R = RA * RB;
+    float2 t[RB][RA];
+#pragma unroll
+    for (int qb = 0; qb < RB; ++qb) {
+#pragma unroll
+        for (int qa = 0; qa < RA; ++qa) t[qb][qa] = x[RB * qa + qb];
+        dft_prime<RA>(t[qb]);
+    }
+#pragma unroll
+    for (int ka = 0; ka < RA; ++ka) {
+        float2 c[RB];
+        c[0] = t[0][ka];
+#pragma unroll
+        for (int qb = 1; qb < RB; ++qb) c[qb] = ka == 0 ? t[qb][0] : cmul(t[qb][ka], cw<R>((qb * ka) % R));
+        dft_prime<RB>(c);
+#pragma unroll
+        for (int kb = 0; kb < RB; ++kb) x[ka + RA * kb] = c[kb];
+    }
+}
+
+struct Source {   // where the first stage finds (l + i r) * hann (fft.rs:53-63); zeros from W on (fft.rs:65-69)
+    const float *a, *b;
+    uint32_t cl, cr;
+    bool data_b;
+};
+
+template <int RA, int RB>
+__device__ __forceinline__ void stage(float2 *s, const Params &p, int st, const Source &src, uint32_t tid, uint32_t nt)
+{
+    constexpr int R = RA * RB;
+    const uint32_t m = p.m[st], count = p.P / R, sh = p.pad_shift;
     const float inv_m = p.inv_m[st];
+    const float2 *tw = p.tw + p.tw_off[st];
+    auto at = [&](uint32_t i) -> float2 & { return s[i + (i >> sh)]; };
     for (uint32_t b = tid; b < count; b += nt) {
         const uint32_t blk = (uint32_t)(((float)b + 0.5f) * inv_m);  // b / m: exact for every supported length (tests/test_host_logic.py)
         const uint32_t j = b - blk * m;
-        float2 *base = s + blk * m * R + j;
+        const uint32_t base = blk * m * R + j;
         float2 x[R];
+        if (st == 0) {   // blk = 0: sample n = q m + j
 #pragma unroll
-        for (int q = 0; q < R; ++q) x[q] = base[q * m];
-        if (R == 2) dft2(x);
-        else if (R == 3) dft3(x);
-        else if (R == 4) dft4(x);
-        else if (R == 5) dft5(x);
-        else dft7(x);
-        base[0] = x[0];
+            for (int q = 0; q < R; ++q) {
+                const uint32_t n = q * m + j;
+                float2 v = make_float2(0.0f, 0.0f);
+                if (n < p.W) {
+                    const float w = p.window[n];
+                    if (p.vec2) {
+                        const float2 lr = *reinterpret_cast<const float2 *>(src.a + (size_t)n * p.C + src.cl);
+                        v = make_float2(lr.x * w, lr.y * w);
+                    } else {
+                        const float l = src.a[(size_t)n * p.C + src.cl];
+                        const float r = src.data_b ? src.b[(size_t)n * p.C + src.cr] : 0.0f;
+                        v = make_float2(l * w, r * w);
+                    }
+                }
+                x[q] = v;
+            }
+        } else {
 #pragma unroll
-        for (int k = 1; k < R; ++k) base[k * m] = j == 0 ? x[k] : cmul(x[k], p.tw[j * k * tws]);
+            for (int q = 0; q < R; ++q) x[q] = at(base + q * m);
+        }
+        dft_composite<RA, RB>(x);
+        at(base) = x[0];
+        if (m == 1 || j == 0) {
+#pragma unroll
+            for (int k = 1; k < R; ++k) at(base + k * m) = x[k];
+        } else {
+            const float2 *twj = tw + (size_t)j * (R - 1);
+#pragma unroll
+            for (int k = 1; k < R; ++k) at(base + k * m) = cmul(x[k], twj[k - 1]);
+        }
     }
     __syncthreads();
 }
+
+#define MIX_STAGE_CASES(X) X(7, 4) X(7, 3) X(7, 2) X(5, 5) X(5, 4) X(5, 3) X(5, 2) X(4, 4) X(4, 3) X(4, 2) X(3, 3) X(3, 2) \
+                           X(7, 1) X(5, 1) X(4, 1) X(3, 1) X(2, 1)
 
 __global__ void __launch_bounds__(1024) stft_mixed_kernel(Params p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float2 *s = reinterpret_cast<float2 *>(smem_raw);
-    const uint32_t W = p.W, P = p.P, M = W - 1;
+    const uint32_t W = p.W, M = W - 1;
     const uint32_t tid = threadIdx.x, nt = blockDim.x;
     const uint32_t pair = blockIdx.y;
     // (l, r) of one frame -- or, for a mono stream, frames 2q and 2q+1 by GLOBAL index (see sgx_kernels.hip)
     long long row_a, row_b = -1;
-    const float *src_a, *src_b;
-    uint32_t cl, cr;
-    bool data_b = true;
+    Source src;
+    src.data_b = true;
     if (p.mono_pairs) {
         const unsigned long long fa = 2 * (p.pair_base + blockIdx.x), fb = fa + 1;
         row_a = (long long)fa - (long long)p.first_frame;
         row_b = row_a + 1;
-        data_b = fb < p.total_frames;
-        src_a = p.pcm + (size_t)(fa * p.H);
-        src_b = data_b ? src_a + p.H : src_a;
-        cl = cr = 0;
+        src.data_b = fb < p.total_frames;
+        src.a = p.pcm + (size_t)(fa * p.H);
+        src.b = src.data_b ? src.a + p.H : src.a;
+        src.cl = src.cr = 0;
     } else {
         row_a = (long long)blockIdx.x;
-        src_a = src_b = p.pcm + (size_t)((p.first_frame + blockIdx.x) * p.H) * p.C;
-        cl = p.C == 1 ? 0 : 2 * pair;
-        cr = p.C == 1 ? 0 : 2 * pair + 1;
+        src.a = src.b = p.pcm + (size_t)((p.first_frame + blockIdx.x) * p.H) * p.C;
+        src.cl = p.C == 1 ? 0 : 2 * pair;
+        src.cr = p.C == 1 ? 0 : 2 * pair + 1;
     }
-
-    // (l + i r) * hann (fft.rs:53-63); zeros up to P (fft.rs:65-69)
-    for (uint32_t n = tid; n < P; n += nt) {
-        float2 v = make_float2(0.0f, 0.0f);
-        if (n < W) {
-            const float w = p.window[n];
-            const float l = src_a[(size_t)n * p.C + cl];
-            const float r = data_b ? src_b[(size_t)n * p.C + cr] : 0.0f;
-            v = make_float2(l * w, r * w);
-        }
-        s[n] = v;
-    }
-    __syncthreads();
 
     for (uint32_t st = 0; st < p.n_stages; ++st) {
-        switch (p.radix[st]) {  // uniform
-        case 2: stage<2>(s, p, st, tid, nt); break;
-        case 3: stage<3>(s, p, st, tid, nt); break;
-        case 4: stage<4>(s, p, st, tid, nt); break;
-        case 5: stage<5>(s, p, st, tid, nt); break;
-        default: stage<7>(s, p, st, tid, nt); break;
+        const uint32_t code = p.ra[st] * 8 + p.rb[st];  // uniform
+        switch (code) {
+#define X(A, B) case A * 8 + B: stage<A, B>(s, p, (int)st, src, tid, nt); break;
+            MIX_STAGE_CASES(X)
+#undef X
+        default: break;
         }
     }
 
@@ -192,8 +266,8 @@ __global__ void __launch_bounds__(1024) stft_mixed_kernel(Params p)
     float2 *out_a = reinterpret_cast<float2 *>(p.mags) + ((size_t)(st_a ? row_a : 0) * p.pairs + pair) * M;
     float2 *out_b = reinterpret_cast<float2 *>(p.mags) + ((size_t)(st_b ? row_b : 0) * p.pairs + pair) * M;
     for (uint32_t j = tid; j < M; j += nt) {
-        const uint32_t k = j + 1;
-        const float2 a = s[p.pos[k]], b = s[p.pos[P - k]];
+        const uint32_t w = p.split[j];
+        const float2 a = s[w & 0xffffu], b = s[w >> 16];
         const float sre = a.x + b.x, sim = a.y - b.y;
         const float dre = a.x - b.x, dim = a.y + b.y;
         const float left = sqrtf(fmaf(sre, sre, sim * sim)) * 0.5f * p.scale;
@@ -219,40 +293,132 @@ bool mixed_supported(uint32_t W)
     return n == 1;
 }
 
+namespace mix {
+
+// The stage plan: P's factors 7, 5, 3, 4 (pairs of twos) and a last 2, grouped into stages of one or two factors with
+// a product <= kMaxRadix -- fewest stages, then the smallest largest radix (registers), then the smallest sum.
+// Stages with an odd factor come first (largest first), powers of two last.  tests/test_host_logic.py restates it.
+struct Plan { std::vector<std::pair<uint32_t, uint32_t>> stages; };
+
+static void plan_search(std::vector<uint32_t> &rest, std::vector<std::pair<uint32_t, uint32_t>> &cur,
+                        std::vector<std::pair<uint32_t, uint32_t>> &best, uint64_t &best_key)
+{
+    if (rest.empty()) {
+        uint64_t mx = 0, sum = 0;
+        for (auto &g : cur) { mx = std::max<uint64_t>(mx, g.first * g.second); sum += g.first * g.second; }
+        const uint64_t key = ((uint64_t)cur.size() << 40) | (mx << 20) | sum;
+        if (key < best_key) { best_key = key; best = cur; }
+        return;
+    }
+    const uint32_t f = rest.back();   // the smallest remaining factor goes alone or with any other
+    rest.pop_back();
+    cur.push_back({f, 1});
+    plan_search(rest, cur, best, best_key);
+    cur.pop_back();
+    for (size_t i = 0; i < rest.size(); ++i) {
+        if (i > 0 && rest[i] == rest[i - 1]) continue;
+        const uint32_t g = rest[i];
+        if (f * g > kMaxRadix || (f == 2 && g == 2)) continue;
+        rest.erase(rest.begin() + (long)i);
+        cur.push_back({std::max(f, g), std::min(f, g)});
+        plan_search(rest, cur, best, best_key);
+        cur.pop_back();
+        rest.insert(rest.begin() + (long)i, g);
+    }
+    rest.push_back(f);
+}
+
+static bool make_plan(uint32_t P, Plan &plan)
+{
+    std::vector<uint32_t> factors;   // descending
+    uint32_t n = P;
+    for (uint32_t f : {7u, 5u})
+        while (n % f == 0) { factors.push_back(f); n /= f; }
+    std::vector<uint32_t> threes;
+    while (n % 3 == 0) { threes.push_back(3); n /= 3; }
+    while (n % 4 == 0) { factors.push_back(4); n /= 4; }
+    factors.insert(factors.end(), threes.begin(), threes.end());
+    if (n % 2 == 0) { factors.push_back(2); n /= 2; }
+    if (n != 1) return false;
+    std::sort(factors.begin(), factors.end(), std::greater<uint32_t>());
+    std::vector<std::pair<uint32_t, uint32_t>> cur, best;
+    uint64_t best_key = ~0ull;
+    plan_search(factors, cur, best, best_key);
+    auto odd = [](const std::pair<uint32_t, uint32_t> &g) { return ((g.first * g.second) & (g.first * g.second - 1)) != 0; };
+    std::stable_sort(best.begin(), best.end(), [&](const auto &a, const auto &b) {
+        if (odd(a) != odd(b)) return odd(a);
+        return a.first * a.second > b.first * b.second;
+    });
+    plan.stages = best;
+    return !best.empty() && best.size() <= (size_t)kMaxStages;
+}
+
+}  // namespace mix
+
 hipError_t mixed_init(sgx_ctx *c, void **out)
 {
     using namespace mix;
     auto *t = new MixTables();
-    const uint32_t P = c->P;
-    // stage order: the odd factors first (long strides), then radix 4, then a last radix 2
-    std::vector<uint32_t> radices;
-    uint32_t n = P;
-    for (uint32_t f : {7u, 5u, 3u})
-        while (n % f == 0) { radices.push_back(f); n /= f; }
-    while (n % 4 == 0) { radices.push_back(4); n /= 4; }
-    if (n % 2 == 0) { radices.push_back(2); n /= 2; }
-    if (n != 1 || radices.size() > (size_t)kMaxStages) { delete t; return hipErrorInvalidValue; }
-    t->n_stages = (uint32_t)radices.size();
+    const uint32_t P = c->P, M = c->W - 1;
+    Plan plan;
+    if (!make_plan(P, plan)) { delete t; return hipErrorInvalidValue; }
+    t->n_stages = (uint32_t)plan.stages.size();
+    std::vector<uint32_t> radix(t->n_stages);
+    std::vector<float2> tw;
     uint32_t ns = P;
     for (uint32_t i = 0; i < t->n_stages; ++i) {
-        t->radix[i] = radices[i];
-        t->m[i] = ns / radices[i];
-        t->tws[i] = P / ns;
+        t->ra[i] = plan.stages[i].first;
+        t->rb[i] = plan.stages[i].second;
+        radix[i] = t->ra[i] * t->rb[i];
+        t->m[i] = ns / radix[i];
         t->inv_m[i] = 1.0f / (float)t->m[i];
+        t->tw_off[i] = (uint32_t)tw.size();
+        if (t->m[i] > 1)
+            for (uint32_t j = 0; j < t->m[i]; ++j)
+                for (uint32_t k = 1; k < radix[i]; ++k) {
+                    const unsigned long long e = ((unsigned long long)j * k) % ns;
+                    const double ang = -2.0 * M_PI * (double)e / (double)ns;
+                    double cs = cos(ang), sn = sin(ang);
+                    if (e == 0) { cs = 1.0; sn = 0.0; }
+                    if (4 * e == ns) { cs = 0.0; sn = -1.0; }
+                    if (2 * e == ns) { cs = -1.0; sn = 0.0; }
+                    if (4 * e == 3ull * ns) { cs = 0.0; sn = 1.0; }
+                    tw.push_back(make_float2((float)cs, (float)sn));
+                }
         ns = t->m[i];
     }
+    // one point of padding in 32 wherever it costs no resident workgroup (it cannot at the largest lengths: P = 20480
+    // fills the 160 KB by itself)
+    const size_t kLds = 160 * 1024;
+    const size_t plain = (size_t)P * sizeof(float2), padded = (size_t)(P + (P >> 5)) * sizeof(float2);
+    t->pad_shift = (padded <= kLds && kLds / padded == kLds / plain) ? 5 : 31;
+    t->lds_points = t->pad_shift == 5 ? P + (P >> 5) : P;
+    auto padpos = [&](uint32_t i) { return i + (t->pad_shift == 5 ? (i >> 5) : 0u); };
     // bin K = k1 + r1 (k2 + r2 (k3 + ...)) ends at k1 m1 + k2 m2 + ...
     std::vector<uint32_t> pos(P);
     for (uint32_t K = 0; K < P; ++K) {
         uint32_t k = K, at = 0;
         for (uint32_t i = 0; i < t->n_stages; ++i) {
-            at += (k % t->radix[i]) * t->m[i];
-            k /= t->radix[i];
+            at += (k % radix[i]) * t->m[i];
+            k /= radix[i];
         }
-        pos[K] = at;
+        pos[K] = padpos(at);
     }
-    hipError_t e = hipMalloc(reinterpret_cast<void **>(&t->d_pos), (size_t)P * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMemcpy(t->d_pos, pos.data(), (size_t)P * sizeof(uint32_t), hipMemcpyHostToDevice);
+    std::vector<uint32_t> split(M);
+    for (uint32_t j = 0; j < M; ++j) split[j] = pos[j + 1] | (pos[P - (j + 1)] << 16);   // positions < 21 120 < 2^16
+    // threads: the widest stage's butterflies in one round where the resident workgroups leave room (16 waves per CU
+    // at this kernel's register budget), whole waves
+    const unsigned resident = (unsigned)std::max<size_t>(1, std::min<size_t>(8, kLds / ((size_t)t->lds_points * sizeof(float2))));
+    unsigned widest = 0;
+    for (uint32_t i = 0; i < t->n_stages; ++i) widest = std::max(widest, P / radix[i]);
+    unsigned cap = (1024u / resident) / 64 * 64;
+    cap = std::max(cap, 64u);
+    unsigned threads = std::min(cap, (widest + 63) / 64 * 64);
+    t->threads = std::max(threads, 64u);
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&t->d_split), (size_t)std::max<uint32_t>(M, 1) * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemcpy(t->d_split, split.data(), (size_t)M * sizeof(uint32_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&t->d_tw), std::max<size_t>(tw.size(), 1) * sizeof(float2));
+    if (e == hipSuccess && !tw.empty()) e = hipMemcpy(t->d_tw, tw.data(), tw.size() * sizeof(float2), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         mixed_destroy(t);
         return e;
@@ -265,7 +431,8 @@ void mixed_destroy(void *tables)
 {
     auto *t = static_cast<mix::MixTables *>(tables);
     if (!t) return;
-    if (t->d_pos) (void)hipFree(t->d_pos);
+    if (t->d_split) (void)hipFree(t->d_split);
+    if (t->d_tw) (void)hipFree(t->d_tw);
     delete t;
 }
 
@@ -278,8 +445,8 @@ hipError_t launch_stft_mixed(const sgx_ctx *c, const void *tables, const float *
     Params p{};
     p.pcm = d_pcm;
     p.window = c->d_window;
-    p.tw = c->d_twiddle;
-    p.pos = t->d_pos;
+    p.tw = t->d_tw;
+    p.split = t->d_split;
     p.W = c->W;
     p.P = c->P;
     p.H = c->H;
@@ -287,30 +454,26 @@ hipError_t launch_stft_mixed(const sgx_ctx *c, const void *tables, const float *
     p.pairs = pairs;
     p.scale = 2.0f / (float)c->W;
     p.n_stages = t->n_stages;
+    p.pad_shift = t->pad_shift;
     for (uint32_t i = 0; i < t->n_stages; ++i) {
-        p.radix[i] = t->radix[i];
+        p.ra[i] = t->ra[i];
+        p.rb[i] = t->rb[i];
         p.m[i] = t->m[i];
-        p.tws[i] = t->tws[i];
+        p.tw_off[i] = t->tw_off[i];
         p.inv_m[i] = t->inv_m[i];
     }
     p.first_frame = first_frame;
     p.n_frames = n_frames;
     p.total_frames = total_frames;
-    const size_t lds = (size_t)c->P * sizeof(float2);
+    // (l, r) of a channel pair as one 8-byte word: even channel count and an 8-byte aligned stream
+    p.vec2 = (channels >= 2 && channels % 2 == 0 && reinterpret_cast<uintptr_t>(d_pcm) % 8 == 0) ? 1u : 0u;
+    const size_t lds = (size_t)t->lds_points * sizeof(float2);
     if (lds > 64 * 1024) {  // per launch: the attribute is per device, and a process may hold contexts on several
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(stft_mixed_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)lds);
         if (e != hipSuccess) return e;
     }
-    // about one radix-4 butterfly per thread and stage, and as many resident workgroups as the LDS image allows
-    // (2048 threads per CU): independent workgroups fill each other's barrier waits
-    unsigned threads = ((c->P / 4 + 63) / 64) * 64;
-    const unsigned resident = (unsigned)((160 * 1024) / (lds ? lds : 1));
-    if (resident >= 2) {
-        const unsigned cap = (2048u / (resident > 8 ? 8 : resident)) / 64 * 64;
-        if (threads > cap) threads = cap;
-    }
-    threads = threads > 1024u ? 1024u : (threads < 64u ? 64u : threads);
+    const unsigned threads = t->threads;
     const size_t max_chunk = 1u << 30;
     if (channels == 1 && !(c->cfg.flags & SGX_FLAG_INDEPENDENT_FRAMES)) {
         p.mono_pairs = 1;

@@ -81,32 +81,68 @@ def test_log_axis_matches_oracle_and_roundtrips():
     assert np.array_equal(e, oracle.bin_edges(1024))
 
 
-def test_mixed_radix_block_index_arithmetic_is_exact_for_every_supported_length():
+def mixed_radix_plan(P):
+    """csrc/stft_mixed.hip make_plan restated: P's factors 7, 5, 4 (pairs of twos), 3 and a last 2, grouped into stages of
+    one or two factors with a product <= 28 -- fewest stages, then the smallest largest radix, then the smallest sum."""
+    n, factors = P, []
+    for f in (7, 5):
+        while n % f == 0:
+            factors.append(f)
+            n //= f
+    threes = []
+    while n % 3 == 0:
+        threes.append(3)
+        n //= 3
+    while n % 4 == 0:
+        factors.append(4)
+        n //= 4
+    factors += threes
+    if n % 2 == 0:
+        factors.append(2)
+        n //= 2
+    if n != 1:
+        return None
+    factors.sort(reverse=True)
+    best = [None, None]
+
+    def search(rest, cur):
+        if not rest:
+            prods = [a * b for a, b in cur]
+            key = (len(cur), max(prods), sum(prods))
+            if best[0] is None or key < best[0]:
+                best[0], best[1] = key, list(cur)
+            return
+        f, rest = rest[-1], rest[:-1]
+        search(rest, cur + [(f, 1)])
+        for i, g in enumerate(rest):
+            if (i > 0 and rest[i] == rest[i - 1]) or f * g > 28:
+                continue
+            search(rest[:i] + rest[i + 1:], cur + [(max(f, g), min(f, g))])
+
+    search(factors, [])
+    odd = lambda g: (g[0] * g[1]) & (g[0] * g[1] - 1) != 0  # noqa: E731
+    return sorted(best[1], key=lambda g: (not odd(g), -(g[0] * g[1])))
+
+
+def test_mixed_radix_plan_and_block_index_arithmetic_for_every_supported_length():
+    # the two sizes the application produces (0.05 s at 48 and 44.1 kHz) make three trips through LDS
+    assert [a * b for a, b in mixed_radix_plan(4800)] == [20, 15, 16]
+    assert sorted(a * b for a, b in mixed_radix_plan(4410)) == [14, 15, 21]
     # csrc/stft_mixed.hip splits a butterfly number b into (block, offset) with one float multiply,
     # block = uint((b + 0.5f) * (1.0f / m)), instead of an integer division.  float32 arithmetic is the same on the
-    # host: every stage of every supported length (2W <= 20480 with prime factors 2, 3, 5, 7) is checked here.
-    def stages(P):
-        n, out = P, []
-        for f in (7, 5, 3):
-            while n % f == 0:
-                out.append(f)
-                n //= f
-        while n % 4 == 0:
-            out.append(4)
-            n //= 4
-        if n % 2 == 0:
-            out.append(2)
-            n //= 2
-        return out if n == 1 else None
-
+    # host: every stage of every supported length (2W <= 20480 with prime factors 2, 3, 5, 7) is checked here,
+    # and that the kernel has a stage for every (RA, RB) the plan can ask for.
+    have = {(7, 4), (7, 3), (7, 2), (5, 5), (5, 4), (5, 3), (5, 2), (4, 4), (4, 3), (4, 2), (3, 3), (3, 2), (7, 1), (5, 1), (4, 1), (3, 1), (2, 1)}
     lengths = 0
     for P in range(8, 20481, 2):
-        radices = stages(P)
-        if radices is None:
+        plan = mixed_radix_plan(P)
+        if plan is None:
             continue
         lengths += 1
+        assert len(plan) <= 8 and set(plan) <= have, (P, plan)
         ns = P
-        for r in radices:
+        for ra, rb in plan:
+            r = ra * rb
             m = ns // r
             b = np.arange(P // r, dtype=np.float32)
             got = ((b + np.float32(0.5)) * (np.float32(1.0) / np.float32(m))).astype(np.uint32)
