@@ -125,9 +125,10 @@ def test_config4_16384_point_kernel(torch_cuda, mags_err, ch, force_generic):
     assert np.array_equal(rg.reshape(own.shape), own)
 
 
-@pytest.mark.parametrize("Wt,Ht", [(512, 64), (1024, 333), (4096, 512), (2400, 93), (735, 200), (1102, 100)])
+@pytest.mark.parametrize("Wt,Ht", [(512, 64), (256, 100), (1024, 333), (4096, 512), (2400, 93), (735, 200), (1102, 100)])
 def test_generic_kernel_pairs_mono_frames_by_global_index(torch_cuda, mags_err, Wt, Ht):
-    # sizes served by the generic power-of-two kernel, the mixed-radix kernel (4800 = 2^6 3 5^2, 1470 = 2 3 5 7^2) and the
+    # sizes served by the generic power-of-two kernel (W < 1024), the mixed-radix kernel (4800 = 2^6 3 5^2, 1470 = 2 3 5 7^2,
+    # and the powers of two from W = 1024 on that have no tuned kernel: 2048 = 16 x 16 x 8, 8192 = 16 x 16 x 16 x 2) and the
     # chirp-z kernel (2204 = 4 * 19 * 29): a mono stream rides two frames per transform there too
     # (frames 2q and 2q+1 in the real / imaginary part), any sub-range writes the bytes of the full run, and
     # SGX_FLAG_INDEPENDENT_FRAMES restores the reference's (s, s) dataflow
@@ -136,7 +137,7 @@ def test_generic_kernel_pairs_mono_frames_by_global_index(torch_cuda, mags_err, 
     dev = to_dev(torch, pcm)
     ref = oracle.stream_process(pcm, 1, Wt, Ht, threads=8)
     eng = engine(window_samples=Wt, hop_samples=Ht, channels=1)
-    assert eng.info.stft_kernel == (0 if Wt & (Wt - 1) == 0 else (4 if Wt == 1102 else 6))
+    assert eng.info.stft_kernel == ((0 if Wt < 1024 else 6) if Wt & (Wt - 1) == 0 else (4 if Wt == 1102 else 6))
     tol = 2.0
     got = eng.stft_batch(dev).cpu().numpy()
     assert got.shape == ref.shape == (38, 1, Wt - 1, 2)
