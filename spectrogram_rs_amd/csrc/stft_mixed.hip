@@ -36,8 +36,9 @@ constexpr uint32_t kMaxRadix = 28;
 struct MixTables {
     uint32_t *d_split = nullptr;  // [M] padded position of bin k | padded position of bin P - k << 16   (k = j + 1)
     float2 *d_tw = nullptr;       // per stage: [m][R - 1] w_Ns^{j k}
-    uint32_t n_stages = 0, pad_shift = 31, lds_points = 0, threads = 0;
+    uint32_t n_stages = 0, pad_every = 0, lds_points = 0, threads = 0;
     uint32_t ra[kMaxStages] = {}, rb[kMaxStages] = {}, m[kMaxStages] = {}, tw_off[kMaxStages] = {};
+    uint32_t q_stride[kMaxStages] = {}, blk_stride[kMaxStages] = {};   // padded LDS positions: see stage()
     float inv_m[kMaxStages] = {};
 };
 
@@ -48,9 +49,9 @@ struct Params {
     const uint32_t *split;
     float *mags;
     unsigned long long first_frame, pair_base, n_frames, total_frames;
-    uint32_t mono_pairs, W, P, H, C, pairs, n_stages, pad_shift, vec2;
-    float scale;
-    uint32_t ra[kMaxStages], rb[kMaxStages], m[kMaxStages], tw_off[kMaxStages];
+    uint32_t mono_pairs, W, P, H, C, pairs, n_stages, vec2;
+    float scale, inv_pad;
+    uint32_t ra[kMaxStages], rb[kMaxStages], m[kMaxStages], tw_off[kMaxStages], q_stride[kMaxStages], blk_stride[kMaxStages];
     float inv_m[kMaxStages];
 };
 
@@ -172,48 +173,58 @@ struct Source {   // where the first stage finds (l + i r) * hann (fft.rs:53-63)
     bool data_b;
 };
 
+// LDS positions.  The last stage (m = 1) reads R consecutive points per lane -- a lane stride of R points, 32-way bank
+// conflicts when R is even -- so the image carries one point of padding per D = R_last points: position(i) = i + i / D.
+// Every earlier stage's m is a multiple of R_last, hence of D, which makes the R accesses of a butterfly an arithmetic
+// sequence:
+//   position(blk m R + j + q m) = blk * blk_stride + j + j / D + q * q_stride      (one add per access)
+// with blk_stride = m R (1 + 1 / D) and q_stride = m (1 + 1 / D) from the host (last stage: R + 1 and 1); j / D by one float
+// multiply (inv_pad = 0 when the image is not padded).
 template <int RA, int RB>
 __device__ __forceinline__ void stage(float2 *s, const Params &p, int st, const Source &src, uint32_t tid, uint32_t nt)
 {
     constexpr int R = RA * RB;
-    const uint32_t m = p.m[st], count = p.P / R, sh = p.pad_shift;
+    const uint32_t m = p.m[st], count = p.P / R, qs = p.q_stride[st];
     const float inv_m = p.inv_m[st];
     const float2 *tw = p.tw + p.tw_off[st];
-    auto at = [&](uint32_t i) -> float2 & { return s[i + (i >> sh)]; };
+    const uint32_t q_nz = st == 0 ? (p.W + m - 1) / m : (uint32_t)R;   // first stage: rows q >= q_nz lie wholly in the padding
     for (uint32_t b = tid; b < count; b += nt) {
         const uint32_t blk = (uint32_t)(((float)b + 0.5f) * inv_m);  // b / m: exact for every supported length (tests/test_host_logic.py)
         const uint32_t j = b - blk * m;
-        const uint32_t base = blk * m * R + j;
+        float2 *at = s + (blk * p.blk_stride[st] + j + (uint32_t)(((float)j + 0.5f) * p.inv_pad));
         float2 x[R];
-        if (st == 0) {   // blk = 0: sample n = q m + j; no branches: a row past the window is loaded from sample W - 1 and dropped
+        if (st == 0) {   // blk = 0: sample n = q m + j; a lane past the window loads sample W - 1 and drops it
 #pragma unroll
             for (int q = 0; q < R; ++q) {
-                const uint32_t n = q * m + j, nc = n < p.W ? n : p.W - 1;
-                const float w = p.window[nc];
-                float l, r;
-                if (p.vec2) {   // uniform
-                    const float2 lr = *reinterpret_cast<const float2 *>(src.a + (nc * p.C + src.cl));
-                    l = lr.x;
-                    r = lr.y;
-                } else {
-                    l = src.a[nc * p.C + src.cl];
-                    r = src.data_b ? src.b[nc * p.C + src.cr] : 0.0f;
+                x[q] = make_float2(0.0f, 0.0f);
+                if ((uint32_t)q < q_nz) {   // uniform
+                    const uint32_t n = q * m + j, nc = n < p.W ? n : p.W - 1;
+                    const float w = p.window[nc];
+                    float l, r;
+                    if (p.vec2) {   // uniform
+                        const float2 lr = *reinterpret_cast<const float2 *>(src.a + (nc * p.C + src.cl));
+                        l = lr.x;
+                        r = lr.y;
+                    } else {
+                        l = src.a[nc * p.C + src.cl];
+                        r = src.data_b ? src.b[nc * p.C + src.cr] : 0.0f;
+                    }
+                    if (n < p.W) x[q] = make_float2(l * w, r * w);
                 }
-                x[q] = n < p.W ? make_float2(l * w, r * w) : make_float2(0.0f, 0.0f);
             }
         } else {
 #pragma unroll
-            for (int q = 0; q < R; ++q) x[q] = at(base + q * m);
+            for (int q = 0; q < R; ++q) x[q] = at[q * qs];
         }
         dft_composite<RA, RB>(x);
-        at(base) = x[0];
+        at[0] = x[0];
         if (m == 1 || j == 0) {
 #pragma unroll
-            for (int k = 1; k < R; ++k) at(base + k * m) = x[k];
+            for (int k = 1; k < R; ++k) at[k * qs] = x[k];
         } else {
             const float2 *twj = tw + (size_t)j * (R - 1);
 #pragma unroll
-            for (int k = 1; k < R; ++k) at(base + k * m) = cmul(x[k], twj[k - 1]);
+            for (int k = 1; k < R; ++k) at[k * qs] = cmul(x[k], twj[k - 1]);
         }
     }
     __syncthreads();
@@ -295,7 +306,7 @@ namespace mix {
 
 // The stage plan: P's factors 7, 5, 3, 4 (pairs of twos) and a last 2, grouped into stages of one or two factors with
 // a product <= kMaxRadix -- fewest stages, then the smallest largest radix (registers), then the smallest sum.
-// Stages with an odd factor come first (largest first), powers of two last.  tests/test_host_logic.py restates it.
+// Stages with an odd factor come first (largest first), powers of two last (smallest first).  tests/test_host_logic.py restates it.
 struct Plan { std::vector<std::pair<uint32_t, uint32_t>> stages; };
 
 static void plan_search(std::vector<uint32_t> &rest, std::vector<std::pair<uint32_t, uint32_t>> &cur,
@@ -345,7 +356,8 @@ static bool make_plan(uint32_t P, Plan &plan)
     auto odd = [](const std::pair<uint32_t, uint32_t> &g) { return ((g.first * g.second) & (g.first * g.second - 1)) != 0; };
     std::stable_sort(best.begin(), best.end(), [&](const auto &a, const auto &b) {
         if (odd(a) != odd(b)) return odd(a);
-        return a.first * a.second > b.first * b.second;
+        if (odd(a)) return a.first * a.second > b.first * b.second;
+        return a.first * a.second < b.first * b.second;   // powers of two: the largest last (its padding is the thinnest)
     });
     plan.stages = best;
     return !best.empty() && best.size() <= (size_t)kMaxStages;
@@ -385,13 +397,31 @@ hipError_t mixed_init(sgx_ctx *c, void **out)
                 }
         ns = t->m[i];
     }
-    // one point of padding in 32 wherever it costs no resident workgroup (it cannot at the largest lengths: P = 20480
-    // fills the 160 KB by itself)
+    // one point of padding per R_last points (see stage()) when R_last is even and the padding costs no resident
+    // workgroup (it cannot be afforded at the largest lengths: P = 20480 fills the 160 KB by itself)
     const size_t kLds = 160 * 1024;
-    const size_t plain = (size_t)P * sizeof(float2), padded = (size_t)(P + (P >> 5)) * sizeof(float2);
-    t->pad_shift = (padded <= kLds && kLds / padded == kLds / plain) ? 5 : 31;
-    t->lds_points = t->pad_shift == 5 ? P + (P >> 5) : P;
-    auto padpos = [&](uint32_t i) { return i + (t->pad_shift == 5 ? (i >> 5) : 0u); };
+    const uint32_t r_last = radix[t->n_stages - 1];
+    auto resident_of = [&](uint32_t points) {
+        return (unsigned)std::max<size_t>(1, std::min<size_t>(8, kLds / ((size_t)points * sizeof(float2))));
+    };
+    auto threads_of = [&](uint32_t points) {
+        // the widest stage's butterflies in one round where the resident workgroups leave room (16 waves per CU at this
+        // kernel's register budget), whole waves  (measured at 4800 points: 256 threads 1.72 ms, 192 2.13, 320 2.11)
+        unsigned widest = 0;
+        for (uint32_t i = 0; i < t->n_stages; ++i) widest = std::max(widest, P / radix[i]);
+        unsigned cap = std::max((1024u / resident_of(points)) / 64 * 64, 64u);
+        return std::max(std::min(cap, (widest + 63) / 64 * 64), 64u);
+    };
+    uint32_t best_d = 0;
+    if (r_last % 2 == 0 && (size_t)(P + P / r_last) * sizeof(float2) <= kLds && resident_of(P + P / r_last) == resident_of(P)) best_d = r_last;
+    t->pad_every = best_d;
+    t->lds_points = best_d ? P + P / best_d : P;
+    auto padpos = [&](uint32_t i) { return i + (t->pad_every ? i / t->pad_every : 0u); };
+    for (uint32_t i = 0; i < t->n_stages; ++i) {
+        t->q_stride[i] = t->m[i] == 1 ? 1u : padpos(t->m[i]);          // m > 1 is a multiple of R_last, hence of D
+        t->blk_stride[i] = padpos(t->m[i] * radix[i]);
+    }
+    t->threads = threads_of(t->lds_points);
     // bin K = k1 + r1 (k2 + r2 (k3 + ...)) ends at k1 m1 + k2 m2 + ...
     std::vector<uint32_t> pos(P);
     for (uint32_t K = 0; K < P; ++K) {
@@ -404,15 +434,6 @@ hipError_t mixed_init(sgx_ctx *c, void **out)
     }
     std::vector<uint32_t> split(M);
     for (uint32_t j = 0; j < M; ++j) split[j] = pos[j + 1] | (pos[P - (j + 1)] << 16);   // positions < 21 120 < 2^16
-    // threads: the widest stage's butterflies in one round where the resident workgroups leave room (16 waves per CU
-    // at this kernel's register budget), whole waves
-    const unsigned resident = (unsigned)std::max<size_t>(1, std::min<size_t>(8, kLds / ((size_t)t->lds_points * sizeof(float2))));
-    unsigned widest = 0;
-    for (uint32_t i = 0; i < t->n_stages; ++i) widest = std::max(widest, P / radix[i]);
-    unsigned cap = (1024u / resident) / 64 * 64;   // (measured at 4800 points: 256 threads 1.72 ms, 192 2.13, 320 2.11)
-    cap = std::max(cap, 64u);
-    unsigned threads = std::min(cap, (widest + 63) / 64 * 64);
-    t->threads = std::max(threads, 64u);
     hipError_t e = hipMalloc(reinterpret_cast<void **>(&t->d_split), (size_t)std::max<uint32_t>(M, 1) * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMemcpy(t->d_split, split.data(), (size_t)M * sizeof(uint32_t), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&t->d_tw), std::max<size_t>(tw.size(), 1) * sizeof(float2));
@@ -452,13 +473,15 @@ hipError_t launch_stft_mixed(const sgx_ctx *c, const void *tables, const float *
     p.pairs = pairs;
     p.scale = 2.0f / (float)c->W;
     p.n_stages = t->n_stages;
-    p.pad_shift = t->pad_shift;
+    p.inv_pad = t->pad_every ? 1.0f / (float)t->pad_every : 0.0f;
     for (uint32_t i = 0; i < t->n_stages; ++i) {
         p.ra[i] = t->ra[i];
         p.rb[i] = t->rb[i];
         p.m[i] = t->m[i];
         p.tw_off[i] = t->tw_off[i];
         p.inv_m[i] = t->inv_m[i];
+        p.q_stride[i] = t->q_stride[i];
+        p.blk_stride[i] = t->blk_stride[i];
     }
     p.first_frame = first_frame;
     p.n_frames = n_frames;

@@ -121,13 +121,14 @@ def mixed_radix_plan(P):
 
     search(factors, [])
     odd = lambda g: (g[0] * g[1]) & (g[0] * g[1] - 1) != 0  # noqa: E731
-    return sorted(best[1], key=lambda g: (not odd(g), -(g[0] * g[1])))
+    return sorted(best[1], key=lambda g: (not odd(g), -(g[0] * g[1]) if odd(g) else g[0] * g[1]))
 
 
 def test_mixed_radix_plan_and_block_index_arithmetic_for_every_supported_length():
     # the two sizes the application produces (0.05 s at 48 and 44.1 kHz) make three trips through LDS
     assert [a * b for a, b in mixed_radix_plan(4800)] == [20, 15, 16]
     assert sorted(a * b for a, b in mixed_radix_plan(4410)) == [14, 15, 21]
+    assert [a * b for a, b in mixed_radix_plan(2048)] == [8, 16, 16] and [a * b for a, b in mixed_radix_plan(8192)] == [4, 8, 16, 16]
     # csrc/stft_mixed.hip splits a butterfly number b into (block, offset) with one float multiply,
     # block = uint((b + 0.5f) * (1.0f / m)), instead of an integer division.  float32 arithmetic is the same on the
     # host: every stage of every supported length (2W <= 20480 with prime factors 2, 3, 5, 7) is checked here,
@@ -149,6 +150,11 @@ def test_mixed_radix_plan_and_block_index_arithmetic_for_every_supported_length(
             assert np.array_equal(got, (np.arange(P // r) // m).astype(np.uint32)), (P, r, m)
             ns = m
         assert ns == 1
+        # the padded LDS position adds j / R_last by the same kind of multiply (j < m of the first stage at most)
+        r_last = plan[-1][0] * plan[-1][1]
+        j = np.arange(P // (plan[0][0] * plan[0][1]), dtype=np.float32)
+        got = ((j + np.float32(0.5)) * (np.float32(1.0) / np.float32(r_last))).astype(np.uint32)
+        assert np.array_equal(got, (np.arange(len(j)) // r_last).astype(np.uint32)), (P, r_last)
     assert lengths > 300
 
 
