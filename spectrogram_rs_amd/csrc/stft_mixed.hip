@@ -17,7 +17,7 @@
 // RB points), so a transform makes three trips through LDS instead of six; the first stage reads the windowed
 // samples straight from the stream (no staging trip for the input), the last (m = 1) has no twiddles; a stage's
 // twiddles w_Ns^{j k}, k = 1 .. R-1, lie side by side in a per-stage table (16-byte reads instead of R-1 gathers
-// from the full circle); the LDS image is padded by one point in 32 (the last stage reads at a lane stride of R
+// from the full circle); the LDS image is padded by one point per R_last points (the last stage reads at a lane stride of R
 // points); the split reads both positions of a bin from one packed word.  Measured at W = 2400, hop 93, stereo
 // (SQ counters, profiles/r02_mixed_radix.txt): the first version kept the LDS array busy 62 % of the launch, 58 %
 // of that in bank conflicts, and the address unit 58 %.
