@@ -110,6 +110,14 @@ int upload_palette(sgx_ctx *c)
     SGX_HIP(c, upload(&c->d_lut_thr, c->pal.lut_thr.data(), c->pal.lut_thr.size()));
     SGX_HIP(c, upload(&c->d_alpha_thr, c->pal.alpha_thr.data(), c->pal.alpha_thr.size()));
     SGX_HIP(c, upload(&c->d_t_thr, c->pal.t_thr.data(), c->pal.t_thr.size()));
+    c->pal.t_cell.clear();
+    if (c->pal.segments && c->pal.stereo && c->pal.t_thr.size() < 65535) {
+        // t_cell[c] = switch points in cells below c: a balance in cell c has passed at least t_cell[c] of them and at most t_cell[c + 1]
+        c->pal.t_cell.assign(sgx::kTCells + 1, 0);
+        for (double thr : c->pal.t_thr)
+            for (int cell = sgx::sgx_t_cell(thr) + 1; cell <= sgx::kTCells; ++cell) ++c->pal.t_cell[cell];
+    }
+    SGX_HIP(c, upload(&c->d_t_cell, c->pal.t_cell.data(), c->pal.t_cell.size()));
     ++c->palette_gen;
     return SGX_OK;
 }
@@ -294,7 +302,7 @@ void sgx_destroy(sgx_ctx *c)
     sgx::q16384_destroy(c->d_q16k);
     c->d_q16k = nullptr;
     void *ptrs[] = {c->d_window, c->d_twiddle, c->d_rows, c->d_samples, c->d_lut_thr, c->d_alpha_thr,
-                    c->d_lut_rgba, c->d_t_thr, c->d_band_rows, c->d_band_samples, c->d_levels, c->d_ws_mags, c->d_one_in, c->d_one_out, c->d_cksum};
+                    c->d_lut_rgba, c->d_t_thr, c->d_t_cell, c->d_band_rows, c->d_band_samples, c->d_levels, c->d_ws_mags, c->d_one_in, c->d_one_out, c->d_cksum};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete c;

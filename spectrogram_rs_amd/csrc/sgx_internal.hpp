@@ -11,6 +11,15 @@
 
 namespace sgx {
 
+// The grid over the balance t = l / (|l| + |r|) that shortens the search for its colour segment: a monotone cell number,
+// the same IEEE double operations on the host (table) and on the device (lookup).
+constexpr int kTCells = 512;
+__host__ __device__ inline int sgx_t_cell(double t)
+{
+    const double x = (t + 1.0) * (double)(kTCells / 2);
+    return x >= (double)kTCells ? kTCells - 1 : (x > 0.0 ? (int)x : 0);
+}
+
 // One row of the pixel column (py = 0 is the LOWEST frequency; it is written at image row R-1-py).
 struct RowEntry {
     uint32_t first;  // index of the row's first entry in the sample table
@@ -52,6 +61,7 @@ struct Palette {
     sgx_gradient_fn fn = nullptr;
     void *fn_user = nullptr;
     std::vector<double> t_thr;      // stereo + segments: smallest t (as double) at which segment i+1 starts
+    std::vector<uint16_t> t_cell;   // [kTCells + 1]: t_cell[c] = how many switch points fall in cells below c of the grid over t in [-1, 1] (sgx_t_cell)
     uint8_t nan_rgb[3] = {0, 0, 0}; // colour of t = NaN (l = r = 0 in the diverging branch)
 };
 
@@ -86,6 +96,7 @@ struct sgx_ctx {
     float *d_alpha_thr = nullptr;  // [255]
     uchar4 *d_lut_rgba = nullptr;  // [n]
     double *d_t_thr = nullptr;     // [n-1], segment palettes with a diverging scheme only
+    uint16_t *d_t_cell = nullptr;  // [kTCells + 1] (or null)
     void *d_fast = nullptr;        // tables of the wave-per-transform kernel (opaque here)
     void *d_fast_wg = nullptr;     // tables of the workgroup-per-transform kernel
     void *d_blu = nullptr;         // tables of the Bluestein (non-power-of-two) kernel
@@ -126,6 +137,8 @@ hipError_t launch_stft_wg4096(const sgx_ctx *c, const void *tables, const float 
                               size_t first_frame, size_t n_frames, size_t total_frames, float *d_mags);
 bool wg4096_can_fuse_render(const sgx_ctx *c, const void *tables);
 bool wg4096_seed_is_within_one(const sgx_ctx *c);
+void lut_seed_coefficients(const sgx_ctx *c, float &a, float &b);
+namespace wg { bool seed_within_one(const std::vector<float> &thr, double guess_a, double guess_b); }   // stft4096_wg.hip: is floor(log2(p + 1e-7) a + b) within one of the threshold count for every power?   // LUT level ~ floor(log2(power + 1e-7) a + b): the seed of the threshold count
 hipError_t launch_render_wg4096(const sgx_ctx *c, const void *tables, const float *d_pcm, uint32_t channels, uint32_t pairs,
                                 size_t first_frame, size_t n_frames, size_t total_frames, uint8_t *d_rgba);
 hipError_t launch_stft_wgp4096(const sgx_ctx *c, const void *tables, const float *d_pcm, uint32_t channels, uint32_t pairs,

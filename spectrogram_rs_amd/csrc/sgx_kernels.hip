@@ -184,6 +184,9 @@ struct RenderParams {
     const double *t_thr;        // segment palettes, diverging branch: [n_lut - 1] switch points of the balance t
     uint32_t segments;
     uchar4 nan_rgba;            // colour of t = NaN
+    float guess_a, guess_b;     // seeded threshold counts: level (mono) or alpha byte (diverging) ~ floor(log2(power + 1e-7) a + b - 1/2), then one compare
+    uint32_t alpha_seed;        // the alpha table passes the seed proof with (guess_a, guess_b)
+    const uint16_t *t_cell;     // [kTCells + 1] or null (segment palettes, diverging branch)
 };
 
 // number of thresholds <= v in a sorted table (NaN thresholds sort last and never match)
@@ -199,7 +202,10 @@ __device__ __forceinline__ uint32_t count_reached(const float *thr, uint32_t n, 
 }
 
 // ColorScheme::color_for((l, r)) (colorscheme.rs:55-71) as threshold counts; `thr` / `athr` are the LDS copies
-__device__ __forceinline__ uchar4 color_for(const RenderParams &p, const float *thr, const float *athr, float l, float r)
+// `tthr` / `lut`: the diverging branch's switch points and the colours, wherever the caller keeps them (LDS or global)
+// `tcell` (or null): the grid over t that brackets the segment (sgx_t_cell; table from upload_palette)
+__device__ __forceinline__ uchar4 color_for(const RenderParams &p, const float *thr, const float *athr, const double *tthr, const uchar4 *lut,
+                                            const uint16_t *tcell, float l, float r)
 {
     // colorscheme.rs:59: norm_sqr = l*l + r*r, then the dB ramp as a threshold count
     const float power = (l * l) + (r * r);
@@ -213,23 +219,35 @@ __device__ __forceinline__ uchar4 color_for(const RenderParams &p, const float *
                 px = p.nan_rgba;
             } else {
                 uint32_t lo = 0, hi = p.n_lut - 1;  // number of switch points <= t
+                if (tcell) {   // the cells below t's hold switch points t has passed, the cells above it ones it has not
+                    const int cell = sgx_t_cell(t);
+                    lo = tcell[cell];
+                    hi = tcell[cell + 1];
+                }
                 while (lo < hi) {
                     const uint32_t mid = (lo + hi) >> 1;
-                    if (t >= p.t_thr[mid]) lo = mid + 1;
+                    if (t >= tthr[mid]) lo = mid + 1;
                     else hi = mid;
                 }
-                px = p.lut_rgba[lo];
+                px = lut[lo];
             }
         } else {
             double x = (p.lut_mode == SGX_LUT_ROUND_NM1) ? floor(t * (double)(p.n_lut - 1) + 0.5) : floor(t * (double)p.n_lut);
             uint32_t idx = 0;
             if (x > 0.0) idx = x >= (double)p.n_lut ? p.n_lut - 1 : (uint32_t)x;
-            px = p.lut_rgba[idx];
+            px = lut[idx];
         }
-        px.w = (unsigned char)count_reached(athr, 255, power);  // (alpha * 255.0) as u8, simple_spectrogram.rs:159
+        if (p.alpha_seed) {   // the seed proof holds on the alpha table (launch_render): one read and one compare instead of eight
+            const float ua = fmaf(__builtin_amdgcn_logf(power + 1e-7f), p.guess_a, p.guess_b);
+            int ia = (int)floorf(ua - 0.5f);
+            ia = ia < 0 ? 0 : (ia > 254 ? 254 : ia);
+            px.w = (unsigned char)((uint32_t)ia + (power >= athr[ia] ? 1u : 0u));
+        } else {
+            px.w = (unsigned char)count_reached(athr, 255, power);  // (alpha * 255.0) as u8, simple_spectrogram.rs:159
+        }
     } else {
         // :67-70; alpha = 1.0 -> 255
-        px = (p.segments && power != power) ? p.nan_rgba : p.lut_rgba[count_reached(thr, p.n_lut - 1, power)];
+        px = (p.segments && power != power) ? p.nan_rgba : lut[count_reached(thr, p.n_lut - 1, power)];
         px.w = 255;
     }
     return px;
@@ -289,7 +307,7 @@ __global__ void __launch_bounds__(256) render_kernel(RenderParams p)
         }
         const float l = sl / row.count_f, r = sr / row.count_f;  // :72
 
-        const uchar4 px = color_for(p, thr, athr, l, r);
+        const uchar4 px = color_for(p, thr, athr, p.t_thr, p.lut_rgba, p.t_cell, l, r);
         dst[p.R - 1 - py] = px;  // simple_spectrogram.rs:150
     }
 }
@@ -298,24 +316,58 @@ __global__ void __launch_bounds__(256) render_kernel(RenderParams p)
 // then one thread per row), by persistent workgroups that keep the threshold tables in LDS and request the
 // next column's magnitudes while the current one is rendered.  Used whenever the column, its interpolated
 // samples and the tables fit in LDS; render_kernel above is the general fallback.
+//   KPRE  bins per thread held in registers for the next column (M <= 256 KPRE)
+//   MODE  kGeneric: color_for as written above (thresholds bisected: eight dependent LDS reads per table and pixel,
+//           the diverging branch in double precision)
+//         kMonoSeed: a 256-level palette without the diverging branch whose dB thresholds pass the host's seed proof
+//           (wg::seed_within_one): the level is floor(log2(power + 1e-7) a + b - 1/2) or one above it, one 16-byte LDS
+//           access brings that entry's threshold and both candidate colours, one compare picks (the fused kernel's
+//           pixel_for)
+//         kStereoSeed: the diverging branch (colorscheme.rs:63-66) of a 256-level palette indexed floor(t n): the alpha
+//           byte by the same seed + compare on the alpha thresholds (proof on that table); the level
+//           floor(256 fl64(l / l1)) is the largest k with 256 l >= k l1 -- k / 256 is a double, so rounding the quotient
+//           cannot cross it, and both products are exact in double -- found from a float32 quotient (off by one at
+//           most) and two exact compares: no double-precision division, no floor
+constexpr int kGeneric = 0, kMonoSeed = 1, kStereoSeed = 2;
+template <int KPRE, int MODE>
 __global__ void __launch_bounds__(256) render_two_pass_kernel(RenderParams p, unsigned long long n_columns, uint32_t n_samples)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float2 *m = reinterpret_cast<float2 *>(smem_raw);                 // [M]
     float2 *vbuf = m + p.M + 1;                                       // [n_samples]
-    float *thr = reinterpret_cast<float *>(vbuf + n_samples);         // [n_lut - 1]
+    float *thr = reinterpret_cast<float *>(vbuf + n_samples);         // [n_lut - 1]      (bisection)
     float *athr = thr + p.n_lut;                                      // [255]
+    uint2 *pal = reinterpret_cast<uint2 *>(vbuf + n_samples);         // [256] {threshold to leave level i, RGBA of level i}   (kMonoSeed)
+    float *athr_s = reinterpret_cast<float *>(vbuf + n_samples);      // [256] alpha thresholds, then [256] RGBA words           (kStereoSeed)
+    uint32_t *rgba_s = reinterpret_cast<uint32_t *>(athr_s + 256);
     const uint32_t tid = threadIdx.x;
-    for (uint32_t i = tid; i + 1 < p.n_lut; i += 256) thr[i] = p.lut_thr[i];
-    for (uint32_t i = tid; i < 255; i += 256) athr[i] = p.alpha_thr[i];
+    if (MODE == kMonoSeed) {
+        pal[tid] = make_uint2(__float_as_uint(tid < 255 ? p.lut_thr[tid] : __builtin_nanf("")), *reinterpret_cast<const uint32_t *>(&p.lut_rgba[tid]));
+    } else if (MODE == kStereoSeed) {
+        athr_s[tid] = tid < 255 ? p.alpha_thr[tid] : __builtin_nanf("");
+        rgba_s[tid] = *reinterpret_cast<const uint32_t *>(&p.lut_rgba[tid]) & 0x00ffffffu;
+    } else {
+        for (uint32_t i = tid; i + 1 < p.n_lut; i += 256) thr[i] = p.lut_thr[i];
+        for (uint32_t i = tid; i < 255; i += 256) athr[i] = p.alpha_thr[i];
+    }
+    // kGeneric: the colours and the diverging branch's switch points behind the two float tables (8-byte aligned)
+    uchar4 *lut_s = reinterpret_cast<uchar4 *>(thr + ((p.n_lut + 255 + 1) & ~1u));   // [n_lut]
+    double *tthr_s = reinterpret_cast<double *>(lut_s + ((p.n_lut + 1) & ~1u));      // [n_lut - 1]
+    uint16_t *tcell_s = reinterpret_cast<uint16_t *>(tthr_s + p.n_lut);               // [kTCells + 1]
+    if (MODE == kGeneric) {
+        for (uint32_t i = tid; i < p.n_lut; i += 256) lut_s[i] = p.lut_rgba[i];
+        if (p.stereo && p.segments)
+            for (uint32_t i = tid; i + 1 < p.n_lut; i += 256) tthr_s[i] = p.t_thr[i];
+        if (p.t_cell)
+            for (uint32_t i = tid; i <= (uint32_t)kTCells; i += 256) tcell_s[i] = p.t_cell[i];
+    }
 
-    constexpr int kPre = 8;  // bins per thread held in registers for the next column (M <= 2048 here)
     const int32_t last = (int32_t)p.M - 1;
-    float2 nxt[kPre];
+    float2 nxt[KPRE];
     auto request = [&](unsigned long long col) {
         const float2 *src = reinterpret_cast<const float2 *>(p.mags) + col * p.M;
 #pragma unroll
-        for (int j = 0; j < kPre; ++j) {
+        for (int j = 0; j < KPRE; ++j) {
             const uint32_t i = tid + 256u * j;
             nxt[j] = i < p.M ? src[i] : make_float2(0.0f, 0.0f);
         }
@@ -325,7 +377,7 @@ __global__ void __launch_bounds__(256) render_two_pass_kernel(RenderParams p, un
     for (; col < n_columns; col += gridDim.x) {
         __syncthreads();  // the previous column's row pass is done with m / vbuf
 #pragma unroll
-        for (int j = 0; j < kPre; ++j) {
+        for (int j = 0; j < KPRE; ++j) {
             const uint32_t i = tid + 256u * j;
             if (i < p.M) m[i] = nxt[j];
         }
@@ -377,8 +429,42 @@ __global__ void __launch_bounds__(256) render_two_pass_kernel(RenderParams p, un
                 sl = sl + v.x;
                 sr = sr + v.y;
             }
-            const float l = sl / row.count_f, r = sr / row.count_f;  // :72
-            dst[p.R - 1 - py] = color_for(p, thr, athr, l, r);
+            float l = sl, r = sr;
+            if (row.count > 1) {  // x / 1.0 == x: only rows that average several samples divide (:72)
+                l = sl / row.count_f;
+                r = sr / row.count_f;
+            }
+            if (MODE == kStereoSeed) {
+                const float power = (l * l) + (r * r);   // colorscheme.rs:59
+                const float l1 = fabsf(l) + fabsf(r);    // :65 l1_norm, float32
+                uint32_t idx = 0;                        // t <= 0 or NaN: floor(t n) > 0 fails, level 0
+                if (l > 0.0f && l1 < __builtin_inff()) {
+                    int k = (int)((l / l1) * 256.0f);
+                    k = k < 0 ? 0 : (k > 256 ? 256 : k);
+                    const double L = (double)l * 256.0, D = (double)l1;
+                    if (L < (double)k * D) --k;
+                    else if (L >= (double)(k + 1) * D) ++k;
+                    idx = k > 255 ? 255u : (uint32_t)k;
+                } else if (l > 0.0f) {   // an infinite l1: the reference's own arithmetic
+                    const double x = floor(((double)l / (double)l1) * 256.0);
+                    if (x > 0.0) idx = x >= 256.0 ? 255u : (uint32_t)x;
+                }
+                const float ua = fmaf(__builtin_amdgcn_logf(power + 1e-7f), p.guess_a, p.guess_b);   // host: the alpha table's coefficients
+                int ia = (int)floorf(ua - 0.5f);
+                ia = ia < 0 ? 0 : (ia > 254 ? 254 : ia);
+                const uint32_t alpha = (uint32_t)ia + (power >= athr_s[ia] ? 1u : 0u);   // (alpha * 255.0) as u8, simple_spectrogram.rs:159
+                *reinterpret_cast<uint32_t *>(dst + (p.R - 1 - py)) = rgba_s[idx] | (alpha << 24);
+            } else if (MODE == kMonoSeed) {
+                const float power = (l * l) + (r * r);   // colorscheme.rs:59
+                const float u = fmaf(__builtin_amdgcn_logf(power + 1e-7f), p.guess_a, p.guess_b);
+                int idx = (int)floorf(u - 0.5f);
+                idx = idx < 0 ? 0 : (idx > 254 ? 254 : idx);
+                const uint2 e0 = pal[idx], e1 = pal[idx + 1];
+                const uint32_t rgba = (power >= __uint_as_float(e0.x) ? e1.y : e0.y) | 0xff000000u;   // alpha = 1.0 -> 255
+                *reinterpret_cast<uint32_t *>(dst + (p.R - 1 - py)) = (p.segments && power != power) ? (*reinterpret_cast<const uint32_t *>(&p.nan_rgba) | 0xff000000u) : rgba;
+            } else {
+                dst[p.R - 1 - py] = color_for(p, thr, athr, tthr_s, lut_s, p.t_cell ? tcell_s : nullptr, l, r);
+            }
         }
     }
 }
@@ -401,20 +487,54 @@ hipError_t launch_render(const sgx_ctx *c, const float *d_mags, size_t n_columns
     p.stereo = (uint32_t)c->pal.stereo;
     p.lut_mode = c->cfg.lut_index_mode;
     p.t_thr = c->d_t_thr;
+    p.t_cell = (c->pal.segments && c->pal.stereo && !(c->cfg.flags & SGX_FLAG_LUT_WALK)) ? c->d_t_cell : nullptr;
     p.segments = c->pal.segments ? 1u : 0u;
     p.nan_rgba = make_uchar4(c->pal.nan_rgb[0], c->pal.nan_rgb[1], c->pal.nan_rgb[2], 255);
     const size_t n_samples = c->tab.samples.size();
-    const size_t lds2 = (size_t)(c->M + 1 + n_samples) * sizeof(float2) + (size_t)(c->pal.n + 255) * sizeof(float);
-    if (c->M <= 2048 && lds2 <= 64 * 1024) {
+    int mode = kGeneric;
+    p.guess_a = p.guess_b = 0.0f;
+    p.alpha_seed = 0;
+    if (!c->pal.stereo && c->pal.n == 256 && wg4096_seed_is_within_one(c)) {
+        mode = kMonoSeed;
+        lut_seed_coefficients(c, p.guess_a, p.guess_b);
+    } else if (c->pal.stereo && !(c->cfg.flags & SGX_FLAG_LUT_WALK)) {
+        // alpha byte = (bounded * 255.0) as u8: bounded * 255 = log2(x) a + b with these coefficients; the same proof on its table
+        const double span = (double)c->cfg.max_db - (double)c->cfg.min_db;
+        const double a = 10.0 * log10(2.0) * 255.0 / span, b = -(double)c->cfg.min_db * 255.0 / span;
+        if (wg::seed_within_one(c->pal.alpha_thr, a, b)) {
+            p.alpha_seed = 1;
+            p.guess_a = (float)a;
+            p.guess_b = (float)b;
+            if (!c->pal.segments && c->pal.n == 256 && c->cfg.lut_index_mode == SGX_LUT_FLOOR_N) mode = kStereoSeed;
+        }
+    }
+    const size_t tail = mode != kGeneric ? 256 * sizeof(uint2)
+                                         : (size_t)((c->pal.n + 255 + 1) & ~1u) * sizeof(float) + (size_t)((c->pal.n + 1) & ~1u) * sizeof(uchar4) +
+                                               (size_t)c->pal.n * sizeof(double) + (size_t)(kTCells + 4) * sizeof(uint16_t);
+    const size_t lds2 = (size_t)(c->M + 1 + n_samples) * sizeof(float2) + tail;
+    if (c->M <= 256 * 40 && lds2 <= 160 * 1024) {
         // persistent two-pass form: workgroups sized to the LDS image, each walks columns blockIdx.x, + grid, ...
         int n_cu = 256;
         (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device);
         const size_t per_cu = (160 * 1024) / lds2 < 8 ? (160 * 1024) / lds2 : 8;
         size_t blocks = (size_t)n_cu * (per_cu ? per_cu : 1);
         if (blocks > n_columns) blocks = n_columns;
-        hipLaunchKernelGGL(render_two_pass_kernel, dim3((unsigned)blocks), dim3(256), lds2, c->stream, p,
-                           (unsigned long long)n_columns, (uint32_t)n_samples);
-        return hipGetLastError();
+        auto go = [&](auto kernel) -> hipError_t {
+            if (lds2 > 64 * 1024) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+                if (e != hipSuccess) return e;
+            }
+            hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(256), lds2, c->stream, p, (unsigned long long)n_columns, (uint32_t)n_samples);
+            return hipGetLastError();
+        };
+        const uint32_t need = (c->M + 255) / 256;
+#define SGX_TWO_PASS(K) (mode == kMonoSeed ? go(render_two_pass_kernel<K, kMonoSeed>) : mode == kStereoSeed ? go(render_two_pass_kernel<K, kStereoSeed>) : go(render_two_pass_kernel<K, kGeneric>))
+        if (need <= 8) return SGX_TWO_PASS(8);
+        if (need <= 10) return SGX_TWO_PASS(10);
+        if (need <= 16) return SGX_TWO_PASS(16);
+        if (need <= 32) return SGX_TWO_PASS(32);
+        return SGX_TWO_PASS(40);
+#undef SGX_TWO_PASS
     }
     const size_t lds = (size_t)(c->M + 1) * sizeof(float2) + (size_t)(c->pal.n + 255) * sizeof(float);
     if (lds > 64 * 1024) {  // per launch: the attribute is per device, and a process may hold contexts on several

@@ -453,9 +453,7 @@ bool wg4096_can_fuse_render(const sgx_ctx *c, const void *tables)
     return t && t->fusable && c->pal.n == 256 && !c->pal.stereo && !c->pal.segments;
 }
 
-namespace {
-
-void seed_coefficients(const sgx_ctx *c, float &a, float &b)
+void lut_seed_coefficients(const sgx_ctx *c, float &a, float &b)
 {
     // t * n = (10 log10(x) - min_db) * n / (max_db - min_db) = log2(x) * a + b   (seed only)
     const double span = (double)c->cfg.max_db - (double)c->cfg.min_db;
@@ -464,12 +462,10 @@ void seed_coefficients(const sgx_ctx *c, float &a, float &b)
     b = (float)(-(double)c->cfg.min_db * n / span + (c->cfg.lut_index_mode == SGX_LUT_ROUND_NM1 ? 0.5 : 0.0));
 }
 
-}  // namespace
-
 bool wg4096_seed_is_within_one(const sgx_ctx *c)
 {
     float a, b;
-    seed_coefficients(c, a, b);
+    lut_seed_coefficients(c, a, b);
     return !(c->cfg.flags & SGX_FLAG_LUT_WALK) && wg::seed_within_one(c->pal.lut_thr, (double)a, (double)b);
 }
 
@@ -510,7 +506,7 @@ hipError_t launch_wg(const sgx_ctx *c, const void *tables, const float *d_pcm, u
             p.rgba = d_rgba;
             p.R = c->R;
             p.interp = c->cfg.interp;
-            seed_coefficients(c, p.guess_a, p.guess_b);
+            lut_seed_coefficients(c, p.guess_a, p.guess_b);
             p.seed_pm1 = wg4096_seed_is_within_one(c) ? 1u : 0u;
         }
         // mono normally rides two frames per transform; SGX_FLAG_INDEPENDENT_FRAMES runs it as (s, s) pairs

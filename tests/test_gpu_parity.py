@@ -461,6 +461,43 @@ def test_render_stereo_scheme_bit_exact(torch_cuda, gradients):
     assert got[..., 3].min() == 0 and got[..., 3].max() == 255
 
 
+@pytest.mark.parametrize("scheme", ["lut256", "lut256_round", "brewer", "lut256_walk"])
+def test_diverging_branch_at_its_switch_points(torch_cuda, gradients, scheme):
+    # colorscheme.rs:63-66 on constant columns (the interpolators return a constant spectrum's value exactly): balances
+    # that sit exactly on k / 256 and one float to either side, negative values (cubic overshoot), zeros, infinities
+    # and NaN, levels across every alpha byte.  256-level palettes indexed floor(t n) take the division-free level and
+    # the seeded alpha byte; round(t (n - 1)) and the ColorBrewer splines (segment search through the balance grid)
+    # keep the double-precision quotient; SGX_FLAG_LUT_WALK keeps every search a bisection.
+    torch = torch_cuda
+    rng = np.random.default_rng(5)
+    k = np.arange(1, 256, dtype=np.float32)
+    l_tie, r_tie = k * np.float32(2.0 ** -10), (256 - k) * np.float32(2.0 ** -10)
+    pairs = [np.stack([l_tie, r_tie], 1), np.stack([np.nextafter(l_tie, np.float32(0)), r_tie], 1),
+             np.stack([np.nextafter(l_tie, np.float32(1)), r_tie], 1), np.stack([l_tie * np.float32(1e-3), r_tie * np.float32(1e-3)], 1)]
+    mag = (10 ** rng.uniform(-6, 1, (3000, 2))).astype(np.float32) * rng.choice(np.array([1, 1, 1, -1], np.float32), (3000, 2))
+    special = np.array([[0, 0], [0, 1e-3], [1e-3, 0], [np.inf, 1], [1, np.inf], [np.inf, np.inf], [np.nan, 1], [1, np.nan], [-1e-3, 1e-3],
+                        [1e-3, -1e-3], [1e-20, 1e-20], [3e38, 3e38], [1e-45, 0], [-0.0, 0.0]], np.float32)
+    lr = np.concatenate(pairs + [mag, special]).astype(np.float32)
+    mags = np.repeat(lr[:, None, :], M, 1)
+    kw = dict(window_samples=W, hop_samples=H, channels=2)
+    dev = to_dev(torch, mags)
+    if scheme == "brewer":
+        # the oracle has no callback gradients: the all-bisection build of the same tables (SGX_FLAG_LUT_WALK: no balance
+        # grid, no seeded alpha byte) is the check, and the oracle pins that build on a LUT in the other cases
+        eng = engine(**kw)
+        eng.set_builtin_scheme("spectral", stereo=True)
+        walk = engine(lut_walk=True, **kw)
+        walk.set_builtin_scheme("spectral", stereo=True)
+        ref = walk.render_mags(dev).cpu().numpy()
+    else:
+        mode = oracle.LUT_ROUND_NM1 if scheme == "lut256_round" else oracle.LUT_FLOOR_N
+        eng = engine(lut_index_mode=mode, lut_walk=(scheme == "lut256_walk"), **kw)
+        eng.set_gradient(gradients["plasma"], stereo=True)
+        ref = oracle.render_columns(mags, SR, gradients["plasma"], stereo=True, mode=mode)
+    got = eng.render_mags(dev).cpu().numpy()
+    assert np.array_equal(got, ref)
+
+
 def test_threshold_tables_reproduce_log10_everywhere(torch_cuda, gradients):
     # dense sweep of powers across every LUT boundary: one bin per "column", constant spectrum
     torch = torch_cuda
