@@ -328,9 +328,13 @@ __global__ void __launch_bounds__(256) render_kernel(RenderParams p)
 //           floor(256 fl64(l / l1)) is the largest k with 256 l >= k l1 -- k / 256 is a double, so rounding the quotient
 //           cannot cross it, and both products are exact in double -- found from a float32 quotient (off by one at
 //           most) and two exact compares: no double-precision division, no floor
+//   SPT   > 0: a thread's samples (tid + 256 k, k < SPT) and rows (tid + 256 i, i < 4) are the same for every column: their
+//         table entries are read once and stay in registers (i0 + one weight per sample -- mu^2, mu^3, 1 - o' and the
+//         upper tap are re-derived by the single-rounded operations the host table was built with; first | count << 16
+//         per row), so a column costs no table loads and no dependent load -> gather chain.  0: tables streamed per column.
 constexpr int kGeneric = 0, kMonoSeed = 1, kStereoSeed = 2;
-template <int KPRE, int MODE>
-__global__ void __launch_bounds__(256) render_two_pass_kernel(RenderParams p, unsigned long long n_columns, uint32_t n_samples)
+template <int KPRE, int MODE, int SPT>
+__global__ void __launch_bounds__(256, KPRE <= 16 ? 4 : 2) render_two_pass_kernel(RenderParams p, unsigned long long n_columns, uint32_t n_samples)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float2 *m = reinterpret_cast<float2 *>(smem_raw);                 // [M]
@@ -363,6 +367,23 @@ __global__ void __launch_bounds__(256) render_two_pass_kernel(RenderParams p, un
     }
 
     const int32_t last = (int32_t)p.M - 1;
+    int32_t s_i0[SPT > 0 ? SPT : 1];
+    float s_w[SPT > 0 ? SPT : 1];
+    uint32_t row_w[4] = {0u, 0u, 0u, 0u};
+    if (SPT > 0) {
+#pragma unroll
+        for (int k = 0; k < SPT; ++k) {
+            const uint32_t sidx = tid + 256u * k;
+            const SampleEntry se = p.samples[sidx < n_samples ? sidx : 0];
+            s_i0[k] = se.i0;
+            s_w[k] = p.interp == SGX_INTERP_COSINE ? se.w2 : se.w0;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t py = tid + 256u * i;
+            if (py < p.R) row_w[i] = p.rows[py].first | (p.rows[py].count << 16);
+        }
+    }
     float2 nxt[KPRE];
     auto request = [&](unsigned long long col) {
         const float2 *src = reinterpret_cast<const float2 *>(p.mags) + col * p.M;
@@ -372,67 +393,131 @@ __global__ void __launch_bounds__(256) render_two_pass_kernel(RenderParams p, un
             nxt[j] = i < p.M ? src[i] : make_float2(0.0f, 0.0f);
         }
     };
-    unsigned long long col = blockIdx.x;
-    if (col < n_columns) request(col);
-    for (; col < n_columns; col += gridDim.x) {
-        __syncthreads();  // the previous column's row pass is done with m / vbuf
+    auto fill = [&]() {
 #pragma unroll
         for (int j = 0; j < KPRE; ++j) {
             const uint32_t i = tid + 256u * j;
             if (i < p.M) m[i] = nxt[j];
         }
+    };
+    // Order of the vector-memory stream (vmcnt retires in order: a wait for a load is a wait for every store issued
+    // before it): the magnitudes of column c + 2 are requested BEFORE column c's pixel stores, and they are waited for
+    // only after column c + 1's sample pass -- by then the only stores ahead of them (column c - 1's ... none) have
+    // long landed.  The first form of this loop requested behind the stores and waited at the top: every column paid a
+    // full store round trip.
+    unsigned long long col = blockIdx.x;
+    if (col < n_columns) {
+        request(col);
+        fill();
         if (col + gridDim.x < n_columns) request(col + gridDim.x);
-        __syncthreads();
+    }
+    for (; col < n_columns; col += gridDim.x) {
+        __syncthreads();  // m is filled; the previous column's row pass is done with vbuf
         // ---- sample pass (interpolated_frequency_sample.rs:79-105)
-        uint32_t sidx = tid;
-        SampleEntry se_cur = p.samples[sidx < n_samples ? sidx : 0];
-        while (sidx < n_samples) {
-            // the next step's table entry is requested before this step's gathers (one L1 latency overlapped)
-            const SampleEntry se = se_cur;
-            se_cur = p.samples[sidx + 256 < n_samples ? sidx + 256 : 0];
-            float2 v;
-            if (p.interp == SGX_INTERP_COSINE) {
-                const float2 a = m[se.i0], b = m[se.i1];
-                v.x = a.x * se.w1 + b.x * se.w2;
-                v.y = a.y * se.w1 + b.y * se.w2;
-            } else {
-                const int32_t x1 = se.i0;
-                const int32_t x0 = x1 > 0 ? x1 - 1 : 0;
-                const int32_t x2 = x1 + 1 < last ? x1 + 1 : last;
-                const int32_t x3 = x1 + 2 < last ? x1 + 2 : last;
-                const float2 y0 = m[x0], y1 = m[x1], y2 = m[x2], y3 = m[x3];
-                const float mu = se.w0, mu2 = se.w1, mu3 = se.w2;
-                {
-                    const float a0 = ((y3.x - y2.x) - y0.x) + y1.x;
-                    const float a1 = (y0.x - y1.x) - a0;
-                    const float a2 = y2.x - y0.x;
-                    v.x = ((a0 * mu3) + (a1 * mu2)) + ((a2 * mu) + y1.x);
+        if (SPT > 0) {
+#pragma unroll
+            for (int k = 0; k < SPT; ++k) {
+                const uint32_t sidx = tid + 256u * k;
+                if (sidx >= n_samples) break;
+                // opaque copies: everything derived from a table entry (tap addresses, mu^2, mu^3) is re-derived per column;
+                // left visible, the compiler hoists all of it out of the column loop -- 100 registers and a resident workgroup
+                int32_t x1 = s_i0[k];
+                float wk = s_w[k];
+                asm volatile("" : "+v"(x1), "+v"(wk));
+                float2 v;
+                if (p.interp == SGX_INTERP_COSINE) {
+                    const int32_t hi = x1 + 1 < last ? x1 + 1 : last;   // clamp(ceil(idx), low + 1, M - 1)  (:81)
+                    const float o2 = wk, w1 = 1.0f - o2;
+                    const float2 a = m[x1], b = m[hi];
+                    v.x = a.x * w1 + b.x * o2;
+                    v.y = a.y * w1 + b.y * o2;
+                } else {
+                    const int32_t x0 = x1 > 0 ? x1 - 1 : 0;
+                    const int32_t x2 = x1 + 1 < last ? x1 + 1 : last;
+                    const int32_t x3 = x1 + 2 < last ? x1 + 2 : last;
+                    const float2 y0 = m[x0], y1 = m[x1], y2 = m[x2], y3 = m[x3];
+                    const float mu = wk, mu2 = mu * mu, mu3 = mu * mu2;   // num_traits::pow (:93-94), as the host table
+                    {
+                        const float a0 = ((y3.x - y2.x) - y0.x) + y1.x;
+                        const float a1 = (y0.x - y1.x) - a0;
+                        const float a2 = y2.x - y0.x;
+                        v.x = ((a0 * mu3) + (a1 * mu2)) + ((a2 * mu) + y1.x);
+                    }
+                    {
+                        const float a0 = ((y3.y - y2.y) - y0.y) + y1.y;
+                        const float a1 = (y0.y - y1.y) - a0;
+                        const float a2 = y2.y - y0.y;
+                        v.y = ((a0 * mu3) + (a1 * mu2)) + ((a2 * mu) + y1.y);
+                    }
                 }
-                {
-                    const float a0 = ((y3.y - y2.y) - y0.y) + y1.y;
-                    const float a1 = (y0.y - y1.y) - a0;
-                    const float a2 = y2.y - y0.y;
-                    v.y = ((a0 * mu3) + (a1 * mu2)) + ((a2 * mu) + y1.y);
-                }
+                vbuf[sidx] = v;
             }
-            vbuf[sidx] = v;
-            sidx += 256;
+        } else {
+            uint32_t sidx = tid;
+            SampleEntry se_cur = p.samples[sidx < n_samples ? sidx : 0];
+            while (sidx < n_samples) {
+                // the next step's table entry is requested before this step's gathers (one L1 latency overlapped)
+                const SampleEntry se = se_cur;
+                se_cur = p.samples[sidx + 256 < n_samples ? sidx + 256 : 0];
+                float2 v;
+                if (p.interp == SGX_INTERP_COSINE) {
+                    const float2 a = m[se.i0], b = m[se.i1];
+                    v.x = a.x * se.w1 + b.x * se.w2;
+                    v.y = a.y * se.w1 + b.y * se.w2;
+                } else {
+                    const int32_t x1 = se.i0;
+                    const int32_t x0 = x1 > 0 ? x1 - 1 : 0;
+                    const int32_t x2 = x1 + 1 < last ? x1 + 1 : last;
+                    const int32_t x3 = x1 + 2 < last ? x1 + 2 : last;
+                    const float2 y0 = m[x0], y1 = m[x1], y2 = m[x2], y3 = m[x3];
+                    const float mu = se.w0, mu2 = se.w1, mu3 = se.w2;
+                    {
+                        const float a0 = ((y3.x - y2.x) - y0.x) + y1.x;
+                        const float a1 = (y0.x - y1.x) - a0;
+                        const float a2 = y2.x - y0.x;
+                        v.x = ((a0 * mu3) + (a1 * mu2)) + ((a2 * mu) + y1.x);
+                    }
+                    {
+                        const float a0 = ((y3.y - y2.y) - y0.y) + y1.y;
+                        const float a1 = (y0.y - y1.y) - a0;
+                        const float a2 = y2.y - y0.y;
+                        v.y = ((a0 * mu3) + (a1 * mu2)) + ((a2 * mu) + y1.y);
+                    }
+                }
+                vbuf[sidx] = v;
+                sidx += 256;
+            }
         }
-        __syncthreads();
+        __syncthreads();  // vbuf is complete, m is free
+        if (col + gridDim.x < n_columns) {
+            fill();
+            if (col + 2ull * gridDim.x < n_columns) request(col + 2ull * gridDim.x);
+        }
         // ---- row pass (:60-75 the mean; colorscheme.rs:55-71; simple_spectrogram.rs:150-160)
         uchar4 *dst = reinterpret_cast<uchar4 *>(p.rgba) + col * p.R;
-        for (uint32_t py = tid; py < p.R; py += 256) {
-            const RowEntry row = p.rows[py];
+        int i_row = 0;
+        for (uint32_t py = tid; py < p.R; py += 256, ++i_row) {
+            uint32_t first, count;
+            if (SPT > 0) {
+                const uint32_t w = i_row == 0 ? row_w[0] : i_row == 1 ? row_w[1] : i_row == 2 ? row_w[2] : row_w[3];
+                first = w & 0xffffu;
+                count = w >> 16;
+            } else {
+                const RowEntry row = p.rows[py];
+                first = row.first;
+                count = row.count;
+            }
             float sl = 0.0f, sr = 0.0f;  // Complex::sum starts at zero
-            for (uint32_t i = 0; i < row.count; ++i) {
-                const float2 v = vbuf[row.first + i];
+            for (uint32_t i = 0; i < count; ++i) {
+                const float2 v = vbuf[first + i];
                 sl = sl + v.x;
                 sr = sr + v.y;
             }
             float l = sl, r = sr;
-            if (row.count > 1) {  // x / 1.0 == x: only rows that average several samples divide (:72)
-                l = sl / row.count_f;
-                r = sr / row.count_f;
+            if (count > 1) {  // x / 1.0 == x: only rows that average several samples divide (:72)
+                const float nf = (float)count;   // `n as f32`
+                l = sl / nf;
+                r = sr / nf;
             }
             if (MODE == kStereoSeed) {
                 const float power = (l * l) + (r * r);   // colorscheme.rs:59
@@ -516,24 +601,29 @@ hipError_t launch_render(const sgx_ctx *c, const float *d_mags, size_t n_columns
         // persistent two-pass form: workgroups sized to the LDS image, each walks columns blockIdx.x, + grid, ...
         int n_cu = 256;
         (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device);
-        const size_t per_cu = (160 * 1024) / lds2 < 8 ? (160 * 1024) / lds2 : 8;
-        size_t blocks = (size_t)n_cu * (per_cu ? per_cu : 1);
-        if (blocks > n_columns) blocks = n_columns;
         auto go = [&](auto kernel) -> hipError_t {
             if (lds2 > 64 * 1024) {
                 hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
                 if (e != hipSuccess) return e;
             }
+            // as many persistent workgroups as the device keeps resident (LDS image and registers of THIS instantiation)
+            int per_cu = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, lds2) != hipSuccess || per_cu < 1) per_cu = 1;
+            size_t blocks = (size_t)n_cu * (size_t)(per_cu > 8 ? 8 : per_cu);
+            if (blocks > n_columns) blocks = n_columns;
             hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(256), lds2, c->stream, p, (unsigned long long)n_columns, (uint32_t)n_samples);
             return hipGetLastError();
         };
         const uint32_t need = (c->M + 255) / 256;
-#define SGX_TWO_PASS(K) (mode == kMonoSeed ? go(render_two_pass_kernel<K, kMonoSeed>) : mode == kStereoSeed ? go(render_two_pass_kernel<K, kStereoSeed>) : go(render_two_pass_kernel<K, kGeneric>))
-        if (need <= 8) return SGX_TWO_PASS(8);
-        if (need <= 10) return SGX_TWO_PASS(10);
-        if (need <= 16) return SGX_TWO_PASS(16);
-        if (need <= 32) return SGX_TWO_PASS(32);
-        return SGX_TWO_PASS(40);
+        // table entries in registers: 12 samples and 4 rows per thread at most, 16-bit row fields
+        bool in_regs = n_samples <= 256 * 12 && c->R <= 1024 && n_samples < 65536;
+        for (const RowEntry &r : c->tab.rows) in_regs = in_regs && r.count < 65536 && r.first < 65536;
+#define SGX_TWO_PASS(K, S) (mode == kMonoSeed ? go(render_two_pass_kernel<K, kMonoSeed, S>) : mode == kStereoSeed ? go(render_two_pass_kernel<K, kStereoSeed, S>) : go(render_two_pass_kernel<K, kGeneric, S>))
+        if (need <= 8) return in_regs ? SGX_TWO_PASS(8, 12) : SGX_TWO_PASS(8, 0);
+        if (need <= 10) return in_regs ? SGX_TWO_PASS(10, 12) : SGX_TWO_PASS(10, 0);
+        if (need <= 16) return SGX_TWO_PASS(16, 0);
+        if (need <= 32) return SGX_TWO_PASS(32, 0);
+        return SGX_TWO_PASS(40, 0);
 #undef SGX_TWO_PASS
     }
     const size_t lds = (size_t)(c->M + 1) * sizeof(float2) + (size_t)(c->pal.n + 255) * sizeof(float);
