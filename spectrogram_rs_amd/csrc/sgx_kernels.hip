@@ -316,7 +316,9 @@ __global__ void __launch_bounds__(256) render_kernel(RenderParams p)
 // then one thread per row), by persistent workgroups that keep the threshold tables in LDS and request the
 // next column's magnitudes while the current one is rendered.  Used whenever the column, its interpolated
 // samples and the tables fit in LDS; render_kernel above is the general fallback.
-//   KPRE  bins per thread held in registers for the next column (M <= 256 KPRE)
+//   NT    threads per workgroup: 256 where four workgroups fit a CU's LDS, 512 / 1024 where only two / one do (16 waves per
+//         CU either way: a 130 KB column image with four waves on it ran at a fifth of the rate)
+//   KPRE  bins per thread held in registers for the next column (M <= NT KPRE)
 //   MODE  kGeneric: color_for as written above (thresholds bisected: eight dependent LDS reads per table and pixel,
 //           the diverging branch in double precision)
 //         kMonoSeed: a 256-level palette without the diverging branch whose dB thresholds pass the host's seed proof
@@ -333,8 +335,8 @@ __global__ void __launch_bounds__(256) render_kernel(RenderParams p)
 //         upper tap are re-derived by the single-rounded operations the host table was built with; first | count << 16
 //         per row), so a column costs no table loads and no dependent load -> gather chain.  0: tables streamed per column.
 constexpr int kGeneric = 0, kMonoSeed = 1, kStereoSeed = 2;
-template <int KPRE, int MODE, int SPT>
-__global__ void __launch_bounds__(256, KPRE <= 16 ? 4 : 2) render_two_pass_kernel(RenderParams p, unsigned long long n_columns, uint32_t n_samples)
+template <int KPRE, int MODE, int SPT, int NT>
+__global__ void __launch_bounds__(NT, 4) render_two_pass_kernel(RenderParams p, unsigned long long n_columns, uint32_t n_samples)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float2 *m = reinterpret_cast<float2 *>(smem_raw);                 // [M]
@@ -346,24 +348,26 @@ __global__ void __launch_bounds__(256, KPRE <= 16 ? 4 : 2) render_two_pass_kerne
     uint32_t *rgba_s = reinterpret_cast<uint32_t *>(athr_s + 256);
     const uint32_t tid = threadIdx.x;
     if (MODE == kMonoSeed) {
-        pal[tid] = make_uint2(__float_as_uint(tid < 255 ? p.lut_thr[tid] : __builtin_nanf("")), *reinterpret_cast<const uint32_t *>(&p.lut_rgba[tid]));
+        if (tid < 256) pal[tid] = make_uint2(__float_as_uint(tid < 255 ? p.lut_thr[tid] : __builtin_nanf("")), *reinterpret_cast<const uint32_t *>(&p.lut_rgba[tid]));
     } else if (MODE == kStereoSeed) {
-        athr_s[tid] = tid < 255 ? p.alpha_thr[tid] : __builtin_nanf("");
-        rgba_s[tid] = *reinterpret_cast<const uint32_t *>(&p.lut_rgba[tid]) & 0x00ffffffu;
+        if (tid < 256) {
+            athr_s[tid] = tid < 255 ? p.alpha_thr[tid] : __builtin_nanf("");
+            rgba_s[tid] = *reinterpret_cast<const uint32_t *>(&p.lut_rgba[tid]) & 0x00ffffffu;
+        }
     } else {
-        for (uint32_t i = tid; i + 1 < p.n_lut; i += 256) thr[i] = p.lut_thr[i];
-        for (uint32_t i = tid; i < 255; i += 256) athr[i] = p.alpha_thr[i];
+        for (uint32_t i = tid; i + 1 < p.n_lut; i += NT) thr[i] = p.lut_thr[i];
+        for (uint32_t i = tid; i < 255; i += NT) athr[i] = p.alpha_thr[i];
     }
     // kGeneric: the colours and the diverging branch's switch points behind the two float tables (8-byte aligned)
     uchar4 *lut_s = reinterpret_cast<uchar4 *>(thr + ((p.n_lut + 255 + 1) & ~1u));   // [n_lut]
     double *tthr_s = reinterpret_cast<double *>(lut_s + ((p.n_lut + 1) & ~1u));      // [n_lut - 1]
     uint16_t *tcell_s = reinterpret_cast<uint16_t *>(tthr_s + p.n_lut);               // [kTCells + 1]
     if (MODE == kGeneric) {
-        for (uint32_t i = tid; i < p.n_lut; i += 256) lut_s[i] = p.lut_rgba[i];
+        for (uint32_t i = tid; i < p.n_lut; i += NT) lut_s[i] = p.lut_rgba[i];
         if (p.stereo && p.segments)
-            for (uint32_t i = tid; i + 1 < p.n_lut; i += 256) tthr_s[i] = p.t_thr[i];
+            for (uint32_t i = tid; i + 1 < p.n_lut; i += NT) tthr_s[i] = p.t_thr[i];
         if (p.t_cell)
-            for (uint32_t i = tid; i <= (uint32_t)kTCells; i += 256) tcell_s[i] = p.t_cell[i];
+            for (uint32_t i = tid; i <= (uint32_t)kTCells; i += NT) tcell_s[i] = p.t_cell[i];
     }
 
     const int32_t last = (int32_t)p.M - 1;
@@ -373,14 +377,14 @@ __global__ void __launch_bounds__(256, KPRE <= 16 ? 4 : 2) render_two_pass_kerne
     if (SPT > 0) {
 #pragma unroll
         for (int k = 0; k < SPT; ++k) {
-            const uint32_t sidx = tid + 256u * k;
+            const uint32_t sidx = tid + (uint32_t)NT * k;
             const SampleEntry se = p.samples[sidx < n_samples ? sidx : 0];
             s_i0[k] = se.i0;
             s_w[k] = p.interp == SGX_INTERP_COSINE ? se.w2 : se.w0;
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const uint32_t py = tid + 256u * i;
+            const uint32_t py = tid + (uint32_t)NT * i;
             if (py < p.R) row_w[i] = p.rows[py].first | (p.rows[py].count << 16);
         }
     }
@@ -389,14 +393,14 @@ __global__ void __launch_bounds__(256, KPRE <= 16 ? 4 : 2) render_two_pass_kerne
         const float2 *src = reinterpret_cast<const float2 *>(p.mags) + col * p.M;
 #pragma unroll
         for (int j = 0; j < KPRE; ++j) {
-            const uint32_t i = tid + 256u * j;
+            const uint32_t i = tid + (uint32_t)NT * j;
             nxt[j] = i < p.M ? src[i] : make_float2(0.0f, 0.0f);
         }
     };
     auto fill = [&]() {
 #pragma unroll
         for (int j = 0; j < KPRE; ++j) {
-            const uint32_t i = tid + 256u * j;
+            const uint32_t i = tid + (uint32_t)NT * j;
             if (i < p.M) m[i] = nxt[j];
         }
     };
@@ -417,7 +421,7 @@ __global__ void __launch_bounds__(256, KPRE <= 16 ? 4 : 2) render_two_pass_kerne
         if (SPT > 0) {
 #pragma unroll
             for (int k = 0; k < SPT; ++k) {
-                const uint32_t sidx = tid + 256u * k;
+                const uint32_t sidx = tid + (uint32_t)NT * k;
                 if (sidx >= n_samples) break;
                 // opaque copies: everything derived from a table entry (tap addresses, mu^2, mu^3) is re-derived per column;
                 // left visible, the compiler hoists all of it out of the column loop -- 100 registers and a resident workgroup
@@ -458,7 +462,7 @@ __global__ void __launch_bounds__(256, KPRE <= 16 ? 4 : 2) render_two_pass_kerne
             while (sidx < n_samples) {
                 // the next step's table entry is requested before this step's gathers (one L1 latency overlapped)
                 const SampleEntry se = se_cur;
-                se_cur = p.samples[sidx + 256 < n_samples ? sidx + 256 : 0];
+                se_cur = p.samples[sidx + NT < n_samples ? sidx + NT : 0];
                 float2 v;
                 if (p.interp == SGX_INTERP_COSINE) {
                     const float2 a = m[se.i0], b = m[se.i1];
@@ -485,7 +489,7 @@ __global__ void __launch_bounds__(256, KPRE <= 16 ? 4 : 2) render_two_pass_kerne
                     }
                 }
                 vbuf[sidx] = v;
-                sidx += 256;
+                sidx += NT;
             }
         }
         __syncthreads();  // vbuf is complete, m is free
@@ -496,7 +500,7 @@ __global__ void __launch_bounds__(256, KPRE <= 16 ? 4 : 2) render_two_pass_kerne
         // ---- row pass (:60-75 the mean; colorscheme.rs:55-71; simple_spectrogram.rs:150-160)
         uchar4 *dst = reinterpret_cast<uchar4 *>(p.rgba) + col * p.R;
         int i_row = 0;
-        for (uint32_t py = tid; py < p.R; py += 256, ++i_row) {
+        for (uint32_t py = tid; py < p.R; py += NT, ++i_row) {
             uint32_t first, count;
             if (SPT > 0) {
                 const uint32_t w = i_row == 0 ? row_w[0] : i_row == 1 ? row_w[1] : i_row == 2 ? row_w[2] : row_w[3];
@@ -597,10 +601,13 @@ hipError_t launch_render(const sgx_ctx *c, const float *d_mags, size_t n_columns
                                          : (size_t)((c->pal.n + 255 + 1) & ~1u) * sizeof(float) + (size_t)((c->pal.n + 1) & ~1u) * sizeof(uchar4) +
                                                (size_t)c->pal.n * sizeof(double) + (size_t)(kTCells + 4) * sizeof(uint16_t);
     const size_t lds2 = (size_t)(c->M + 1 + n_samples) * sizeof(float2) + tail;
-    if (c->M <= 256 * 40 && lds2 <= 160 * 1024) {
+    if (c->M <= 1024 * 10 && lds2 <= 160 * 1024) {
         // persistent two-pass form: workgroups sized to the LDS image, each walks columns blockIdx.x, + grid, ...
         int n_cu = 256;
         (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device);
+        const size_t fit = (160 * 1024) / lds2;
+        unsigned nt = fit >= 4 ? 256u : (fit >= 2 ? 512u : 1024u);
+        while (nt < 1024u && (c->M + nt - 1) / nt > 16) nt *= 2;
         auto go = [&](auto kernel) -> hipError_t {
             if (lds2 > 64 * 1024) {
                 hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
@@ -608,22 +615,24 @@ hipError_t launch_render(const sgx_ctx *c, const float *d_mags, size_t n_columns
             }
             // as many persistent workgroups as the device keeps resident (LDS image and registers of THIS instantiation)
             int per_cu = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, lds2) != hipSuccess || per_cu < 1) per_cu = 1;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, (int)nt, lds2) != hipSuccess || per_cu < 1) per_cu = 1;
             size_t blocks = (size_t)n_cu * (size_t)(per_cu > 8 ? 8 : per_cu);
             if (blocks > n_columns) blocks = n_columns;
-            hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(256), lds2, c->stream, p, (unsigned long long)n_columns, (uint32_t)n_samples);
+            hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(nt), lds2, c->stream, p, (unsigned long long)n_columns, (uint32_t)n_samples);
             return hipGetLastError();
         };
-        const uint32_t need = (c->M + 255) / 256;
+        const uint32_t need = (c->M + nt - 1) / nt;
         // table entries in registers: 12 samples and 4 rows per thread at most, 16-bit row fields
-        bool in_regs = n_samples <= 256 * 12 && c->R <= 1024 && n_samples < 65536;
+        bool in_regs = nt == 256 && n_samples <= 256 * 12 && c->R <= 1024 && n_samples < 65536;
         for (const RowEntry &r : c->tab.rows) in_regs = in_regs && r.count < 65536 && r.first < 65536;
-#define SGX_TWO_PASS(K, S) (mode == kMonoSeed ? go(render_two_pass_kernel<K, kMonoSeed, S>) : mode == kStereoSeed ? go(render_two_pass_kernel<K, kStereoSeed, S>) : go(render_two_pass_kernel<K, kGeneric, S>))
-        if (need <= 8) return in_regs ? SGX_TWO_PASS(8, 12) : SGX_TWO_PASS(8, 0);
-        if (need <= 10) return in_regs ? SGX_TWO_PASS(10, 12) : SGX_TWO_PASS(10, 0);
-        if (need <= 16) return SGX_TWO_PASS(16, 0);
-        if (need <= 32) return SGX_TWO_PASS(32, 0);
-        return SGX_TWO_PASS(40, 0);
+#define SGX_TWO_PASS(K, S, T) (mode == kMonoSeed ? go(render_two_pass_kernel<K, kMonoSeed, S, T>) : mode == kStereoSeed ? go(render_two_pass_kernel<K, kStereoSeed, S, T>) : go(render_two_pass_kernel<K, kGeneric, S, T>))
+        if (nt == 256) {
+            if (need <= 8) return in_regs ? SGX_TWO_PASS(8, 12, 256) : SGX_TWO_PASS(8, 0, 256);
+            if (need <= 10) return in_regs ? SGX_TWO_PASS(10, 12, 256) : SGX_TWO_PASS(10, 0, 256);
+            return SGX_TWO_PASS(16, 0, 256);
+        }
+        if (nt == 512) return need <= 8 ? SGX_TWO_PASS(8, 0, 512) : SGX_TWO_PASS(16, 0, 512);
+        return need <= 8 ? SGX_TWO_PASS(8, 0, 1024) : SGX_TWO_PASS(10, 0, 1024);
 #undef SGX_TWO_PASS
     }
     const size_t lds = (size_t)(c->M + 1) * sizeof(float2) + (size_t)(c->pal.n + 255) * sizeof(float);

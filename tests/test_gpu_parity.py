@@ -461,6 +461,24 @@ def test_render_stereo_scheme_bit_exact(torch_cuda, gradients):
     assert got[..., 3].min() == 0 and got[..., 3].max() == 255
 
 
+@pytest.mark.parametrize("Wt,Ht,interp", [(1024, 128, "cubic"), (4096, 512, "cubic"), (4096, 512, "cosine"), (8192, 512, "cosine"), (300, 50, "cubic")])
+def test_pixel_stage_alone_at_other_window_sizes(torch_cuda, gradients, Wt, Ht, interp):
+    # sgx_render_mags picks its workgroup size by how many column images fit a CU's LDS (256 / 512 / 1024 threads at
+    # 1023 / 4095 / 8191 bins) and keeps table entries in registers only in the first case: every shape against the oracle
+    torch = torch_cuda
+    code = {"cubic": oracle.INTERP_CUBIC, "cosine": oracle.INTERP_COSINE}[interp]
+    eng = engine(window_samples=Wt, hop_samples=Ht, channels=2, interp=code)
+    eng.set_gradient(gradients["magma"])
+    pcm = oracle.white_noise(2 * (Wt + 5 * Ht), seed=Wt)
+    mags = eng.stft_batch(to_dev(torch, pcm))
+    got = eng.render_mags(mags[:, 0]).cpu().numpy()
+    ref = oracle.render_columns(mags[:, 0].cpu().numpy(), SR, gradients["magma"], interp=code)
+    assert got.shape == ref.shape == (6, R, 4) and np.array_equal(got, ref)
+    eng.set_gradient(gradients["plasma"], stereo=True)
+    assert np.array_equal(eng.render_mags(mags[:, 0]).cpu().numpy(),
+                          oracle.render_columns(mags[:, 0].cpu().numpy(), SR, gradients["plasma"], interp=code, stereo=True))
+
+
 @pytest.mark.parametrize("scheme", ["lut256", "lut256_round", "brewer", "lut256_walk"])
 def test_diverging_branch_at_its_switch_points(torch_cuda, gradients, scheme):
     # colorscheme.rs:63-66 on constant columns (the interpolators return a constant spectrum's value exactly): balances
