@@ -80,12 +80,13 @@ if t4a:
     out["note_config4"] = (
         "config 4: FETCH_SIZE / WRITE_SIZE count requests between L2 and the fabric, Infinity-Cache hits included. Per hop position the "
         f"transform kernel writes {write_kb:.0f} KB = 262 KB of algorithmic output + 131 KB of the even bins' magnitudes parked in the "
-        f"workgroups' slots of a 16 MB buffer (csrc/stft16384_q.hip, Q_STAGE), and fetches {fetch_kb:.0f} KB = those 131 KB read back + "
-        f"{fetch_kb - 131:.0f} KB of input (16 KB algorithmic; each pair plane is read through the L2s of the XCDs that share its hops). "
-        "L2 is write-through and the output stream turns a 4 MB L2 over between a slot's write and its read, so both directions of the "
-        "parked data reach the fabric -- the buffer itself lives in the 256 MB Infinity Cache, not in HBM.  The alternative without "
-        "staging (8-byte stores at a 16-byte stride) measured 2.7x algorithmic with the excess going to HBM (write amplification 2.0x) "
-        "and ran 13 % slower.")
+        f"workgroups' slots of a 16 MB buffer (csrc/stft16384_q.hip, Q_STAGE; L2 is write-through, so parked bytes reach the fabric once -- "
+        f"the buffer itself lives in the 256 MB Infinity Cache, not in HBM), and fetches {fetch_kb:.0f} KB: the input (16 KB algorithmic, read "
+        "through the L2s of the XCDs that share a plane's hops) plus whatever part of the 131 KB of parked magnitudes L2 no longer holds when "
+        "they are read back.  With plain output stores that was all of it (fetch 199 KB, total 2.13 x algorithmic): the output stream "
+        "turned a 4 MB L2 over between a slot's write and its read.  The output stores now carry the nt bit (no allocation in L2) and "
+        "the read-back mostly hits.  The alternative without staging (8-byte stores at a 16-byte stride) measured 2.7x algorithmic with "
+        "the excess going to HBM (write amplification 2.0x) and ran 13 % slower.")
 json.dump(out, open(os.path.join(root, "profiles", f"{rnd}_hbm_traffic.json"), "w"), indent=1)
 
 # ---- pipes of the fused pixel kernel -------------------------------------------------------------------------------
