@@ -37,6 +37,7 @@ struct MixTables {
     uint32_t *d_split = nullptr;  // [M] padded position of bin k | padded position of bin P - k << 16   (k = j + 1)
     float2 *d_tw = nullptr;       // per stage: [m][R - 1] w_Ns^{j k}
     uint32_t n_stages = 0, pad_every = 0, lds_points = 0, threads = 0;
+    int fixed = 0;                // 4800 / 4410: the host's plan is the compile-time one of stft_mixed_fixed_kernel
     uint32_t ra[kMaxStages] = {}, rb[kMaxStages] = {}, m[kMaxStages] = {}, tw_off[kMaxStages] = {};
     uint32_t q_stride[kMaxStages] = {}, blk_stride[kMaxStages] = {};   // padded LDS positions: see stage()
     float inv_m[kMaxStages] = {};
@@ -180,25 +181,51 @@ struct Source {   // where the first stage finds (l + i r) * hann (fft.rs:53-63)
 //   position(blk m R + j + q m) = blk * blk_stride + j + j / D + q * q_stride      (one add per access)
 // with blk_stride = m R (1 + 1 / D) and q_stride = m (1 + 1 / D) from the host (last stage: R + 1 and 1); j / D by one float
 // multiply (inv_pad = 0 when the image is not padded).
-template <int RA, int RB>
-__device__ __forceinline__ void stage(float2 *s, const Params &p, int st, const Source &src, uint32_t tid, uint32_t nt)
+// A stage's geometry: read from the launch parameters (any supported length), or compile-time constants (the two lengths
+// the application itself produces: every index multiply, LDS offset and "is this row inside the window" test folds
+// away, and rows of the first stage that lie in the zero padding prune the butterfly at compile time).
+struct DynGeo {
+    uint32_t m_, count_, qs_, bs_, W_, nt_;
+    float inv_m_, inv_pad_;
+    bool first_;
+    __device__ __forceinline__ uint32_t m() const { return m_; }
+    __device__ __forceinline__ uint32_t count() const { return count_; }
+    __device__ __forceinline__ uint32_t qs() const { return qs_; }
+    __device__ __forceinline__ uint32_t W() const { return W_; }
+    __device__ __forceinline__ uint32_t nt() const { return nt_; }
+    __device__ __forceinline__ bool first() const { return first_; }
+    __device__ __forceinline__ uint32_t blk_of(uint32_t b) const { return (uint32_t)(((float)b + 0.5f) * inv_m_); }  // b / m: exact for every supported length (tests/test_host_logic.py)
+    __device__ __forceinline__ uint32_t base_of(uint32_t blk, uint32_t j) const { return blk * bs_ + j + (uint32_t)(((float)j + 0.5f) * inv_pad_); }
+};
+template <uint32_t M, uint32_t COUNT, uint32_t QS, uint32_t BS, uint32_t WN, uint32_t PAD, uint32_t NT, bool FIRST>
+struct FixGeo {
+    __device__ __forceinline__ constexpr uint32_t m() const { return M; }
+    __device__ __forceinline__ constexpr uint32_t count() const { return COUNT; }
+    __device__ __forceinline__ constexpr uint32_t qs() const { return QS; }
+    __device__ __forceinline__ constexpr uint32_t W() const { return WN; }
+    __device__ __forceinline__ constexpr uint32_t nt() const { return NT; }
+    __device__ __forceinline__ constexpr bool first() const { return FIRST; }
+    __device__ __forceinline__ uint32_t blk_of(uint32_t b) const { return b / M; }
+    __device__ __forceinline__ uint32_t base_of(uint32_t blk, uint32_t j) const { return blk * BS + j + (PAD ? j / (PAD ? PAD : 1u) : 0u); }
+};
+
+template <int RA, int RB, typename Geo>
+__device__ __forceinline__ void stage(float2 *s, const Params &p, const float2 *tw, const Geo g, const Source &src, uint32_t tid)
 {
     constexpr int R = RA * RB;
-    const uint32_t m = p.m[st], count = p.P / R, qs = p.q_stride[st];
-    const float inv_m = p.inv_m[st];
-    const float2 *tw = p.tw + p.tw_off[st];
-    const uint32_t q_nz = st == 0 ? (p.W + m - 1) / m : (uint32_t)R;   // first stage: rows q >= q_nz lie wholly in the padding
-    for (uint32_t b = tid; b < count; b += nt) {
-        const uint32_t blk = (uint32_t)(((float)b + 0.5f) * inv_m);  // b / m: exact for every supported length (tests/test_host_logic.py)
+    const uint32_t m = g.m(), qs = g.qs();
+    const uint32_t q_nz = g.first() ? (g.W() + m - 1) / m : (uint32_t)R;   // first stage: rows q >= q_nz lie wholly in the padding
+    for (uint32_t b = tid; b < g.count(); b += g.nt()) {
+        const uint32_t blk = g.first() ? 0u : g.blk_of(b);
         const uint32_t j = b - blk * m;
-        float2 *at = s + (blk * p.blk_stride[st] + j + (uint32_t)(((float)j + 0.5f) * p.inv_pad));
+        float2 *at = s + g.base_of(blk, j);
         float2 x[R];
-        if (st == 0) {   // blk = 0: sample n = q m + j; a lane past the window loads sample W - 1 and drops it
+        if (g.first()) {   // blk = 0: sample n = q m + j; a lane past the window loads sample W - 1 and drops it
 #pragma unroll
             for (int q = 0; q < R; ++q) {
                 x[q] = make_float2(0.0f, 0.0f);
                 if ((uint32_t)q < q_nz) {   // uniform
-                    const uint32_t n = q * m + j, nc = n < p.W ? n : p.W - 1;
+                    const uint32_t n = q * m + j, nc = n < g.W() ? n : g.W() - 1;
                     const float w = p.window[nc];
                     float l, r;
                     if (p.vec2) {   // uniform
@@ -209,7 +236,7 @@ __device__ __forceinline__ void stage(float2 *s, const Params &p, int st, const 
                         l = src.a[nc * p.C + src.cl];
                         r = src.data_b ? src.b[nc * p.C + src.cr] : 0.0f;
                     }
-                    if (n < p.W) x[q] = make_float2(l * w, r * w);
+                    if (n < g.W()) x[q] = make_float2(l * w, r * w);
                 }
             }
         } else {
@@ -233,16 +260,10 @@ __device__ __forceinline__ void stage(float2 *s, const Params &p, int st, const 
 #define MIX_STAGE_CASES(X) X(7, 4) X(7, 3) X(7, 2) X(5, 5) X(5, 4) X(5, 3) X(5, 2) X(4, 4) X(4, 3) X(4, 2) X(3, 3) X(3, 2) \
                            X(7, 1) X(5, 1) X(4, 1) X(3, 1) X(2, 1)
 
-__global__ void __launch_bounds__(1024) stft_mixed_kernel(Params p)
+// (l, r) of one frame -- or, for a mono stream, frames 2q and 2q+1 by GLOBAL index (see sgx_kernels.hip)
+__device__ __forceinline__ void frame_source(const Params &p, uint32_t pair, Source &src, long long &row_a, long long &row_b)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    float2 *s = reinterpret_cast<float2 *>(smem_raw);
-    const uint32_t W = p.W, M = W - 1;
-    const uint32_t tid = threadIdx.x, nt = blockDim.x;
-    const uint32_t pair = blockIdx.y;
-    // (l, r) of one frame -- or, for a mono stream, frames 2q and 2q+1 by GLOBAL index (see sgx_kernels.hip)
-    long long row_a, row_b = -1;
-    Source src;
+    row_b = -1;
     src.data_b = true;
     if (p.mono_pairs) {
         const unsigned long long fa = 2 * (p.pair_base + blockIdx.x), fb = fa + 1;
@@ -258,18 +279,12 @@ __global__ void __launch_bounds__(1024) stft_mixed_kernel(Params p)
         src.cl = p.C == 1 ? 0 : 2 * pair;
         src.cr = p.C == 1 ? 0 : 2 * pair + 1;
     }
+}
 
-    for (uint32_t st = 0; st < p.n_stages; ++st) {
-        const uint32_t code = p.ra[st] * 8 + p.rb[st];  // uniform
-        switch (code) {
-#define X(A, B) case A * 8 + B: stage<A, B>(s, p, (int)st, src, tid, nt); break;
-            MIX_STAGE_CASES(X)
-#undef X
-        default: break;
-        }
-    }
-
-    // split + magnitude + scale (fft.rs:81-98); k = 1 .. W-1 kept
+// split + magnitude + scale (fft.rs:81-98); k = 1 .. W-1 kept
+__device__ __forceinline__ void split_store(const Params &p, const float2 *s, uint32_t pair, long long row_a, long long row_b, uint32_t tid, uint32_t nt)
+{
+    const uint32_t M = p.W - 1;
     const bool st_a = row_a >= 0 && (unsigned long long)row_a < p.n_frames;
     const bool st_b = p.mono_pairs && row_b >= 0 && (unsigned long long)row_b < p.n_frames;
     float2 *out_a = reinterpret_cast<float2 *>(p.mags) + ((size_t)(st_a ? row_a : 0) * p.pairs + pair) * M;
@@ -289,6 +304,75 @@ __global__ void __launch_bounds__(1024) stft_mixed_kernel(Params p)
         }
     }
 }
+
+__global__ void __launch_bounds__(1024) stft_mixed_kernel(Params p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2 *s = reinterpret_cast<float2 *>(smem_raw);
+    const uint32_t tid = threadIdx.x, nt = blockDim.x;
+    const uint32_t pair = blockIdx.y;
+    long long row_a, row_b;
+    Source src;
+    frame_source(p, pair, src, row_a, row_b);
+
+    for (uint32_t st = 0; st < p.n_stages; ++st) {
+        const uint32_t code = p.ra[st] * 8 + p.rb[st];  // uniform
+        DynGeo g;
+        g.m_ = p.m[st];
+        g.count_ = p.P / (p.ra[st] * p.rb[st]);
+        g.qs_ = p.q_stride[st];
+        g.bs_ = p.blk_stride[st];
+        g.W_ = p.W;
+        g.nt_ = nt;
+        g.inv_m_ = p.inv_m[st];
+        g.inv_pad_ = p.inv_pad;
+        g.first_ = st == 0;
+        const float2 *tw = p.tw + p.tw_off[st];
+        switch (code) {
+#define X(A, B) case A * 8 + B: stage<A, B>(s, p, tw, g, src, tid); break;
+            MIX_STAGE_CASES(X)
+#undef X
+        default: break;
+        }
+    }
+    split_store(p, s, pair, row_a, row_b, tid, nt);
+}
+
+// The two lengths the application produces (0.05 s at 48 and 44.1 kHz), three stages each, everything about the plan a
+// compile-time constant.  PAD = R2 (even) -> position(i) = i + i / R2; the host checks that its own plan for the length is
+// exactly this one before it launches these (mixed_init).
+template <int P_, int R0A, int R0B, int R1A, int R1B, int R2A, int R2B>
+struct Fixed3 {
+#ifndef SGX_MIX_FIXED_NT
+#define SGX_MIX_FIXED_NT 512   // 62 registers: eight waves per SIMD; every stage is one round (same-device A/B: 256 threads 1.41 ms, 320 1.31, 512 1.33 at 4800; 1.21 / 1.17 / 1.14 at 4410)
+#endif
+    static constexpr uint32_t P = P_, W = P_ / 2, NT = SGX_MIX_FIXED_NT;
+    static constexpr uint32_t R0 = R0A * R0B, R1 = R1A * R1B, R2 = R2A * R2B;
+    static constexpr uint32_t M0 = P / R0, M1 = M0 / R1, M2 = 1;
+    static constexpr uint32_t PAD = R2;
+    static constexpr uint32_t pp(uint32_t i) { return i + i / PAD; }
+    static constexpr uint32_t TW1 = M0 * (R0 - 1);   // offset of the second stage's twiddle rows
+    static_assert(M1 == R2 && R2 % 2 == 0 && M0 % R2 == 0, "plan shape");
+};
+
+template <typename F, int R0A, int R0B, int R1A, int R1B, int R2A, int R2B>
+__global__ void __launch_bounds__(SGX_MIX_FIXED_NT, SGX_MIX_FIXED_NT == 256 ? 4 : 8) stft_mixed_fixed_kernel(Params p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2 *s = reinterpret_cast<float2 *>(smem_raw);
+    const uint32_t tid = threadIdx.x;
+    const uint32_t pair = blockIdx.y;
+    long long row_a, row_b;
+    Source src;
+    frame_source(p, pair, src, row_a, row_b);
+    stage<R0A, R0B>(s, p, p.tw, FixGeo<F::M0, F::P / F::R0, F::pp(F::M0), F::pp(F::P), F::W, F::PAD, F::NT, true>{}, src, tid);
+    stage<R1A, R1B>(s, p, p.tw + F::TW1, FixGeo<F::M1, F::P / F::R1, F::pp(F::M1), F::pp(F::M0), F::W, F::PAD, F::NT, false>{}, src, tid);
+    stage<R2A, R2B>(s, p, p.tw, FixGeo<1, F::P / F::R2, 1, F::pp(F::M1), F::W, F::PAD, F::NT, false>{}, src, tid);
+    split_store(p, s, pair, row_a, row_b, tid, F::NT);
+}
+
+using Fixed4800 = Fixed3<4800, 5, 4, 5, 3, 4, 4>;
+using Fixed4410 = Fixed3<4410, 7, 3, 5, 3, 7, 2>;
 
 }  // namespace mix
 
@@ -422,6 +506,17 @@ hipError_t mixed_init(sgx_ctx *c, void **out)
         t->blk_stride[i] = padpos(t->m[i] * radix[i]);
     }
     t->threads = threads_of(t->lds_points);
+    auto is_plan = [&](uint32_t Pn, std::initializer_list<std::pair<uint32_t, uint32_t>> st, uint32_t tw1) {
+        if (P != Pn || t->n_stages != st.size() || t->threads != 256 || t->pad_every != radix[t->n_stages - 1]) return false;
+        uint32_t i = 0;
+        for (const auto &g : st) {
+            if (t->ra[i] != g.first || t->rb[i] != g.second) return false;
+            ++i;
+        }
+        return t->tw_off[1] == tw1;
+    };
+    if (is_plan(4800, {{5, 4}, {5, 3}, {4, 4}}, Fixed4800::TW1)) t->fixed = 4800;
+    if (is_plan(4410, {{7, 3}, {5, 3}, {7, 2}}, Fixed4410::TW1)) t->fixed = 4410;
     // bin K = k1 + r1 (k2 + r2 (k3 + ...)) ends at k1 m1 + k2 m2 + ...
     std::vector<uint32_t> pos(P);
     for (uint32_t K = 0; K < P; ++K) {
@@ -495,6 +590,11 @@ hipError_t launch_stft_mixed(const sgx_ctx *c, const void *tables, const float *
         if (e != hipSuccess) return e;
     }
     const unsigned threads = t->threads;
+    auto launch = [&](dim3 grid) {
+        if (t->fixed == 4800) hipLaunchKernelGGL((stft_mixed_fixed_kernel<Fixed4800, 5, 4, 5, 3, 4, 4>), grid, dim3(Fixed4800::NT), lds, c->stream, p);
+        else if (t->fixed == 4410) hipLaunchKernelGGL((stft_mixed_fixed_kernel<Fixed4410, 7, 3, 5, 3, 7, 2>), grid, dim3(Fixed4410::NT), lds, c->stream, p);
+        else hipLaunchKernelGGL(stft_mixed_kernel, grid, dim3(threads), lds, c->stream, p);
+    };
     const size_t max_chunk = 1u << 30;
     if (channels == 1 && !(c->cfg.flags & SGX_FLAG_INDEPENDENT_FRAMES)) {
         p.mono_pairs = 1;
@@ -503,7 +603,7 @@ hipError_t launch_stft_mixed(const sgx_ctx *c, const void *tables, const float *
         for (unsigned long long q = q0; q < q1; q += max_chunk) {
             const unsigned long long chunk = q1 - q < max_chunk ? q1 - q : max_chunk;
             p.pair_base = q;
-            hipLaunchKernelGGL(stft_mixed_kernel, dim3((unsigned)chunk, 1), dim3(threads), lds, c->stream, p);
+            launch(dim3((unsigned)chunk, 1));
             hipError_t e = hipGetLastError();
             if (e != hipSuccess) return e;
         }
@@ -514,7 +614,7 @@ hipError_t launch_stft_mixed(const sgx_ctx *c, const void *tables, const float *
         p.first_frame = first_frame + done;
         p.n_frames = chunk;
         p.mags = d_mags + done * (size_t)pairs * c->M * 2;
-        hipLaunchKernelGGL(stft_mixed_kernel, dim3((unsigned)chunk, pairs), dim3(threads), lds, c->stream, p);
+        launch(dim3((unsigned)chunk, pairs));
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
