@@ -385,6 +385,10 @@ int sgx_stft_batch_f16(sgx_ctx *c, const float *d_pcm, size_t n_samples, size_t 
     if (c->stft_kernel == 2) {
         hipError_t e = sgx::launch_stft_wg4096_f16(c, c->d_fast_wg, d_pcm, c->C, c->pairs, first_frame, n, total, d_mags_f16);
         if (e != hipSuccess) return fail_hip(c, e, "sgx_stft_batch_f16: kernel launch");
+    } else if (c->stft_kernel == 6) {
+        // the application's own window lengths: half pairs straight from the split (no float32 round trip)
+        hipError_t e = sgx::launch_stft_mixed(c, c->d_mix, d_pcm, c->C, c->pairs, first_frame, n, total, static_cast<float *>(d_mags_f16), true);
+        if (e != hipSuccess) return fail_hip(c, e, "sgx_stft_batch_f16: kernel launch");
     } else {
         // kernels without a native half store: float32 into the bounded workspace, then one conversion pass
         const size_t per_frame = (size_t)c->pairs * c->M;  // (l, r) pairs per frame

@@ -159,7 +159,7 @@ bool mixed_supported(uint32_t W);
 hipError_t mixed_init(sgx_ctx *c, void **out);
 void mixed_destroy(void *tables);
 hipError_t launch_stft_mixed(const sgx_ctx *c, const void *tables, const float *d_pcm, uint32_t channels, uint32_t pairs,
-                             size_t first_frame, size_t n_frames, size_t total_frames, float *d_mags);
+                             size_t first_frame, size_t n_frames, size_t total_frames, float *d_mags, bool out_f16 = false);   // out_f16: (l, r) half pairs, 4 B per bin
 bool bluestein_supported(uint32_t W);
 hipError_t bluestein_init(sgx_ctx *c, void **out);
 void bluestein_destroy(void *tables);

@@ -24,6 +24,8 @@
 #include <algorithm>
 #include <vector>
 
+#include <hip/hip_fp16.h>
+
 #include "sgx_internal.hpp"
 
 namespace sgx {
@@ -51,6 +53,7 @@ struct Params {
     float *mags;
     unsigned long long first_frame, pair_base, n_frames, total_frames;
     uint32_t mono_pairs, W, P, H, C, pairs, n_stages, vec2;
+    uint32_t out_f16;   // magnitudes are stored as (l, r) half pairs, 4 B per bin (the F16F16 ring of gpu_spectrogram.rs:218-226)
     float scale, inv_pad;
     uint32_t ra[kMaxStages], rb[kMaxStages], m[kMaxStages], tw_off[kMaxStages], q_stride[kMaxStages], blk_stride[kMaxStages];
     float inv_m[kMaxStages];
@@ -287,8 +290,9 @@ __device__ __forceinline__ void split_store(const Params &p, const float2 *s, ui
     const uint32_t M = p.W - 1;
     const bool st_a = row_a >= 0 && (unsigned long long)row_a < p.n_frames;
     const bool st_b = p.mono_pairs && row_b >= 0 && (unsigned long long)row_b < p.n_frames;
-    float2 *out_a = reinterpret_cast<float2 *>(p.mags) + ((size_t)(st_a ? row_a : 0) * p.pairs + pair) * M;
-    float2 *out_b = reinterpret_cast<float2 *>(p.mags) + ((size_t)(st_b ? row_b : 0) * p.pairs + pair) * M;
+    const size_t off_a = ((size_t)(st_a ? row_a : 0) * p.pairs + pair) * M, off_b = ((size_t)(st_b ? row_b : 0) * p.pairs + pair) * M;
+    float2 *out_a = reinterpret_cast<float2 *>(p.mags) + off_a, *out_b = reinterpret_cast<float2 *>(p.mags) + off_b;
+    __half2 *half_a = reinterpret_cast<__half2 *>(p.mags) + off_a, *half_b = reinterpret_cast<__half2 *>(p.mags) + off_b;
     for (uint32_t j = tid; j < M; j += nt) {
         const uint32_t w = p.split[j];
         const float2 a = s[w & 0xffffu], b = s[w >> 16];
@@ -296,7 +300,14 @@ __device__ __forceinline__ void split_store(const Params &p, const float2 *s, ui
         const float dre = a.x - b.x, dim = a.y + b.y;
         const float left = sqrtf(fmaf(sre, sre, sim * sim)) * 0.5f * p.scale;
         const float right = sqrtf(fmaf(dre, dre, dim * dim)) * 0.5f * p.scale;
-        if (p.mono_pairs) {
+        if (p.out_f16) {   // round to nearest even, as the conversion pass of the kernels without a native half store
+            if (p.mono_pairs) {
+                if (st_a) half_a[j] = __floats2half2_rn(left, left);
+                if (st_b) half_b[j] = __floats2half2_rn(right, right);
+            } else {
+                half_a[j] = __floats2half2_rn(left, right);
+            }
+        } else if (p.mono_pairs) {
             if (st_a) st_stream(out_a + j, left, left);
             if (st_b) st_stream(out_b + j, right, right);
         } else {
@@ -551,7 +562,7 @@ void mixed_destroy(void *tables)
 }
 
 hipError_t launch_stft_mixed(const sgx_ctx *c, const void *tables, const float *d_pcm, uint32_t channels, uint32_t pairs,
-                             size_t first_frame, size_t n_frames, size_t total_frames, float *d_mags)
+                             size_t first_frame, size_t n_frames, size_t total_frames, float *d_mags, bool out_f16)
 {
     using namespace mix;
     if (n_frames == 0) return hipSuccess;
@@ -568,6 +579,7 @@ hipError_t launch_stft_mixed(const sgx_ctx *c, const void *tables, const float *
     p.pairs = pairs;
     p.scale = 2.0f / (float)c->W;
     p.n_stages = t->n_stages;
+    p.out_f16 = out_f16 ? 1u : 0u;
     p.inv_pad = t->pad_every ? 1.0f / (float)t->pad_every : 0.0f;
     for (uint32_t i = 0; i < t->n_stages; ++i) {
         p.ra[i] = t->ra[i];
@@ -613,7 +625,7 @@ hipError_t launch_stft_mixed(const sgx_ctx *c, const void *tables, const float *
         const size_t chunk = n_frames - done < max_chunk ? n_frames - done : max_chunk;
         p.first_frame = first_frame + done;
         p.n_frames = chunk;
-        p.mags = d_mags + done * (size_t)pairs * c->M * 2;
+        p.mags = d_mags + done * (size_t)pairs * c->M * (out_f16 ? 1 : 2);
         launch(dim3((unsigned)chunk, pairs));
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;

@@ -653,9 +653,12 @@ def test_frame_pairing_dynamic_range_and_independent_frames(torch_cuda, mags_err
 
 
 @pytest.mark.parametrize("kw", [dict(channels=1), dict(channels=2), dict(channels=1, force_generic=True),
-                                dict(channels=2, window_samples=2400, hop_samples=93)])
+                                dict(channels=2, window_samples=2400, hop_samples=93), dict(channels=1, window_samples=2400, hop_samples=93),
+                                dict(channels=2, window_samples=2205, hop_samples=86), dict(channels=4, window_samples=1600, hop_samples=50),
+                                dict(channels=2, window_samples=1102, hop_samples=100)])
 def test_half_precision_ring_rows(torch_cuda, kw):
-    # the F16F16 ring format of the default widget: the half rows are the float rows rounded to nearest even
+    # the F16F16 ring format of the default widget: the half rows are the float rows rounded to nearest even (the 4096-point
+    # and the mixed-radix kernels store them themselves, the others through a conversion pass)
     torch = torch_cuda
     kw = dict(dict(window_samples=W, hop_samples=H), **kw)
     eng = engine(**kw)
