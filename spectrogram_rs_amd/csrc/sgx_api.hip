@@ -8,6 +8,10 @@
 #include "sgx_gradients.inc"
 #include "sgx_internal.hpp"
 
+#ifndef SGX_POW2_MIXED_MIN
+#define SGX_POW2_MIXED_MIN 512
+#endif
+
 namespace {
 
 thread_local std::string g_create_error;
@@ -255,9 +259,10 @@ int sgx_create(const sgx_config *cfg, sgx_ctx **out_ctx)
     if (rc != SGX_OK) { std::string m = c->err; return bail(rc, m); }
 
     c->stft_kernel = 0;
-    // powers of two from W = 1024 on that have no tuned kernel ride the composite-radix stages too (16 x 16 x 8 ...): same-device
-    // A/B against the radix-4 ladder of the generic kernel: W 1024 stereo +28 %, W 4096 +54 % mono / +78 % stereo; W 512: -30 %
-    const bool pow2_mixed = pow2 && c->W >= 1024 && c->W != 2048 && c->W != 8192 && sgx::mixed_supported(c->W) && !(cfg->flags & SGX_FLAG_FORCE_GENERIC);
+    // powers of two from W = 512 on that have no tuned kernel ride the composite-radix stages too (compile-time plans 4 x 16 x 16,
+    // 8 x 16 x 16, 4 x 8 x 16 x 16): same-device A/B against the radix-4 ladder of the generic kernel, mono / stereo:
+    // W 512 +29 % / +44 %, W 1024 +48 % / +90 %, W 4096 +83 % / +117 %; W 256: -14 %, W 128: -53 % (run-time geometry)
+    const bool pow2_mixed = pow2 && c->W >= SGX_POW2_MIXED_MIN && c->W != 2048 && c->W != 8192 && sgx::mixed_supported(c->W) && !(cfg->flags & SGX_FLAG_FORCE_GENERIC);
     if (pow2_mixed || (!pow2 && sgx::mixed_supported(c->W) && !((cfg->flags & SGX_FLAG_FORCE_GENERIC) && sgx::bluestein_supported(c->W)))) {
         // a length FFTW would factor: mixed-radix transform of exactly 2W points (SGX_FLAG_FORCE_GENERIC: chirp-z instead)
         e = sgx::mixed_init(c, &c->d_mix);
@@ -328,6 +333,7 @@ int sgx_query(const sgx_ctx *c, sgx_info *out)
     out->render_path = 0;
     if ((c->stft_kernel == 2 || c->stft_kernel == 3) && !(c->cfg.flags & SGX_FLAG_NO_FUSED_RENDER) && sgx::wg4096_can_fuse_render(c, c->d_fast_wg))
         out->render_path = 1u | (sgx::wg4096_seed_is_within_one(c) ? 2u : 0u);
+    if (c->stft_kernel == 6 && sgx::mixed_fixed_plan(c->d_mix)) out->render_path |= 4u;
     out->mags_bytes_per_frame = (uint64_t)c->pairs * c->M * 2 * sizeof(float);
     out->rgba_bytes_per_frame = (uint64_t)c->pairs * c->R * 4;
     return SGX_OK;

@@ -158,6 +158,7 @@ hipError_t launch_stft_q16384(const sgx_ctx *c, void *tables, const float *d_pcm
 bool mixed_supported(uint32_t W);
 hipError_t mixed_init(sgx_ctx *c, void **out);
 void mixed_destroy(void *tables);
+uint32_t mixed_fixed_plan(const void *tables);   // the length whose compile-time plan serves this context, or 0 (run-time geometry)
 hipError_t launch_stft_mixed(const sgx_ctx *c, const void *tables, const float *d_pcm, uint32_t channels, uint32_t pairs,
                              size_t first_frame, size_t n_frames, size_t total_frames, float *d_mags, bool out_f16 = false);   // out_f16: (l, r) half pairs, 4 B per bin
 bool bluestein_supported(uint32_t W);

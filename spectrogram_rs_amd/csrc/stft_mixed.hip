@@ -352,22 +352,30 @@ __global__ void __launch_bounds__(1024) stft_mixed_kernel(Params p)
 // The two lengths the application produces (0.05 s at 48 and 44.1 kHz), three stages each, everything about the plan a
 // compile-time constant.  PAD = R2 (even) -> position(i) = i + i / R2; the host checks that its own plan for the length is
 // exactly this one before it launches these (mixed_init).
-template <int P_, int R0A, int R0B, int R1A, int R1B, int R2A, int R2B>
+template <int P_, int R0A, int R0B, int R1A, int R1B, int R2A, int R2B, int NT_>
 struct Fixed3 {
-#ifndef SGX_MIX_FIXED_NT
-#define SGX_MIX_FIXED_NT 512   // 62 registers: eight waves per SIMD; every stage is one round (same-device A/B: 256 threads 1.41 ms, 320 1.31, 512 1.33 at 4800; 1.21 / 1.17 / 1.14 at 4410)
-#endif
-    static constexpr uint32_t P = P_, W = P_ / 2, NT = SGX_MIX_FIXED_NT;
+    static constexpr uint32_t P = P_, W = P_ / 2, NT = NT_;
     static constexpr uint32_t R0 = R0A * R0B, R1 = R1A * R1B, R2 = R2A * R2B;
     static constexpr uint32_t M0 = P / R0, M1 = M0 / R1, M2 = 1;
-    static constexpr uint32_t PAD = R2;
-    static constexpr uint32_t pp(uint32_t i) { return i + i / PAD; }
+    static constexpr uint32_t PAD = R2 % 2 == 0 ? R2 : 0;   // an odd lane stride needs no padding
+    static constexpr uint32_t pp(uint32_t i) { return i + (PAD ? i / (PAD ? PAD : 1) : 0); }
     static constexpr uint32_t TW1 = M0 * (R0 - 1);   // offset of the second stage's twiddle rows
-    static_assert(M1 == R2 && R2 % 2 == 0 && M0 % R2 == 0, "plan shape");
+    static_assert(M1 == R2 && M0 % R2 == 0 && R0 * R1 * R2 == P, "plan shape");
+};
+
+template <int P_, int R0A, int R0B, int R1A, int R1B, int R2A, int R2B, int R3A, int R3B, int NT_>
+struct Fixed4 {
+    static constexpr uint32_t P = P_, W = P_ / 2, NT = NT_;
+    static constexpr uint32_t R0 = R0A * R0B, R1 = R1A * R1B, R2 = R2A * R2B, R3 = R3A * R3B;
+    static constexpr uint32_t M0 = P / R0, M1 = M0 / R1, M2 = M1 / R2;
+    static constexpr uint32_t PAD = R3 % 2 == 0 ? R3 : 0;
+    static constexpr uint32_t pp(uint32_t i) { return i + (PAD ? i / (PAD ? PAD : 1) : 0); }
+    static constexpr uint32_t TW1 = M0 * (R0 - 1), TW2 = TW1 + M1 * (R1 - 1);
+    static_assert(M2 == R3 && M1 % R3 == 0 && M0 % R3 == 0 && R0 * R1 * R2 * R3 == P, "plan shape");
 };
 
 template <typename F, int R0A, int R0B, int R1A, int R1B, int R2A, int R2B>
-__global__ void __launch_bounds__(SGX_MIX_FIXED_NT, SGX_MIX_FIXED_NT == 256 ? 4 : 8) stft_mixed_fixed_kernel(Params p)
+__global__ void __launch_bounds__(F::NT, F::NT == 256 ? 4 : 8) stft_mixed_fixed_kernel(Params p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float2 *s = reinterpret_cast<float2 *>(smem_raw);
@@ -382,8 +390,32 @@ __global__ void __launch_bounds__(SGX_MIX_FIXED_NT, SGX_MIX_FIXED_NT == 256 ? 4 
     split_store(p, s, pair, row_a, row_b, tid, F::NT);
 }
 
-using Fixed4800 = Fixed3<4800, 5, 4, 5, 3, 4, 4>;
-using Fixed4410 = Fixed3<4410, 7, 3, 5, 3, 7, 2>;
+template <typename F, int R0A, int R0B, int R1A, int R1B, int R2A, int R2B, int R3A, int R3B>
+__global__ void __launch_bounds__(F::NT, F::NT == 256 ? 4 : (F::NT == 512 ? 8 : 4)) stft_mixed_fixed4_kernel(Params p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2 *s = reinterpret_cast<float2 *>(smem_raw);
+    const uint32_t tid = threadIdx.x;
+    const uint32_t pair = blockIdx.y;
+    long long row_a, row_b;
+    Source src;
+    frame_source(p, pair, src, row_a, row_b);
+    stage<R0A, R0B>(s, p, p.tw, FixGeo<F::M0, F::P / F::R0, F::pp(F::M0), F::pp(F::P), F::W, F::PAD, F::NT, true>{}, src, tid);
+    stage<R1A, R1B>(s, p, p.tw + F::TW1, FixGeo<F::M1, F::P / F::R1, F::pp(F::M1), F::pp(F::M0), F::W, F::PAD, F::NT, false>{}, src, tid);
+    stage<R2A, R2B>(s, p, p.tw + F::TW2, FixGeo<F::M2, F::P / F::R2, F::pp(F::M2), F::pp(F::M1), F::W, F::PAD, F::NT, false>{}, src, tid);
+    stage<R3A, R3B>(s, p, p.tw, FixGeo<1, F::P / F::R3, 1, F::pp(F::M2), F::W, F::PAD, F::NT, false>{}, src, tid);
+    split_store(p, s, pair, row_a, row_b, tid, F::NT);
+}
+
+// P, the three stages (RA, RB), threads.  0.05 s at 48 / 44.1 / 32 / 16 / 8 / 88.2 kHz.  512 threads where a stage has more than
+// 256 butterflies (62-64 registers: eight waves per SIMD; same-device A/B at 4800 points: 256 threads 1.41 ms per 100 000
+// stereo frames, 320 1.31, 512 1.33; at 4410: 1.21 / 1.17 / 1.14).
+#define MIX_FIXED_PLANS(X) X(4800, 5, 4, 5, 3, 4, 4, 512) X(4410, 7, 3, 5, 3, 7, 2, 512) X(3200, 5, 4, 5, 2, 4, 4, 512) \
+                           X(1600, 5, 4, 5, 1, 4, 4, 512) X(800, 5, 2, 5, 1, 4, 4, 256) X(8820, 7, 3, 7, 3, 5, 4, 512) \
+                           X(2048, 4, 2, 4, 4, 4, 4, 256) X(1024, 4, 1, 4, 4, 4, 4, 256)
+// four stages: 0.05 s at 96 / 192 / 176.4 kHz, and the 8192-point power of two
+#define MIX_FIXED4_PLANS(X) X(9600, 4, 3, 5, 2, 5, 1, 4, 4, 1024) X(19200, 5, 3, 5, 1, 4, 4, 4, 4, 1024) \
+                            X(17640, 5, 3, 7, 2, 4, 3, 7, 1, 1024) X(8192, 4, 1, 4, 2, 4, 4, 4, 4, 512)
 
 }  // namespace mix
 
@@ -517,17 +549,25 @@ hipError_t mixed_init(sgx_ctx *c, void **out)
         t->blk_stride[i] = padpos(t->m[i] * radix[i]);
     }
     t->threads = threads_of(t->lds_points);
-    auto is_plan = [&](uint32_t Pn, std::initializer_list<std::pair<uint32_t, uint32_t>> st, uint32_t tw1) {
-        if (P != Pn || t->n_stages != st.size() || t->threads != 256 || t->pad_every != radix[t->n_stages - 1]) return false;
-        uint32_t i = 0;
-        for (const auto &g : st) {
-            if (t->ra[i] != g.first || t->rb[i] != g.second) return false;
-            ++i;
+    auto is_plan = [&](uint32_t Pn, std::initializer_list<uint32_t> ab) {   // the compiled plan of a fixed kernel == the host's
+        if (P != Pn || t->n_stages * 2 != ab.size()) return false;
+        uint32_t i = 0, off = 0;
+        for (auto it = ab.begin(); it != ab.end(); ++i) {
+            const uint32_t a = *it++, b = *it++;
+            if (t->ra[i] != a || t->rb[i] != b || (t->m[i] > 1 && t->tw_off[i] != off)) return false;
+            off += t->m[i] * (a * b - 1);
         }
-        return t->tw_off[1] == tw1;
+        const uint32_t rl = radix[t->n_stages - 1];
+        return t->pad_every == (rl % 2 == 0 ? rl : 0u);
     };
-    if (is_plan(4800, {{5, 4}, {5, 3}, {4, 4}}, Fixed4800::TW1)) t->fixed = 4800;
-    if (is_plan(4410, {{7, 3}, {5, 3}, {7, 2}}, Fixed4410::TW1)) t->fixed = 4410;
+#ifndef SGX_MIX_NO_FIXED   // (A/B builds)
+#define X(Pn, A0, B0, A1, B1, A2, B2, N) if (is_plan(Pn, {A0, B0, A1, B1, A2, B2})) t->fixed = Pn;
+    MIX_FIXED_PLANS(X)
+#undef X
+#define X(Pn, A0, B0, A1, B1, A2, B2, A3, B3, N) if (is_plan(Pn, {A0, B0, A1, B1, A2, B2, A3, B3})) t->fixed = Pn;
+    MIX_FIXED4_PLANS(X)
+#undef X
+#endif
     // bin K = k1 + r1 (k2 + r2 (k3 + ...)) ends at k1 m1 + k2 m2 + ...
     std::vector<uint32_t> pos(P);
     for (uint32_t K = 0; K < P; ++K) {
@@ -551,6 +591,8 @@ hipError_t mixed_init(sgx_ctx *c, void **out)
     *out = t;
     return hipSuccess;
 }
+
+uint32_t mixed_fixed_plan(const void *tables) { return tables ? (uint32_t)static_cast<const mix::MixTables *>(tables)->fixed : 0u; }
 
 void mixed_destroy(void *tables)
 {
@@ -596,16 +638,27 @@ hipError_t launch_stft_mixed(const sgx_ctx *c, const void *tables, const float *
     // (l, r) of a channel pair as one 8-byte word: even channel count and an 8-byte aligned stream
     p.vec2 = (channels >= 2 && channels % 2 == 0 && reinterpret_cast<uintptr_t>(d_pcm) % 8 == 0) ? 1u : 0u;
     const size_t lds = (size_t)t->lds_points * sizeof(float2);
-    if (lds > 64 * 1024) {  // per launch: the attribute is per device, and a process may hold contexts on several
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(stft_mixed_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)lds);
-        if (e != hipSuccess) return e;
-    }
     const unsigned threads = t->threads;
+    hipError_t attr_err = hipSuccess;
+    auto go = [&](auto kernel, unsigned nt, dim3 grid) {
+        if (lds > 64 * 1024) {  // per launch: the attribute is per device, and a process may hold contexts on several
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) { attr_err = e; return; }
+        }
+        hipLaunchKernelGGL(kernel, grid, dim3(nt), lds, c->stream, p);
+    };
     auto launch = [&](dim3 grid) {
-        if (t->fixed == 4800) hipLaunchKernelGGL((stft_mixed_fixed_kernel<Fixed4800, 5, 4, 5, 3, 4, 4>), grid, dim3(Fixed4800::NT), lds, c->stream, p);
-        else if (t->fixed == 4410) hipLaunchKernelGGL((stft_mixed_fixed_kernel<Fixed4410, 7, 3, 5, 3, 7, 2>), grid, dim3(Fixed4410::NT), lds, c->stream, p);
-        else hipLaunchKernelGGL(stft_mixed_kernel, grid, dim3(threads), lds, c->stream, p);
+        switch (t->fixed) {
+#define X(Pn, A0, B0, A1, B1, A2, B2, N) \
+    case Pn: go(stft_mixed_fixed_kernel<Fixed3<Pn, A0, B0, A1, B1, A2, B2, N>, A0, B0, A1, B1, A2, B2>, N, grid); break;
+            MIX_FIXED_PLANS(X)
+#undef X
+#define X(Pn, A0, B0, A1, B1, A2, B2, A3, B3, N) \
+    case Pn: go(stft_mixed_fixed4_kernel<Fixed4<Pn, A0, B0, A1, B1, A2, B2, A3, B3, N>, A0, B0, A1, B1, A2, B2, A3, B3>, N, grid); break;
+            MIX_FIXED4_PLANS(X)
+#undef X
+        default: go(stft_mixed_kernel, threads, grid); break;
+        }
     };
     const size_t max_chunk = 1u << 30;
     if (channels == 1 && !(c->cfg.flags & SGX_FLAG_INDEPENDENT_FRAMES)) {
@@ -616,7 +669,7 @@ hipError_t launch_stft_mixed(const sgx_ctx *c, const void *tables, const float *
             const unsigned long long chunk = q1 - q < max_chunk ? q1 - q : max_chunk;
             p.pair_base = q;
             launch(dim3((unsigned)chunk, 1));
-            hipError_t e = hipGetLastError();
+            hipError_t e = attr_err != hipSuccess ? attr_err : hipGetLastError();
             if (e != hipSuccess) return e;
         }
         return hipSuccess;
@@ -627,7 +680,7 @@ hipError_t launch_stft_mixed(const sgx_ctx *c, const void *tables, const float *
         p.n_frames = chunk;
         p.mags = d_mags + done * (size_t)pairs * c->M * (out_f16 ? 1 : 2);
         launch(dim3((unsigned)chunk, pairs));
-        hipError_t e = hipGetLastError();
+        hipError_t e = attr_err != hipSuccess ? attr_err : hipGetLastError();
         if (e != hipSuccess) return e;
     }
     return hipSuccess;

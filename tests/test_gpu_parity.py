@@ -127,8 +127,8 @@ def test_config4_16384_point_kernel(torch_cuda, mags_err, ch, force_generic):
 
 @pytest.mark.parametrize("Wt,Ht", [(512, 64), (256, 100), (1024, 333), (4096, 512), (2400, 93), (735, 200), (1102, 100)])
 def test_generic_kernel_pairs_mono_frames_by_global_index(torch_cuda, mags_err, Wt, Ht):
-    # sizes served by the generic power-of-two kernel (W < 1024), the mixed-radix kernel (4800 = 2^6 3 5^2, 1470 = 2 3 5 7^2,
-    # and the powers of two from W = 1024 on that have no tuned kernel: 2048 = 16 x 16 x 8, 8192 = 16 x 16 x 16 x 2) and the
+    # sizes served by the generic power-of-two kernel (W < 512), the mixed-radix kernel (4800 = 2^6 3 5^2, 1470 = 2 3 5 7^2,
+    # and the powers of two from W = 512 on that have no tuned kernel: 1024 = 4 x 16 x 16, 2048 = 8 x 16 x 16, 8192 = 4 x 8 x 16 x 16) and the
     # chirp-z kernel (2204 = 4 * 19 * 29): a mono stream rides two frames per transform there too
     # (frames 2q and 2q+1 in the real / imaginary part), any sub-range writes the bytes of the full run, and
     # SGX_FLAG_INDEPENDENT_FRAMES restores the reference's (s, s) dataflow
@@ -137,7 +137,7 @@ def test_generic_kernel_pairs_mono_frames_by_global_index(torch_cuda, mags_err, 
     dev = to_dev(torch, pcm)
     ref = oracle.stream_process(pcm, 1, Wt, Ht, threads=8)
     eng = engine(window_samples=Wt, hop_samples=Ht, channels=1)
-    assert eng.info.stft_kernel == ((0 if Wt < 1024 else 6) if Wt & (Wt - 1) == 0 else (4 if Wt == 1102 else 6))
+    assert eng.info.stft_kernel == ((0 if Wt < 512 else 6) if Wt & (Wt - 1) == 0 else (4 if Wt == 1102 else 6))
     tol = 2.0
     got = eng.stft_batch(dev).cpu().numpy()
     assert got.shape == ref.shape == (38, 1, Wt - 1, 2)
@@ -459,6 +459,29 @@ def test_render_stereo_scheme_bit_exact(torch_cuda, gradients):
     ref = oracle.render_columns(mags, SR, gradients["plasma"], stereo=True)
     assert np.array_equal(got, ref)
     assert got[..., 3].min() == 0 and got[..., 3].max() == 255
+
+
+@pytest.mark.parametrize("sr,Wexp,fixed", [(8000, 400, True), (16000, 800, True), (32000, 1600, True), (44100, 2205, True), (48000, 2400, True),
+                                           (88200, 4410, True), (96000, 4800, True), (176400, 8820, True), (192000, 9600, True),
+                                           (24000, 1200, False), (64000, 3200, False)])
+def test_duration_sized_windows_of_the_usual_sample_rates(torch_cuda, mags_err, sr, Wexp, fixed):
+    # FastFourierTransform::new(sample_rate, 0.05) (gpu_spectrogram.rs:323): the lengths the usual device rates produce run
+    # instantiations of the mixed-radix kernel whose plan is a compile-time constant (sgx_info.render_path bit 2), every
+    # other smooth length the run-time geometry: same results either way, stereo and mono pairs, sub-ranges included
+    torch = torch_cuda
+    from spectrogram_rs_amd import SpectrogramEngine
+    for ch in (2, 1):
+        eng = SpectrogramEngine(float(sr), period=0.05, stride=0.004, channels=ch)
+        assert eng.W == Wexp and eng.info.stft_kernel == 6 and bool(eng.info.render_path & 4) == fixed
+        n = eng.W + 6 * eng.H + 5
+        pcm = oracle.white_noise(n * ch, seed=sr % 1000)
+        dev = to_dev(torch, pcm)
+        got = eng.stft_batch(dev).cpu().numpy()
+        ref = oracle.stream_process(pcm, ch, eng.W, eng.H, threads=8)
+        assert got.shape == ref.shape and got.shape[0] == 7
+        assert mags_err(got, ref) <= 2.0
+        assert np.array_equal(eng.stft_batch(dev, first_frame=3, max_frames=3).cpu().numpy(), got[3:6])
+        assert torch.equal(eng.stft_batch_f16(dev), torch.from_numpy(got).cuda().to(torch.float16))
 
 
 @pytest.mark.parametrize("Wt,Ht,interp", [(1024, 128, "cubic"), (4096, 512, "cubic"), (4096, 512, "cosine"), (8192, 512, "cosine"), (300, 50, "cubic")])

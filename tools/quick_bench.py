@@ -157,7 +157,10 @@ if __name__ == "__main__" and "--generic-sizes" in sys.argv:
 
 def others(frames=100_000):
     """the kernels beside the tuned ones: mixed radix (the app's window), chirp-z, generic power of two"""
-    for W, H, ch in ((2400, 93, 2), (2400, 93, 1), (2205, 86, 2), (1102, 100, 2), (1024, 128, 2), (1024, 128, 1), (512, 64, 2)):
+    sizes = ((2400, 93, 2), (2400, 93, 1), (2205, 86, 2), (1102, 100, 2), (1024, 128, 2), (1024, 128, 1), (512, 64, 2))
+    if "--rates" in sys.argv:   # 0.05 s at 8 / 16 / 32 / 88.2 / 96 / 192 kHz
+        sizes = ((400, 16, 2), (800, 31, 2), (1600, 62, 2), (4410, 172, 2), (4800, 187, 2), (9600, 375, 2))
+    for W, H, ch in sizes:
         eng = SpectrogramEngine(48000.0, window_samples=W, hop_samples=H, channels=ch)
         pcm = eng.white_noise((frames - 1) * eng.H + eng.W)
         out = torch.empty((frames, 1, eng.M, 2), dtype=torch.float32, device="cuda")
