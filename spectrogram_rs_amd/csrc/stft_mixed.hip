@@ -13,7 +13,7 @@
 // digit reversal, a host table); the split reads F[k] and F[P - k] through it.
 //
 // Round 2: a stage's radix is a PRODUCT of two prime-ish factors (R = RA RB <= 28: 4800 = 20 x 15 x 16, 4410 =
-// 21 x 21 x 10), its R-point DFT done in registers (RB transforms of RA points, constant twiddles, RA transforms of
+// 21 x 15 x 14), its R-point DFT done in registers (RB transforms of RA points, constant twiddles, RA transforms of
 // RB points), so a transform makes three trips through LDS instead of six; the first stage reads the windowed
 // samples straight from the stream (no staging trip for the input), the last (m = 1) has no twiddles; a stage's
 // twiddles w_Ns^{j k}, k = 1 .. R-1, lie side by side in a per-stage table (16-byte reads instead of R-1 gathers
@@ -21,6 +21,10 @@
 // points); the split reads both positions of a bin from one packed word.  Measured at W = 2400, hop 93, stereo
 // (SQ counters, profiles/r02_mixed_radix.txt): the first version kept the LDS array busy 62 % of the launch, 58 %
 // of that in bank conflicts, and the address unit 58 %.
+//
+// The lengths the usual device rates produce (and the powers of two without a tuned kernel) run instantiations whose
+// whole plan is a compile-time constant (stft_mixed_fixed_kernel / stft_mixed_fixed4_kernel, MIX_FIXED_PLANS): the same
+// stage() over FixGeo instead of DynGeo; half the registers, workgroups of 512 / 1024 threads, +24 % to +64 %.
 #include <algorithm>
 #include <vector>
 
@@ -39,7 +43,7 @@ struct MixTables {
     uint32_t *d_split = nullptr;  // [M] padded position of bin k | padded position of bin P - k << 16   (k = j + 1)
     float2 *d_tw = nullptr;       // per stage: [m][R - 1] w_Ns^{j k}
     uint32_t n_stages = 0, pad_every = 0, lds_points = 0, threads = 0;
-    int fixed = 0;                // 4800 / 4410: the host's plan is the compile-time one of stft_mixed_fixed_kernel
+    int fixed = 0;                // P when the host's plan is the compile-time one of a fixed kernel (MIX_FIXED_PLANS), else 0
     uint32_t ra[kMaxStages] = {}, rb[kMaxStages] = {}, m[kMaxStages] = {}, tw_off[kMaxStages] = {};
     uint32_t q_stride[kMaxStages] = {}, blk_stride[kMaxStages] = {};   // padded LDS positions: see stage()
     float inv_m[kMaxStages] = {};
