@@ -104,7 +104,8 @@ typedef struct sgx_info {
     uint32_t sample_rate_u32; /* SampleRate(sample_rate as u32)      simple_spectrogram.rs:138 */
     uint32_t total_samples_per_column; /* sum over rows of magnitude_in's sample count */
     uint32_t stft_kernel;     /* 0 = generic power-of-two, 1 = 4096-point wave-per-transform, 2 = 4096-point workgroup-per-transform (default), 3 = the same with packed (re, im) arithmetic, 4 = Bluestein chirp-z (any 2W), 5 = 16384-point as four 4096-point residues (default for W = 8192), 6 = mixed radix (2W = 2^a 3^b 5^c 7^d <= 20480, e.g. the application's 4800, 4410 and 19200), 7 = 16384-point, whole transform in LDS (SGX_FLAG_LEGACY_16K) */
-    uint32_t render_path;     /* sgx_render_batch as configured NOW (palette included): bit 0 = one fused PCM-to-pixel kernel,
+    uint32_t render_path;     /* sgx_render_batch as configured NOW (palette included): bit 0 = one fused PCM-to-pixel kernel (the
+                                 4096-point kernel, or a compile-time plan of the mixed-radix kernel whose LDS image holds the column),
                                  bit 1 = its LUT index is seed + one compare pair (else seed + walk); neither = two kernels;
                                  bit 2 = the mixed-radix transform kernel runs a compile-time plan for this length (the
                                  0.05 s windows of the usual sample rates, 8 kHz to 192 kHz) */

@@ -122,6 +122,17 @@ int upload_palette(sgx_ctx *c)
             for (int cell = sgx::sgx_t_cell(thr) + 1; cell <= sgx::kTCells; ++cell) ++c->pal.t_cell[cell];
     }
     SGX_HIP(c, upload(&c->d_t_cell, c->pal.t_cell.data(), c->pal.t_cell.size()));
+    std::vector<uint2> seed;
+    if (!c->pal.stereo && c->pal.n == 256 && c->pal.lut_thr.size() == 255) {
+        seed.resize(256);
+        for (uint32_t i = 0; i < 256; ++i) {
+            uint32_t thr_bits = 0x7fc00000u, word = 0;   // NaN: no power leaves the last level
+            if (i < 255) std::memcpy(&thr_bits, &c->pal.lut_thr[i], 4);
+            std::memcpy(&word, &rgba[i], 4);
+            seed[i] = make_uint2(thr_bits, word | 0xff000000u);
+        }
+    }
+    SGX_HIP(c, upload(&c->d_pal_seed, seed.data(), seed.size()));
     ++c->palette_gen;
     return SGX_OK;
 }
@@ -307,7 +318,7 @@ void sgx_destroy(sgx_ctx *c)
     sgx::q16384_destroy(c->d_q16k);
     c->d_q16k = nullptr;
     void *ptrs[] = {c->d_window, c->d_twiddle, c->d_rows, c->d_samples, c->d_lut_thr, c->d_alpha_thr,
-                    c->d_lut_rgba, c->d_t_thr, c->d_t_cell, c->d_band_rows, c->d_band_samples, c->d_levels, c->d_ws_mags, c->d_one_in, c->d_one_out, c->d_cksum};
+                    c->d_lut_rgba, c->d_pal_seed, c->d_t_thr, c->d_t_cell, c->d_band_rows, c->d_band_samples, c->d_levels, c->d_ws_mags, c->d_one_in, c->d_one_out, c->d_cksum};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete c;
@@ -334,6 +345,7 @@ int sgx_query(const sgx_ctx *c, sgx_info *out)
     if ((c->stft_kernel == 2 || c->stft_kernel == 3) && !(c->cfg.flags & SGX_FLAG_NO_FUSED_RENDER) && sgx::wg4096_can_fuse_render(c, c->d_fast_wg))
         out->render_path = 1u | (sgx::wg4096_seed_is_within_one(c) ? 2u : 0u);
     if (c->stft_kernel == 6 && sgx::mixed_fixed_plan(c->d_mix)) out->render_path |= 4u;
+    if (c->stft_kernel == 6 && !(c->cfg.flags & SGX_FLAG_NO_FUSED_RENDER) && sgx::mixed_can_fuse_render(c, c->d_mix)) out->render_path |= 3u;
     out->mags_bytes_per_frame = (uint64_t)c->pairs * c->M * 2 * sizeof(float);
     out->rgba_bytes_per_frame = (uint64_t)c->pairs * c->R * 4;
     return SGX_OK;
@@ -456,6 +468,13 @@ int sgx_render_batch(sgx_ctx *c, const float *d_pcm, size_t n_samples, size_t fi
         hipError_t e = c->stft_kernel == 3
                            ? sgx::launch_render_wgp4096(c, c->d_fast_wg, d_pcm, c->C, c->pairs, first_frame, n, total, d_rgba)
                            : sgx::launch_render_wg4096(c, c->d_fast_wg, d_pcm, c->C, c->pairs, first_frame, n, total, d_rgba);
+        if (e != hipSuccess) return fail_hip(c, e, "sgx_render_batch: fused launch");
+        if (n_out) *n_out = n;
+        return SGX_OK;
+    }
+    if (c->stft_kernel == 6 && !(c->cfg.flags & SGX_FLAG_NO_FUSED_RENDER) && sgx::mixed_can_fuse_render(c, c->d_mix)) {
+        // the application's own window lengths, one kernel from PCM to pixels: the pixel stage runs on the transform's LDS image
+        hipError_t e = sgx::launch_render_mixed(c, c->d_mix, d_pcm, c->C, c->pairs, first_frame, n, total, d_rgba);
         if (e != hipSuccess) return fail_hip(c, e, "sgx_render_batch: fused launch");
         if (n_out) *n_out = n;
         return SGX_OK;

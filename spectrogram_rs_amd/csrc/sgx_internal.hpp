@@ -95,6 +95,7 @@ struct sgx_ctx {
     float *d_lut_thr = nullptr;    // [n-1]
     float *d_alpha_thr = nullptr;  // [255]
     uchar4 *d_lut_rgba = nullptr;  // [n]
+    uint2 *d_pal_seed = nullptr;   // [256] {threshold to leave level i (NaN for 255), RGBA of level i}: 256-level palettes, mono branch
     double *d_t_thr = nullptr;     // [n-1], segment palettes with a diverging scheme only
     uint16_t *d_t_cell = nullptr;  // [kTCells + 1] (or null)
     void *d_fast = nullptr;        // tables of the wave-per-transform kernel (opaque here)
@@ -158,7 +159,10 @@ hipError_t launch_stft_q16384(const sgx_ctx *c, void *tables, const float *d_pcm
 bool mixed_supported(uint32_t W);
 hipError_t mixed_init(sgx_ctx *c, void **out);
 void mixed_destroy(void *tables);
-uint32_t mixed_fixed_plan(const void *tables);   // the length whose compile-time plan serves this context, or 0 (run-time geometry)
+uint32_t mixed_fixed_plan(const void *tables);
+bool mixed_can_fuse_render(const sgx_ctx *c, const void *tables);   // one kernel from PCM to pixels at this length, palette and row table
+hipError_t launch_render_mixed(const sgx_ctx *c, const void *tables, const float *d_pcm, uint32_t channels, uint32_t pairs, size_t first_frame,
+                               size_t n_frames, size_t total_frames, uint8_t *d_rgba);   // the length whose compile-time plan serves this context, or 0 (run-time geometry)
 hipError_t launch_stft_mixed(const sgx_ctx *c, const void *tables, const float *d_pcm, uint32_t channels, uint32_t pairs,
                              size_t first_frame, size_t n_frames, size_t total_frames, float *d_mags, bool out_f16 = false);   // out_f16: (l, r) half pairs, 4 B per bin
 bool bluestein_supported(uint32_t W);

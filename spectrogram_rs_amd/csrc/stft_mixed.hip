@@ -59,6 +59,13 @@ struct Params {
     uint32_t mono_pairs, W, P, H, C, pairs, n_stages, vec2;
     uint32_t out_f16;   // magnitudes are stored as (l, r) half pairs, 4 B per bin (the F16F16 ring of gpu_spectrogram.rs:218-226)
     float scale, inv_pad;
+    // fused pixel stage (fixed plans only): magnitudes never leave LDS
+    uint32_t render, R, n_samples, interp;
+    const RowEntry *rows;
+    const SampleEntry *samples;
+    const uint2 *pal;          // [256] {threshold to leave level i, RGBA of level i}
+    float guess_a, guess_b;    // level ~ floor(log2(power + 1e-7) a + b - 1/2), then one compare (wg::seed_within_one holds)
+    uint8_t *rgba;             // [F][pairs][R][4]
     uint32_t ra[kMaxStages], rb[kMaxStages], m[kMaxStages], tw_off[kMaxStages], q_stride[kMaxStages], blk_stride[kMaxStages];
     float inv_m[kMaxStages];
 };
@@ -320,6 +327,106 @@ __device__ __forceinline__ void split_store(const Params &p, const float2 *s, ui
     }
 }
 
+// The pixel stage on the transform's own LDS image (magnitude_in -> color_for -> put_pixel, simple_spectrogram.rs:141-161), as
+// the two-pass kernel of sgx_kernels.hip does it on magnitudes from HBM: every thread first takes its bins' magnitudes
+// into registers (all reads of the transform happen before anything is written over it), the column goes to s[0 .. M), the
+// interpolated samples behind it, then one thread per row.  A mono stream carries two frames per transform: .x / .y of a
+// bin are the two columns, each an (s, s) pixel.  256-level palettes without the diverging branch whose thresholds pass
+// the seed proof only (mixed_can_fuse_render); everything else takes the two-kernel route.
+template <uint32_t NT, uint32_t WN>
+__device__ __forceinline__ void pixel_epilogue(const Params &p, float2 *s, uint32_t pair, long long row_a, long long row_b, uint32_t tid)
+{
+    constexpr uint32_t M = WN - 1, kPer = (M + NT - 1) / NT;
+    float2 mg[kPer];
+#pragma unroll
+    for (uint32_t i = 0; i < kPer; ++i) {
+        const uint32_t j = tid + NT * i;
+        mg[i] = make_float2(0.0f, 0.0f);
+        if (j < M) {
+            const uint32_t w = p.split[j];
+            const float2 a = s[w & 0xffffu], b = s[w >> 16];
+            const float sre = a.x + b.x, sim = a.y - b.y;
+            const float dre = a.x - b.x, dim = a.y + b.y;
+            mg[i] = make_float2(sqrtf(fmaf(sre, sre, sim * sim)) * 0.5f * p.scale, sqrtf(fmaf(dre, dre, dim * dim)) * 0.5f * p.scale);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t i = 0; i < kPer; ++i) {
+        const uint32_t j = tid + NT * i;
+        if (j < M) s[j] = mg[i];
+    }
+    __syncthreads();
+    const float2 *m = s;
+    float2 *vbuf = s + M + 1;
+    const int32_t last = (int32_t)M - 1;
+    // ---- sample pass (interpolated_frequency_sample.rs:79-105)
+    for (uint32_t sidx = tid; sidx < p.n_samples; sidx += NT) {
+        const SampleEntry se = p.samples[sidx];
+        float2 v;
+        if (p.interp == SGX_INTERP_COSINE) {
+            const float2 a = m[se.i0], b = m[se.i1];
+            v.x = a.x * se.w1 + b.x * se.w2;
+            v.y = a.y * se.w1 + b.y * se.w2;
+        } else {
+            const int32_t x1 = se.i0;
+            const int32_t x0 = x1 > 0 ? x1 - 1 : 0;
+            const int32_t x2 = x1 + 1 < last ? x1 + 1 : last;
+            const int32_t x3 = x1 + 2 < last ? x1 + 2 : last;
+            const float2 y0 = m[x0], y1 = m[x1], y2 = m[x2], y3 = m[x3];
+            const float mu = se.w0, mu2 = se.w1, mu3 = se.w2;
+            {
+                const float a0 = ((y3.x - y2.x) - y0.x) + y1.x;
+                const float a1 = (y0.x - y1.x) - a0;
+                const float a2 = y2.x - y0.x;
+                v.x = ((a0 * mu3) + (a1 * mu2)) + ((a2 * mu) + y1.x);
+            }
+            {
+                const float a0 = ((y3.y - y2.y) - y0.y) + y1.y;
+                const float a1 = (y0.y - y1.y) - a0;
+                const float a2 = y2.y - y0.y;
+                v.y = ((a0 * mu3) + (a1 * mu2)) + ((a2 * mu) + y1.y);
+            }
+        }
+        vbuf[sidx] = v;
+    }
+    __syncthreads();
+    // ---- row pass (:60-75 the mean; colorscheme.rs:59-61,67-70; simple_spectrogram.rs:150-160)
+    const bool st_a = row_a >= 0 && (unsigned long long)row_a < p.n_frames;
+    const bool st_b = p.mono_pairs && row_b >= 0 && (unsigned long long)row_b < p.n_frames;
+    uint32_t *dst_a = reinterpret_cast<uint32_t *>(p.rgba) + ((size_t)(st_a ? row_a : 0) * p.pairs + pair) * p.R;
+    uint32_t *dst_b = reinterpret_cast<uint32_t *>(p.rgba) + ((size_t)(st_b ? row_b : 0) * p.pairs + pair) * p.R;
+    auto pixel = [&](float l, float r) -> uint32_t {
+        const float power = (l * l) + (r * r);
+        const float u = fmaf(__builtin_amdgcn_logf(power + 1e-7f), p.guess_a, p.guess_b);
+        int idx = (int)floorf(u - 0.5f);
+        idx = idx < 0 ? 0 : (idx > 254 ? 254 : idx);
+        const uint4 e = *reinterpret_cast<const uint4 *>(p.pal + idx);   // {thr(idx), rgba(idx), thr(idx + 1), rgba(idx + 1)}
+        return power >= __uint_as_float(e.x) ? e.w : e.y;
+    };
+    for (uint32_t py = tid; py < p.R; py += NT) {
+        const RowEntry row = p.rows[py];
+        float sl = 0.0f, sr = 0.0f;  // Complex::sum starts at zero
+        for (uint32_t i = 0; i < row.count; ++i) {
+            const float2 v = vbuf[row.first + i];
+            sl = sl + v.x;
+            sr = sr + v.y;
+        }
+        float l = sl, r = sr;
+        if (row.count > 1) {  // x / 1.0 == x: only rows that average several samples divide (:72)
+            l = sl / row.count_f;
+            r = sr / row.count_f;
+        }
+        const uint32_t y = p.R - 1 - py;  // simple_spectrogram.rs:150
+        if (p.mono_pairs) {  // mono -> (s, s): both channels carry the same magnitude
+            if (st_a) dst_a[y] = pixel(l, l);
+            if (st_b) dst_b[y] = pixel(r, r);
+        } else if (st_a) {
+            dst_a[y] = pixel(l, r);
+        }
+    }
+}
+
 __global__ void __launch_bounds__(1024) stft_mixed_kernel(Params p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -391,7 +498,8 @@ __global__ void __launch_bounds__(F::NT, F::NT == 256 ? 4 : 8) stft_mixed_fixed_
     stage<R0A, R0B>(s, p, p.tw, FixGeo<F::M0, F::P / F::R0, F::pp(F::M0), F::pp(F::P), F::W, F::PAD, F::NT, true>{}, src, tid);
     stage<R1A, R1B>(s, p, p.tw + F::TW1, FixGeo<F::M1, F::P / F::R1, F::pp(F::M1), F::pp(F::M0), F::W, F::PAD, F::NT, false>{}, src, tid);
     stage<R2A, R2B>(s, p, p.tw, FixGeo<1, F::P / F::R2, 1, F::pp(F::M1), F::W, F::PAD, F::NT, false>{}, src, tid);
-    split_store(p, s, pair, row_a, row_b, tid, F::NT);
+    if (p.render) pixel_epilogue<F::NT, F::W>(p, s, pair, row_a, row_b, tid);
+    else split_store(p, s, pair, row_a, row_b, tid, F::NT);
 }
 
 template <typename F, int R0A, int R0B, int R1A, int R1B, int R2A, int R2B, int R3A, int R3B>
@@ -408,7 +516,8 @@ __global__ void __launch_bounds__(F::NT, F::NT == 256 ? 4 : (F::NT == 512 ? 8 : 
     stage<R1A, R1B>(s, p, p.tw + F::TW1, FixGeo<F::M1, F::P / F::R1, F::pp(F::M1), F::pp(F::M0), F::W, F::PAD, F::NT, false>{}, src, tid);
     stage<R2A, R2B>(s, p, p.tw + F::TW2, FixGeo<F::M2, F::P / F::R2, F::pp(F::M2), F::pp(F::M1), F::W, F::PAD, F::NT, false>{}, src, tid);
     stage<R3A, R3B>(s, p, p.tw, FixGeo<1, F::P / F::R3, 1, F::pp(F::M2), F::W, F::PAD, F::NT, false>{}, src, tid);
-    split_store(p, s, pair, row_a, row_b, tid, F::NT);
+    if (p.render) pixel_epilogue<F::NT, F::W>(p, s, pair, row_a, row_b, tid);
+    else split_store(p, s, pair, row_a, row_b, tid, F::NT);
 }
 
 // P, the three stages (RA, RB), threads.  0.05 s at 48 / 44.1 / 32 / 16 / 8 / 88.2 kHz.  512 threads where a stage has more than
@@ -607,13 +716,54 @@ void mixed_destroy(void *tables)
     delete t;
 }
 
+bool mixed_can_fuse_render(const sgx_ctx *c, const void *tables)
+{
+    const auto *t = static_cast<const mix::MixTables *>(tables);
+    if (!t || !t->fixed || c->pal.stereo || c->pal.segments || c->pal.n != 256 || !c->d_pal_seed || !wg4096_seed_is_within_one(c)) return false;
+    // the column and its interpolated samples on the transform's LDS image; ten bins per thread in registers at most
+    unsigned nt = 0;
+#define X(Pn, A0, B0, A1, B1, A2, B2, N) if (t->fixed == Pn) nt = N;
+    MIX_FIXED_PLANS(X)
+#undef X
+#define X(Pn, A0, B0, A1, B1, A2, B2, A3, B3, N) if (t->fixed == Pn) nt = N;
+    MIX_FIXED4_PLANS(X)
+#undef X
+    return nt && (size_t)c->M + 1 + c->tab.samples.size() <= t->lds_points && c->M <= nt * 10u;
+}
+
+static hipError_t launch_mixed(const sgx_ctx *c, const void *tables, const float *d_pcm, uint32_t channels, uint32_t pairs,
+                               size_t first_frame, size_t n_frames, size_t total_frames, float *d_mags, bool out_f16, uint8_t *d_rgba);
+
 hipError_t launch_stft_mixed(const sgx_ctx *c, const void *tables, const float *d_pcm, uint32_t channels, uint32_t pairs,
                              size_t first_frame, size_t n_frames, size_t total_frames, float *d_mags, bool out_f16)
+{
+    return launch_mixed(c, tables, d_pcm, channels, pairs, first_frame, n_frames, total_frames, d_mags, out_f16, nullptr);
+}
+
+hipError_t launch_render_mixed(const sgx_ctx *c, const void *tables, const float *d_pcm, uint32_t channels, uint32_t pairs, size_t first_frame,
+                               size_t n_frames, size_t total_frames, uint8_t *d_rgba)
+{
+    return launch_mixed(c, tables, d_pcm, channels, pairs, first_frame, n_frames, total_frames, nullptr, false, d_rgba);
+}
+
+static hipError_t launch_mixed(const sgx_ctx *c, const void *tables, const float *d_pcm, uint32_t channels, uint32_t pairs,
+                               size_t first_frame, size_t n_frames, size_t total_frames, float *d_mags, bool out_f16, uint8_t *d_rgba)
 {
     using namespace mix;
     if (n_frames == 0) return hipSuccess;
     const auto *t = static_cast<const MixTables *>(tables);
     Params p{};
+    if (d_rgba) {
+        p.render = 1;
+        p.rgba = d_rgba;
+        p.R = c->R;
+        p.n_samples = (uint32_t)c->tab.samples.size();
+        p.interp = c->cfg.interp;
+        p.rows = c->d_rows;
+        p.samples = c->d_samples;
+        p.pal = c->d_pal_seed;
+        lut_seed_coefficients(c, p.guess_a, p.guess_b);
+    }
     p.pcm = d_pcm;
     p.window = c->d_window;
     p.tw = t->d_tw;
@@ -682,7 +832,8 @@ hipError_t launch_stft_mixed(const sgx_ctx *c, const void *tables, const float *
         const size_t chunk = n_frames - done < max_chunk ? n_frames - done : max_chunk;
         p.first_frame = first_frame + done;
         p.n_frames = chunk;
-        p.mags = d_mags + done * (size_t)pairs * c->M * (out_f16 ? 1 : 2);
+        p.mags = d_mags ? d_mags + done * (size_t)pairs * c->M * (out_f16 ? 1 : 2) : nullptr;
+        if (d_rgba) p.rgba = d_rgba + done * (size_t)pairs * c->R * 4;
         launch(dim3((unsigned)chunk, pairs));
         hipError_t e = attr_err != hipSuccess ? attr_err : hipGetLastError();
         if (e != hipSuccess) return e;

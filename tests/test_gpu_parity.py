@@ -482,6 +482,18 @@ def test_duration_sized_windows_of_the_usual_sample_rates(torch_cuda, mags_err, 
         assert mags_err(got, ref) <= 2.0
         assert np.array_equal(eng.stft_batch(dev, first_frame=3, max_frames=3).cpu().numpy(), got[3:6])
         assert torch.equal(eng.stft_batch_f16(dev), torch.from_numpy(got).cuda().to(torch.float16))
+        # PCM -> pixels: one kernel where the plan is compiled in and the column fits the transform's LDS image (render_path
+        # bit 0), the same bytes as the pixel stage alone on the stored magnitudes and as the oracle on them
+        eng.set_builtin_gradient("viridis")
+        px = eng.render_batch(dev).cpu().numpy()
+        assert np.array_equal(px, eng.render_mags(torch.from_numpy(got).cuda().reshape(-1, eng.M, 2)).cpu().numpy().reshape(px.shape))
+        own = oracle.render_columns(got.reshape(-1, eng.M, 2), sr, np.load(os.path.join(os.path.dirname(__file__), "golden", "gradients.npz"))["viridis"])
+        assert np.array_equal(px.reshape(own.shape), own)
+        if sr in (44100, 48000, 88200, 96000):   # more bins than samples per column: the pixel stage fits the transform's image
+            assert eng.info.render_path & 1
+        split = SpectrogramEngine(float(sr), period=0.05, stride=0.004, channels=ch, fused_render=False)
+        split.set_builtin_gradient("viridis")
+        assert not (split.info.render_path & 1) and np.array_equal(split.render_batch(dev).cpu().numpy(), px)
 
 
 @pytest.mark.parametrize("Wt,Ht,interp", [(1024, 128, "cubic"), (4096, 512, "cubic"), (4096, 512, "cosine"), (8192, 512, "cosine"), (300, 50, "cubic")])
