@@ -137,6 +137,8 @@ void wg4096_destroy(void *tables);
 hipError_t launch_stft_wg4096(const sgx_ctx *c, const void *tables, const float *d_pcm, uint32_t channels, uint32_t pairs,
                               size_t first_frame, size_t n_frames, size_t total_frames, float *d_mags);
 bool wg4096_can_fuse_render(const sgx_ctx *c, const void *tables);
+hipError_t launch_deinterleave_pairs(const sgx_ctx *c, const float *d_pcm, float *d_planes, size_t plane_floats, size_t first_sample, size_t n_samples,
+                                     uint32_t channels, uint32_t pairs);   // stft16384_q.hip
 bool wg4096_seed_is_within_one(const sgx_ctx *c);
 void lut_seed_coefficients(const sgx_ctx *c, float &a, float &b);
 namespace wg { bool seed_within_one(const std::vector<float> &thr, double guess_a, double guess_b); }   // stft4096_wg.hip: is floor(log2(p + 1e-7) a + b) within one of the threshold count for every power?   // LUT level ~ floor(log2(power + 1e-7) a + b): the seed of the threshold count

@@ -536,6 +536,18 @@ struct TablesQ {
 
 }  // namespace q16k
 
+// (l, r) pair planes of an interleaved multi-channel stream, plain order: plane p = samples [first, first + n) of channels 2p, 2p + 1
+hipError_t launch_deinterleave_pairs(const sgx_ctx *c, const float *d_pcm, float *d_planes, size_t plane_floats, size_t first_sample, size_t n_samples,
+                                     uint32_t channels, uint32_t pairs)
+{
+    int n_cu = 256;
+    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device);
+    const unsigned blocks = (unsigned)std::min<size_t>((n_samples + 255) / 256, (size_t)n_cu * 16);
+    hipLaunchKernelGGL(q16k::deinterleave_pairs_kernel, dim3(blocks), dim3(256), 0, c->stream, d_pcm, d_planes, plane_floats, first_sample, n_samples,
+                       channels, pairs);
+    return hipGetLastError();
+}
+
 bool q16384_supported(const sgx_ctx *c)
 {
     // (l, r) pairs are moved as 8-byte words: the stream must be mono or have an even channel count

@@ -67,6 +67,8 @@ struct WgTables {
     PackedSample *d_samples = nullptr;
     uint32_t n_samples = 0;
     bool fusable = false;
+    mutable float *d_planes = nullptr;   // more than two channels: (l, r) pair planes of the sample range of a call, grown on demand
+    mutable size_t planes_floats = 0;
 };
 
 __device__ __forceinline__ void lds_barrier()

@@ -93,6 +93,32 @@ def test_other_sizes_and_channel_pairs(torch_cuda, mags_err, Wt, Ht, ch):
     assert mags_err(got, ref) <= 2.0
 
 
+@pytest.mark.parametrize("ch,Ht", [(4, 256), (8, 256), (8, 100), (6, 512)])
+def test_4096_point_kernel_on_interleaved_channel_pairs(torch_cuda, mags_err, gradients, ch, Ht):
+    # more than two channels at W = 2048: the pairs are split into planes and each runs the two-channel kernel (transform,
+    # half rows and the fused pixel path alike); sub-ranges give the same bytes; an odd stream offset too
+    torch = torch_cuda
+    eng = engine(window_samples=W, hop_samples=Ht, channels=ch)
+    assert eng.info.stft_kernel == 2
+    n = W + 13 * Ht + 7
+    pcm = oracle.white_noise(n * ch, seed=ch * 100 + Ht)
+    dev = to_dev(torch, pcm)
+    got = eng.stft_batch(dev).cpu().numpy()
+    ref = oracle.stream_process(pcm, ch, W, Ht, threads=8)
+    assert got.shape == ref.shape == (14, ch // 2, M, 2)
+    assert mags_err(got, ref) <= 1.0
+    for first, cnt in ((1, 5), (13, 1), (4, 10)):
+        assert np.array_equal(eng.stft_batch(dev, first_frame=first, max_frames=cnt).cpu().numpy(), got[first:first + cnt])
+    shifted = torch.empty(dev.numel() + 1, dtype=dev.dtype, device=dev.device)
+    shifted[1:] = dev
+    assert np.array_equal(eng.stft_batch(shifted[1:]).cpu().numpy(), got)
+    assert torch.equal(eng.stft_batch_f16(dev), torch.from_numpy(got).cuda().to(torch.float16))
+    eng.set_gradient(gradients["viridis"])
+    px = eng.render_batch(dev).cpu().numpy()
+    own = oracle.render_columns(got.reshape(-1, M, 2), SR, gradients["viridis"])
+    assert px.shape == (14, ch // 2, R, 4) and np.array_equal(px.reshape(own.shape), own)
+
+
 @pytest.mark.parametrize("ch,force_generic", [(8, False), (2, False), (1, False), (8, True)])
 def test_config4_16384_point_kernel(torch_cuda, mags_err, ch, force_generic):
     # BASELINE config 4: W 8192 / P 16384, hop 512, interleaved channel pairs; tuned kernel vs generic vs oracle
