@@ -107,8 +107,9 @@ typedef struct sgx_info {
     uint32_t render_path;     /* sgx_render_batch as configured NOW (palette included): bit 0 = one fused PCM-to-pixel kernel (the
                                  4096-point kernel, or a compile-time plan of the mixed-radix kernel whose LDS image holds the column),
                                  bit 1 = its LUT index is seed + one compare pair (else seed + walk); neither = two kernels;
-                                 bit 2 = the mixed-radix transform kernel runs a compile-time plan for this length (the
-                                 0.05 s windows of the usual sample rates, 8 kHz to 192 kHz) */
+                                 bit 2 = the transform runs a compile-time plan of the composite-radix stages: stft_kernel 6 at the
+                                 0.05 s windows of the usual sample rates (8 kHz to 192 kHz) and the powers of two from 512 on;
+                                 stft_kernel 4 (chirp-z) for W = 342 .. 5461, e.g. 1102 at 22.05 kHz */
     uint64_t mags_bytes_per_frame; /* pairs * M * 2 * 4 */
     uint64_t rgba_bytes_per_frame; /* pairs * R * 4     */
 } sgx_info;

@@ -158,6 +158,7 @@ hipError_t run_stft(const sgx_ctx *c, const float *d_pcm, uint32_t channels, uin
     if (c->stft_kernel == 7 && (channels != 1 || !(c->cfg.flags & SGX_FLAG_INDEPENDENT_FRAMES)))
         return sgx::launch_stft_wg16384(c, c->d_fast_16k, d_pcm, channels, pairs, first, n, total, d_mags);
     if (c->stft_kernel == 6) return sgx::launch_stft_mixed(c, c->d_mix, d_pcm, channels, pairs, first, n, total, d_mags);
+    if (c->stft_kernel == 4 && c->d_chz) return sgx::launch_stft_chirpz(c, c->d_chz, d_pcm, channels, pairs, first, n, total, d_mags);
     if (c->stft_kernel == 4) return sgx::launch_stft_bluestein(c, c->d_blu, d_pcm, channels, pairs, first, n, total, d_mags);
     if (c->stft_kernel == 3) return sgx::launch_stft_wgp4096(c, c->d_fast_wg, d_pcm, channels, pairs, first, n, total, d_mags);
     if (c->stft_kernel == 2) return sgx::launch_stft_wg4096(c, c->d_fast_wg, d_pcm, channels, pairs, first, n, total, d_mags);
@@ -282,6 +283,10 @@ int sgx_create(const sgx_config *cfg, sgx_ctx **out_ctx)
     } else if (!pow2) {
         e = sgx::bluestein_init(c, &c->d_blu);
         if (e != hipSuccess) return bail(SGX_ERR_HIP, std::string("sgx_create: Bluestein tables: ") + hipGetErrorString(e));
+        if (!(cfg->flags & SGX_FLAG_FORCE_GENERIC) && sgx::chirpz_supported(c->W)) {   // (SGX_FLAG_FORCE_GENERIC: the radix-4 ladder, the A/B reference)
+            e = sgx::chirpz_init(c, &c->d_chz);
+            if (e != hipSuccess) return bail(SGX_ERR_HIP, std::string("sgx_create: chirp-z tables: ") + hipGetErrorString(e));
+        }
         c->stft_kernel = 4;
     } else if (!(cfg->flags & SGX_FLAG_FORCE_GENERIC) && sgx::fast4096_supported(c)) {
         e = sgx::fast4096_init(c);
@@ -313,6 +318,8 @@ void sgx_destroy(sgx_ctx *c)
     c->d_blu = nullptr;
     sgx::mixed_destroy(c->d_mix);
     c->d_mix = nullptr;
+    sgx::chirpz_destroy(c->d_chz);
+    c->d_chz = nullptr;
     sgx::wg16384_destroy(c->d_fast_16k);
     c->d_fast_16k = nullptr;
     sgx::q16384_destroy(c->d_q16k);
@@ -345,6 +352,7 @@ int sgx_query(const sgx_ctx *c, sgx_info *out)
     if ((c->stft_kernel == 2 || c->stft_kernel == 3) && !(c->cfg.flags & SGX_FLAG_NO_FUSED_RENDER) && sgx::wg4096_can_fuse_render(c, c->d_fast_wg))
         out->render_path = 1u | (sgx::wg4096_seed_is_within_one(c) ? 2u : 0u);
     if (c->stft_kernel == 6 && sgx::mixed_fixed_plan(c->d_mix)) out->render_path |= 4u;
+    if (c->stft_kernel == 4 && c->d_chz) out->render_path |= 4u;
     if (c->stft_kernel == 6 && !(c->cfg.flags & SGX_FLAG_NO_FUSED_RENDER) && sgx::mixed_can_fuse_render(c, c->d_mix)) out->render_path |= 3u;
     out->mags_bytes_per_frame = (uint64_t)c->pairs * c->M * 2 * sizeof(float);
     out->rgba_bytes_per_frame = (uint64_t)c->pairs * c->R * 4;

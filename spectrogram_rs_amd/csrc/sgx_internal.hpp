@@ -102,6 +102,7 @@ struct sgx_ctx {
     void *d_fast_wg = nullptr;     // tables of the workgroup-per-transform kernel
     void *d_blu = nullptr;         // tables of the Bluestein (non-power-of-two) kernel
     void *d_mix = nullptr;         // tables of the mixed-radix (2, 3, 5, 7-smooth lengths) kernel
+    void *d_chz = nullptr;         // chirp-z through the mixed-radix kernel's stages (or null: the radix-4 ladder of stft_bluestein.hip)
     void *d_fast_16k = nullptr;    // tables of the 16384-point kernel, first design (one 1024-thread workgroup per transform)
     void *d_q16k = nullptr;        // tables of the 16384-point kernel, four 4096-point residues (the default)
 
@@ -162,6 +163,12 @@ bool mixed_supported(uint32_t W);
 hipError_t mixed_init(sgx_ctx *c, void **out);
 void mixed_destroy(void *tables);
 uint32_t mixed_fixed_plan(const void *tables);
+// chirp-z through the composite stages of the mixed-radix kernel (stft_mixed.hip): L = 2048 .. 16384, i.e. W = 342 .. 5461
+bool chirpz_supported(uint32_t W);
+hipError_t chirpz_init(sgx_ctx *c, void **out);
+void chirpz_destroy(void *tables);
+hipError_t launch_stft_chirpz(const sgx_ctx *c, const void *tables, const float *d_pcm, uint32_t channels, uint32_t pairs,
+                              size_t first_frame, size_t n_frames, size_t total_frames, float *d_mags);
 bool mixed_can_fuse_render(const sgx_ctx *c, const void *tables);   // one kernel from PCM to pixels at this length, palette and row table
 hipError_t launch_render_mixed(const sgx_ctx *c, const void *tables, const float *d_pcm, uint32_t channels, uint32_t pairs, size_t first_frame,
                                size_t n_frames, size_t total_frames, uint8_t *d_rgba);   // the length whose compile-time plan serves this context, or 0 (run-time geometry)

@@ -66,6 +66,10 @@ struct Params {
     const uint2 *pal;          // [256] {threshold to leave level i, RGBA of level i}
     float guess_a, guess_b;    // level ~ floor(log2(power + 1e-7) a + b - 1/2), then one compare (wg::seed_within_one holds)
     uint8_t *rgba;             // [F][pairs][R][4]
+    // chirp-z through the same stages (lengths with a prime factor above 7): the transform length is a compile-time power of two,
+    // P stays 2 W, the first stage multiplies by the chirp, the split reads natural-order positions and multiplies again
+    const float2 *chirp;       // [P] exp(-i pi n^2 / P), or null
+    const float2 *bhat;        // [LDS image] FFT_L(conj chirp) / L at the padded digit-reversed positions, zero in the padding
     uint32_t ra[kMaxStages], rb[kMaxStages], m[kMaxStages], tw_off[kMaxStages], q_stride[kMaxStages], blk_stride[kMaxStages];
     float inv_m[kMaxStages];
 };
@@ -213,10 +217,11 @@ struct DynGeo {
 };
 template <uint32_t M, uint32_t COUNT, uint32_t QS, uint32_t BS, uint32_t WN, uint32_t PAD, uint32_t NT, bool FIRST>
 struct FixGeo {
+    uint32_t w_rt = 0;   // WN = 0: the number of non-zero inputs is a run-time value (chirp-z)
     __device__ __forceinline__ constexpr uint32_t m() const { return M; }
     __device__ __forceinline__ constexpr uint32_t count() const { return COUNT; }
     __device__ __forceinline__ constexpr uint32_t qs() const { return QS; }
-    __device__ __forceinline__ constexpr uint32_t W() const { return WN; }
+    __device__ __forceinline__ constexpr uint32_t W() const { return WN ? WN : w_rt; }
     __device__ __forceinline__ constexpr uint32_t nt() const { return NT; }
     __device__ __forceinline__ constexpr bool first() const { return FIRST; }
     __device__ __forceinline__ uint32_t blk_of(uint32_t b) const { return b / M; }
@@ -250,7 +255,7 @@ __device__ __forceinline__ void stage(float2 *s, const Params &p, const float2 *
                         l = src.a[nc * p.C + src.cl];
                         r = src.data_b ? src.b[nc * p.C + src.cr] : 0.0f;
                     }
-                    if (n < g.W()) x[q] = make_float2(l * w, r * w);
+                    if (n < g.W()) x[q] = p.chirp ? cmul(make_float2(l * w, r * w), p.chirp[nc]) : make_float2(l * w, r * w);
                 }
             }
         } else {
@@ -267,6 +272,35 @@ __device__ __forceinline__ void stage(float2 *s, const Params &p, const float2 *
 #pragma unroll
             for (int k = 1; k < R; ++k) at[k * qs] = cmul(x[k], twj[k - 1]);
         }
+    }
+    __syncthreads();
+}
+
+// The inverse of stage() on the same positions: x[q m + j] = sum_k (y_k conj(w_Ns^{j k})) conj(w_R^{q k}), unnormalised, through
+// the forward butterfly: IDFT(v) = conj(DFT(conj(v))).
+template <int RA, int RB, typename Geo>
+__device__ __forceinline__ void stage_inv(float2 *s, const float2 *tw, const Geo g, uint32_t tid)
+{
+    constexpr int R = RA * RB;
+    const uint32_t m = g.m(), qs = g.qs();
+    for (uint32_t b = tid; b < g.count(); b += g.nt()) {
+        const uint32_t blk = g.blk_of(b);
+        const uint32_t j = b - blk * m;
+        float2 *at = s + g.base_of(blk, j);
+        float2 x[R];
+        const float2 y0 = at[0];
+        x[0] = make_float2(y0.x, -y0.y);
+        if (m == 1 || j == 0) {
+#pragma unroll
+            for (int k = 1; k < R; ++k) { const float2 y = at[k * qs]; x[k] = make_float2(y.x, -y.y); }
+        } else {
+            const float2 *twj = tw + (size_t)j * (R - 1);
+#pragma unroll
+            for (int k = 1; k < R; ++k) { const float2 y = at[k * qs]; x[k] = cmul(make_float2(y.x, -y.y), twj[k - 1]); }
+        }
+        dft_composite<RA, RB>(x);
+#pragma unroll
+        for (int q = 0; q < R; ++q) at[q * qs] = make_float2(x[q].x, -x[q].y);
     }
     __syncthreads();
 }
@@ -305,8 +339,16 @@ __device__ __forceinline__ void split_store(const Params &p, const float2 *s, ui
     float2 *out_a = reinterpret_cast<float2 *>(p.mags) + off_a, *out_b = reinterpret_cast<float2 *>(p.mags) + off_b;
     __half2 *half_a = reinterpret_cast<__half2 *>(p.mags) + off_a, *half_b = reinterpret_cast<__half2 *>(p.mags) + off_b;
     for (uint32_t j = tid; j < M; j += nt) {
-        const uint32_t w = p.split[j];
-        const float2 a = s[w & 0xffffu], b = s[w >> 16];
+        float2 a, b;
+        if (p.chirp) {   // natural order after the inverse stages, one point of padding in 16; F[k] = c[k] y[k]
+            const uint32_t k = j + 1, kp = p.P - k;
+            a = cmul(s[k + (k >> 4)], p.chirp[k]);
+            b = cmul(s[kp + (kp >> 4)], p.chirp[kp]);
+        } else {
+            const uint32_t w = p.split[j];
+            a = s[w & 0xffffu];
+            b = s[w >> 16];
+        }
         const float sre = a.x + b.x, sim = a.y - b.y;
         const float dre = a.x - b.x, dim = a.y + b.y;
         const float left = sqrtf(fmaf(sre, sre, sim * sim)) * 0.5f * p.scale;
@@ -519,6 +561,73 @@ __global__ void __launch_bounds__(F::NT, F::NT == 256 ? 4 : (F::NT == 512 ? 8 : 
     if (p.render) pixel_epilogue<F::NT, F::W>(p, s, pair, row_a, row_b, tid);
     else split_store(p, s, pair, row_a, row_b, tid, F::NT);
 }
+
+// ---- chirp-z (Bluestein) through the same stages: F[k] = c[k] sum_{n<W} (z[n] c[n]) conj(c)[k - n], c[n] = exp(-i pi n^2 / P), as a
+// circular convolution of length L = pow2 >= P + W - 1 (stft_bluestein.hip has the derivation and the first implementation, a
+// radix-4 ladder): forward stages (the first one reads z[n] hann[n] c[n] from the stream, rows past W are zero), pointwise
+// product with B^ = FFT_L(conj chirp) / L stored at the image's own positions, the stages inverted in reverse order (natural
+// order back at position n + n / 16), split with the second chirp factor.
+template <typename F, int R0A, int R0B, int R1A, int R1B, int R2A, int R2B>
+__global__ void __launch_bounds__(F::NT, 4) chirpz3_kernel(Params p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2 *s = reinterpret_cast<float2 *>(smem_raw);
+    const uint32_t tid = threadIdx.x;
+    const uint32_t pair = blockIdx.y;
+    long long row_a, row_b;
+    Source src;
+    frame_source(p, pair, src, row_a, row_b);
+    using G0f = FixGeo<F::M0, F::P / F::R0, F::pp(F::M0), F::pp(F::P), 0, F::PAD, F::NT, true>;
+    using G0 = FixGeo<F::M0, F::P / F::R0, F::pp(F::M0), F::pp(F::P), 0, F::PAD, F::NT, false>;
+    using G1 = FixGeo<F::M1, F::P / F::R1, F::pp(F::M1), F::pp(F::M0), 0, F::PAD, F::NT, false>;
+    using G2 = FixGeo<1, F::P / F::R2, 1, F::pp(F::M1), 0, F::PAD, F::NT, false>;
+    stage<R0A, R0B>(s, p, p.tw, G0f{p.W}, src, tid);
+    stage<R1A, R1B>(s, p, p.tw + F::TW1, G1{}, src, tid);
+    stage<R2A, R2B>(s, p, p.tw, G2{}, src, tid);
+    for (uint32_t i = tid; i < F::pp(F::P); i += F::NT) s[i] = cmul(s[i], p.bhat[i]);
+    __syncthreads();
+    stage_inv<R2A, R2B>(s, p.tw, G2{}, tid);
+    stage_inv<R1A, R1B>(s, p.tw + F::TW1, G1{}, tid);
+    stage_inv<R0A, R0B>(s, p.tw, G0{}, tid);
+    split_store(p, s, pair, row_a, row_b, tid, F::NT);
+}
+
+template <typename F, int R0A, int R0B, int R1A, int R1B, int R2A, int R2B, int R3A, int R3B>
+__global__ void __launch_bounds__(F::NT, 4) chirpz4_kernel(Params p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2 *s = reinterpret_cast<float2 *>(smem_raw);
+    const uint32_t tid = threadIdx.x;
+    const uint32_t pair = blockIdx.y;
+    long long row_a, row_b;
+    Source src;
+    frame_source(p, pair, src, row_a, row_b);
+    using G0f = FixGeo<F::M0, F::P / F::R0, F::pp(F::M0), F::pp(F::P), 0, F::PAD, F::NT, true>;
+    using G0 = FixGeo<F::M0, F::P / F::R0, F::pp(F::M0), F::pp(F::P), 0, F::PAD, F::NT, false>;
+    using G1 = FixGeo<F::M1, F::P / F::R1, F::pp(F::M1), F::pp(F::M0), 0, F::PAD, F::NT, false>;
+    using G2 = FixGeo<F::M2, F::P / F::R2, F::pp(F::M2), F::pp(F::M1), 0, F::PAD, F::NT, false>;
+    using G3 = FixGeo<1, F::P / F::R3, 1, F::pp(F::M2), 0, F::PAD, F::NT, false>;
+    stage<R0A, R0B>(s, p, p.tw, G0f{p.W}, src, tid);
+    stage<R1A, R1B>(s, p, p.tw + F::TW1, G1{}, src, tid);
+    stage<R2A, R2B>(s, p, p.tw + F::TW2, G2{}, src, tid);
+    stage<R3A, R3B>(s, p, p.tw, G3{}, src, tid);
+    for (uint32_t i = tid; i < F::pp(F::P); i += F::NT) s[i] = cmul(s[i], p.bhat[i]);
+    __syncthreads();
+    stage_inv<R3A, R3B>(s, p.tw, G3{}, tid);
+    stage_inv<R2A, R2B>(s, p.tw + F::TW2, G2{}, tid);
+    stage_inv<R1A, R1B>(s, p.tw + F::TW1, G1{}, tid);
+    stage_inv<R0A, R0B>(s, p.tw, G0{}, tid);
+    split_store(p, s, pair, row_a, row_b, tid, F::NT);
+}
+
+// L, the stages, threads (W 342 .. 5461; shorter windows keep the radix-4 ladder of stft_bluestein.hip)
+#define CHIRP_PLANS3(X) X(2048, 4, 2, 4, 4, 4, 4, 256) X(4096, 4, 4, 4, 4, 4, 4, 256)
+#define CHIRP_PLANS4(X) X(8192, 4, 1, 4, 2, 4, 4, 4, 4, 512) X(16384, 4, 1, 4, 4, 4, 4, 4, 4, 1024)
+
+struct ChirpTables {
+    float2 *d_chirp = nullptr, *d_bhat = nullptr, *d_tw = nullptr;
+    uint32_t L = 0, lds_points = 0;
+};
 
 // P, the three stages (RA, RB), threads.  0.05 s at 48 / 44.1 / 32 / 16 / 8 / 88.2 kHz.  512 threads where a stage has more than
 // 256 butterflies (62-64 registers: eight waves per SIMD; same-device A/B at 4800 points: 256 threads 1.41 ms per 100 000
@@ -836,6 +945,202 @@ static hipError_t launch_mixed(const sgx_ctx *c, const void *tables, const float
         if (d_rgba) p.rgba = d_rgba + done * (size_t)pairs * c->R * 4;
         launch(dim3((unsigned)chunk, pairs));
         hipError_t e = attr_err != hipSuccess ? attr_err : hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+// ---- chirp-z through the composite stages (see chirpz3_kernel) --------------------------------------------------------
+
+namespace mix {
+
+// host float64 radix-2 FFT (table set-up only)
+static void fft_host(std::vector<double> &re, std::vector<double> &im)
+{
+    const size_t n = re.size();
+    for (size_t i = 1, j = 0; i < n; ++i) {
+        size_t bit = n >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) { std::swap(re[i], re[j]); std::swap(im[i], im[j]); }
+    }
+    for (size_t len = 2; len <= n; len <<= 1) {
+        const double ang = -2.0 * M_PI / (double)len;
+        for (size_t i = 0; i < n; i += len)
+            for (size_t k = 0; k < len / 2; ++k) {
+                const double wr = cos(ang * (double)k), wi = sin(ang * (double)k);
+                const size_t a = i + k, b = i + k + len / 2;
+                const double tr = re[b] * wr - im[b] * wi, ti = re[b] * wi + im[b] * wr;
+                re[b] = re[a] - tr; im[b] = im[a] - ti;
+                re[a] += tr; im[a] += ti;
+            }
+    }
+}
+
+static uint32_t chirp_length(uint32_t W)
+{
+    uint32_t L = 1;
+    while (L < 3 * W - 1) L <<= 1;   // P + W - 1
+    return L;
+}
+
+}  // namespace mix
+
+bool chirpz_supported(uint32_t W)
+{
+    if (W < 4 || 3ull * W - 1 > 16384) return false;
+    const uint32_t L = mix::chirp_length(W);
+    return L == 2048 || L == 4096 || L == 8192 || L == 16384;
+}
+
+hipError_t chirpz_init(sgx_ctx *c, void **out)
+{
+    using namespace mix;
+    const uint32_t W = c->W, P = c->P, L = chirp_length(W);
+    std::vector<uint32_t> radix;
+#define X(Ln, A0, B0, A1, B1, A2, B2, N) if (L == Ln) radix = {A0 * B0, A1 * B1, A2 * B2};
+    CHIRP_PLANS3(X)
+#undef X
+#define X(Ln, A0, B0, A1, B1, A2, B2, A3, B3, N) if (L == Ln) radix = {A0 * B0, A1 * B1, A2 * B2, A3 * B3};
+    CHIRP_PLANS4(X)
+#undef X
+    if (radix.empty()) return hipErrorInvalidValue;
+    auto *t = new ChirpTables();
+    t->L = L;
+    t->lds_points = L + L / 16;
+    auto padpos = [](uint32_t i) { return i + i / 16; };
+    // per-stage twiddle rows [m][R - 1] and the digit reversal, exactly as mixed_init lays them out for the dynamic plan
+    std::vector<float2> tw;
+    std::vector<uint32_t> ms(radix.size());
+    uint32_t ns = L;
+    for (size_t i = 0; i < radix.size(); ++i) {
+        ms[i] = ns / radix[i];
+        if (ms[i] > 1)
+            for (uint32_t j = 0; j < ms[i]; ++j)
+                for (uint32_t k = 1; k < radix[i]; ++k) {
+                    const unsigned long long e = ((unsigned long long)j * k) % ns;
+                    const double ang = -2.0 * M_PI * (double)e / (double)ns;
+                    double cs = cos(ang), sn = sin(ang);
+                    if (e == 0) { cs = 1.0; sn = 0.0; }
+                    if (4 * e == ns) { cs = 0.0; sn = -1.0; }
+                    if (2 * e == ns) { cs = -1.0; sn = 0.0; }
+                    if (4 * e == 3ull * ns) { cs = 0.0; sn = 1.0; }
+                    tw.push_back(make_float2((float)cs, (float)sn));
+                }
+        ns = ms[i];
+    }
+    std::vector<float2> chirp(P), bhat(t->lds_points, make_float2(0.0f, 0.0f));
+    std::vector<double> cr(P), ci(P);
+    for (uint32_t n = 0; n < P; ++n) {
+        const unsigned long long q = ((unsigned long long)n * n) % (2ull * P);  // n^2 mod 2P: exact
+        const double ang = -M_PI * (double)q / (double)P;
+        cr[n] = cos(ang); ci[n] = sin(ang);
+        chirp[n] = make_float2((float)cr[n], (float)ci[n]);
+    }
+    // b[m] = conj(c[|m|]) for m in [-(W-1), P-1], wrapped modulo L
+    std::vector<double> br(L, 0.0), bi(L, 0.0);
+    for (uint32_t m = 0; m < P; ++m) { br[m] = cr[m]; bi[m] = -ci[m]; }
+    for (uint32_t m = 1; m < W; ++m) { br[L - m] = cr[m]; bi[L - m] = -ci[m]; }
+    fft_host(br, bi);
+    for (uint32_t K = 0; K < L; ++K) {   // bin K = k1 + r1 (k2 + r2 (...)) ends at k1 m1 + k2 m2 + ...
+        uint32_t k = K, at = 0;
+        for (size_t i = 0; i < radix.size(); ++i) {
+            at += (k % radix[i]) * ms[i];
+            k /= radix[i];
+        }
+        bhat[padpos(at)] = make_float2((float)(br[K] / (double)L), (float)(bi[K] / (double)L));
+    }
+    auto up = [](float2 **dst, const std::vector<float2> &v) {
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(dst), v.size() * sizeof(float2));
+        if (e == hipSuccess) e = hipMemcpy(*dst, v.data(), v.size() * sizeof(float2), hipMemcpyHostToDevice);
+        return e;
+    };
+    hipError_t e = up(&t->d_chirp, chirp);
+    if (e == hipSuccess) e = up(&t->d_bhat, bhat);
+    if (e == hipSuccess) e = up(&t->d_tw, tw);
+    if (e != hipSuccess) {
+        chirpz_destroy(t);
+        return e;
+    }
+    *out = t;
+    return hipSuccess;
+}
+
+void chirpz_destroy(void *tables)
+{
+    auto *t = static_cast<mix::ChirpTables *>(tables);
+    if (!t) return;
+    if (t->d_chirp) (void)hipFree(t->d_chirp);
+    if (t->d_bhat) (void)hipFree(t->d_bhat);
+    if (t->d_tw) (void)hipFree(t->d_tw);
+    delete t;
+}
+
+hipError_t launch_stft_chirpz(const sgx_ctx *c, const void *tables, const float *d_pcm, uint32_t channels, uint32_t pairs,
+                              size_t first_frame, size_t n_frames, size_t total_frames, float *d_mags)
+{
+    using namespace mix;
+    if (n_frames == 0) return hipSuccess;
+    const auto *t = static_cast<const ChirpTables *>(tables);
+    Params p{};
+    p.pcm = d_pcm;
+    p.window = c->d_window;
+    p.tw = t->d_tw;
+    p.chirp = t->d_chirp;
+    p.bhat = t->d_bhat;
+    p.W = c->W;
+    p.P = c->P;
+    p.H = c->H;
+    p.C = channels;
+    p.pairs = pairs;
+    p.scale = 2.0f / (float)c->W;
+    p.first_frame = first_frame;
+    p.n_frames = n_frames;
+    p.total_frames = total_frames;
+    p.vec2 = (channels >= 2 && channels % 2 == 0 && reinterpret_cast<uintptr_t>(d_pcm) % 8 == 0) ? 1u : 0u;
+    const size_t lds = (size_t)t->lds_points * sizeof(float2);
+    hipError_t attr_err = hipSuccess;
+    auto go = [&](auto kernel, unsigned nt, dim3 grid) {
+        if (lds > 64 * 1024) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) { attr_err = e; return; }
+        }
+        hipLaunchKernelGGL(kernel, grid, dim3(nt), lds, c->stream, p);
+    };
+    auto launch = [&](dim3 grid) {
+        switch (t->L) {
+#define X(Ln, A0, B0, A1, B1, A2, B2, N) \
+    case Ln: go(chirpz3_kernel<Fixed3<Ln, A0, B0, A1, B1, A2, B2, N>, A0, B0, A1, B1, A2, B2>, N, grid); break;
+            CHIRP_PLANS3(X)
+#undef X
+#define X(Ln, A0, B0, A1, B1, A2, B2, A3, B3, N) \
+    case Ln: go(chirpz4_kernel<Fixed4<Ln, A0, B0, A1, B1, A2, B2, A3, B3, N>, A0, B0, A1, B1, A2, B2, A3, B3>, N, grid); break;
+            CHIRP_PLANS4(X)
+#undef X
+        default: attr_err = hipErrorInvalidValue; break;
+        }
+    };
+    const size_t max_chunk = 1u << 30;
+    if (channels == 1 && !(c->cfg.flags & SGX_FLAG_INDEPENDENT_FRAMES)) {
+        p.mono_pairs = 1;
+        p.mags = d_mags;
+        const unsigned long long q0 = first_frame / 2, q1 = (first_frame + n_frames + 1) / 2;
+        for (unsigned long long q = q0; q < q1; q += max_chunk) {
+            const unsigned long long chunk = q1 - q < max_chunk ? q1 - q : max_chunk;
+            p.pair_base = q;
+            launch(dim3((unsigned)chunk, 1));
+            const hipError_t e = attr_err != hipSuccess ? attr_err : hipGetLastError();
+            if (e != hipSuccess) return e;
+        }
+        return hipSuccess;
+    }
+    for (size_t done = 0; done < n_frames; done += max_chunk) {
+        const size_t chunk = n_frames - done < max_chunk ? n_frames - done : max_chunk;
+        p.first_frame = first_frame + done;
+        p.n_frames = chunk;
+        p.mags = d_mags + done * (size_t)pairs * c->M * 2;
+        launch(dim3((unsigned)chunk, pairs));
+        const hipError_t e = attr_err != hipSuccess ? attr_err : hipGetLastError();
         if (e != hipSuccess) return e;
     }
     return hipSuccess;

@@ -487,6 +487,29 @@ def test_render_stereo_scheme_bit_exact(torch_cuda, gradients):
     assert got[..., 3].min() == 0 and got[..., 3].max() == 255
 
 
+@pytest.mark.parametrize("Wt,Ht,ch", [(1102, 100, 2), (551, 43, 2), (1102, 43, 1), (1852, 170, 2), (3001, 300, 1), (5461, 500, 2), (341, 30, 2), (345, 30, 4)])
+def test_chirp_z_through_the_composite_stages(torch_cuda, mags_err, Wt, Ht, ch):
+    # lengths with a prime factor above 7 (1102 = 0.05 s at 22.05 kHz, 551 at 11.025 kHz): from W = 342 on the convolution's
+    # power-of-two transforms run the composite-radix stages and their inverses (render_path bit 2); SGX_FLAG_FORCE_GENERIC
+    # keeps the radix-4 ladder: both against the float64 truth, sub-ranges the same bytes, mono pairs by global index
+    torch = torch_cuda
+    eng = engine(window_samples=Wt, hop_samples=Ht, channels=ch)
+    lad = engine(window_samples=Wt, hop_samples=Ht, channels=ch, force_generic=True)
+    assert eng.info.stft_kernel == lad.info.stft_kernel == 4
+    assert bool(eng.info.render_path & 4) == (Wt >= 342) and not (lad.info.render_path & 4)
+    n = Wt + 8 * Ht + 3
+    pcm = oracle.white_noise(n * ch, seed=Wt)
+    dev = to_dev(torch, pcm)
+    got, old = eng.stft_batch(dev).cpu().numpy(), lad.stft_batch(dev).cpu().numpy()
+    lr = pcm.reshape(-1, ch)
+    for t in (0, 5, 8):
+        truth = oracle.np_truth_frame(np.stack([lr[t * Ht:t * Ht + Wt, 0], lr[t * Ht:t * Ht + Wt, min(1, ch - 1)]], 1), Wt)
+        assert mags_err(got[t, 0], truth) <= 1.0 and mags_err(old[t, 0], truth) <= 1.0
+    assert got.shape == old.shape == (9, max(ch // 2, 1), Wt - 1, 2)
+    for first, cnt in ((1, 4), (8, 1), (3, 5)):
+        assert np.array_equal(eng.stft_batch(dev, first_frame=first, max_frames=cnt).cpu().numpy(), got[first:first + cnt])
+
+
 @pytest.mark.parametrize("sr,Wexp,fixed", [(8000, 400, True), (16000, 800, True), (32000, 1600, True), (44100, 2205, True), (48000, 2400, True),
                                            (88200, 4410, True), (96000, 4800, True), (176400, 8820, True), (192000, 9600, True),
                                            (24000, 1200, False), (64000, 3200, False)])
