@@ -415,10 +415,23 @@ def config3_leg(args, torch, eng, pcm, F):
     achieved = Fp * ALGO_BYTES_PIXEL / (mean * 1e-3) / 1e9
     pipes = load_profile_json("pixel_pipes")
     traffic = load_profile_json("hbm_traffic")
+    # the interpolator the reference actually executes (interpolated_frequency_sample.rs:46-48 calls the cubic one; the cosine one
+    # BASELINE names is dead code there): same leg, same kernel, cubic taps
+    from spectrogram_rs_amd import SpectrogramEngine
+    cubic = None
+    try:
+        eng3 = SpectrogramEngine(48000.0, window_samples=W, hop_samples=H, channels=1, device=eng.device.index, interp=0, gradient="viridis")
+        ms3 = event_times(torch, lambda: eng3.render_batch(pcm, max_frames=Fp, out=rgba), reps=5, warm=2)
+        cubic = {"frames_per_s": Fp / (sum(ms3) / len(ms3) * 1e-3), "launch_ms": stats_ms(ms3),
+                 "what": "the same leg with the cubic interpolator, which is what the reference runs"}
+        eng3.close()
+    except Exception as e:  # noqa: BLE001 -- an extra, never fatal
+        cubic = {"error": f"{type(e).__name__}: {e}"}
     return {
         "workload": f"configs[2]: {Fp} frames of the same stream -> 1024 log rows (cosine interpolation), Viridis RGBA, fused PCM-to-pixel kernel",
         "frames_per_s": Fp / (mean * 1e-3),
         "launch_ms": stats_ms(ms),
+        "cubic": cubic,
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "bytes_per_frame": ALGO_BYTES_PIXEL, "frames_per_launch": Fp,
