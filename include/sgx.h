@@ -109,7 +109,7 @@ typedef struct sgx_info {
                                  bit 1 = its LUT index is seed + one compare pair (else seed + walk); neither = two kernels;
                                  bit 2 = the transform runs a compile-time plan of the composite-radix stages: stft_kernel 6 at the
                                  0.05 s windows of the usual sample rates (8 kHz to 192 kHz) and the powers of two from 512 on;
-                                 stft_kernel 4 (chirp-z) for W = 342 .. 5461, e.g. 1102 at 22.05 kHz */
+                                 stft_kernel 4 (chirp-z) for W = 86 .. 5461, e.g. 1102 at 22.05 kHz */
     uint64_t mags_bytes_per_frame; /* pairs * M * 2 * 4 */
     uint64_t rgba_bytes_per_frame; /* pairs * R * 4     */
 } sgx_info;

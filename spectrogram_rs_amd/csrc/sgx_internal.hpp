@@ -163,7 +163,7 @@ bool mixed_supported(uint32_t W);
 hipError_t mixed_init(sgx_ctx *c, void **out);
 void mixed_destroy(void *tables);
 uint32_t mixed_fixed_plan(const void *tables);
-// chirp-z through the composite stages of the mixed-radix kernel (stft_mixed.hip): L = 2048 .. 16384, i.e. W = 342 .. 5461
+// chirp-z through the composite stages of the mixed-radix kernel (stft_mixed.hip): L = 512 .. 16384, i.e. W = 86 .. 5461
 bool chirpz_supported(uint32_t W);
 hipError_t chirpz_init(sgx_ctx *c, void **out);
 void chirpz_destroy(void *tables);

@@ -568,7 +568,7 @@ __global__ void __launch_bounds__(F::NT, F::NT == 256 ? 4 : (F::NT == 512 ? 8 : 
 // product with B^ = FFT_L(conj chirp) / L stored at the image's own positions, the stages inverted in reverse order (natural
 // order back at position n + n / 16), split with the second chirp factor.
 template <typename F, int R0A, int R0B, int R1A, int R1B, int R2A, int R2B>
-__global__ void __launch_bounds__(F::NT, 4) chirpz3_kernel(Params p)
+__global__ void __launch_bounds__(F::NT, F::NT >= 256 ? 4 : 2) chirpz3_kernel(Params p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float2 *s = reinterpret_cast<float2 *>(smem_raw);
@@ -620,8 +620,8 @@ __global__ void __launch_bounds__(F::NT, 4) chirpz4_kernel(Params p)
     split_store(p, s, pair, row_a, row_b, tid, F::NT);
 }
 
-// L, the stages, threads (W 342 .. 5461; shorter windows keep the radix-4 ladder of stft_bluestein.hip)
-#define CHIRP_PLANS3(X) X(2048, 4, 2, 4, 4, 4, 4, 256) X(4096, 4, 4, 4, 4, 4, 4, 256)
+// L, the stages, threads (W 86 .. 5461; shorter windows keep the radix-4 ladder of stft_bluestein.hip)
+#define CHIRP_PLANS3(X) X(512, 4, 1, 4, 2, 4, 4, 128) X(1024, 4, 1, 4, 4, 4, 4, 256) X(2048, 4, 2, 4, 4, 4, 4, 256) X(4096, 4, 4, 4, 4, 4, 4, 256)
 #define CHIRP_PLANS4(X) X(8192, 4, 1, 4, 2, 4, 4, 4, 4, 512) X(16384, 4, 1, 4, 4, 4, 4, 4, 4, 1024)
 
 struct ChirpTables {
@@ -990,7 +990,7 @@ bool chirpz_supported(uint32_t W)
 {
     if (W < 4 || 3ull * W - 1 > 16384) return false;
     const uint32_t L = mix::chirp_length(W);
-    return L == 2048 || L == 4096 || L == 8192 || L == 16384;
+    return L == 512 || L == 1024 || L == 2048 || L == 4096 || L == 8192 || L == 16384;
 }
 
 hipError_t chirpz_init(sgx_ctx *c, void **out)

@@ -487,16 +487,16 @@ def test_render_stereo_scheme_bit_exact(torch_cuda, gradients):
     assert got[..., 3].min() == 0 and got[..., 3].max() == 255
 
 
-@pytest.mark.parametrize("Wt,Ht,ch", [(1102, 100, 2), (551, 43, 2), (1102, 43, 1), (1852, 170, 2), (3001, 300, 1), (5461, 500, 2), (341, 30, 2), (345, 30, 4)])
+@pytest.mark.parametrize("Wt,Ht,ch", [(1102, 100, 2), (551, 43, 2), (1102, 43, 1), (1852, 170, 2), (3001, 300, 1), (5461, 500, 2), (341, 30, 2), (345, 30, 4), (86, 11, 2), (171, 20, 1), (85, 10, 2)])
 def test_chirp_z_through_the_composite_stages(torch_cuda, mags_err, Wt, Ht, ch):
-    # lengths with a prime factor above 7 (1102 = 0.05 s at 22.05 kHz, 551 at 11.025 kHz): from W = 342 on the convolution's
+    # lengths with a prime factor above 7 (1102 = 0.05 s at 22.05 kHz, 551 at 11.025 kHz): from W = 86 on the convolution's
     # power-of-two transforms run the composite-radix stages and their inverses (render_path bit 2); SGX_FLAG_FORCE_GENERIC
     # keeps the radix-4 ladder: both against the float64 truth, sub-ranges the same bytes, mono pairs by global index
     torch = torch_cuda
     eng = engine(window_samples=Wt, hop_samples=Ht, channels=ch)
     lad = engine(window_samples=Wt, hop_samples=Ht, channels=ch, force_generic=True)
     assert eng.info.stft_kernel == lad.info.stft_kernel == 4
-    assert bool(eng.info.render_path & 4) == (Wt >= 342) and not (lad.info.render_path & 4)
+    assert bool(eng.info.render_path & 4) == (Wt >= 86) and not (lad.info.render_path & 4)
     n = Wt + 8 * Ht + 3
     pcm = oracle.white_noise(n * ch, seed=Wt)
     dev = to_dev(torch, pcm)
