@@ -83,3 +83,33 @@ def test_random_configuration(seed, mags_err, gradients):
                                      stereo=c["diverging"])
         assert np.array_equal(cols[pick], want), c
         assert np.array_equal(eng.render_batch(dev).cpu().numpy().reshape(cols.shape), cols), c
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_random_hops_and_channels_at_the_compiled_plans(seed, mags_err):
+    # the lengths with compile-time plans (0.05 s at the usual rates, powers of two, two chirp-z lengths and two smooth
+    # lengths on the run-time geometry for contrast): random hops (also beyond the window), 1 - 6 channels, ragged tails,
+    # row counts and both interpolators; transform against the oracle, sub-range and half-row bytes, and the one-kernel
+    # pixel path against the pixel stage alone on the stored magnitudes
+    import torch
+    from spectrogram_rs_amd import SpectrogramEngine
+    rng = np.random.default_rng(7000 + seed)
+    W = int(rng.choice([400, 800, 1600, 2205, 2400, 4410, 4800, 8820, 9600, 512, 1024, 4096, 2048, 8192, 1102, 551, 406, 1218]))
+    H = int(rng.integers(1, W + W // 3))
+    ch = int(rng.choice([1, 2, 2, 4, 6]))
+    frames = int(rng.integers(1, 12))
+    n = (frames - 1) * H + W + int(rng.integers(0, H))
+    eng = SpectrogramEngine(48000.0, window_samples=W, hop_samples=H, channels=ch, rows=int(rng.integers(100, 1300)), gradient="viridis",
+                            interp=int(rng.integers(0, 2)))
+    pcm = (oracle.white_noise(n * ch, seed=seed) * np.float32(10.0 ** rng.uniform(-3, 0))).astype(np.float32)
+    dev = torch.from_numpy(pcm).cuda()
+    got = eng.stft_batch(dev).cpu().numpy()
+    ref = oracle.stream_process(pcm, ch, W, H, threads=8)
+    assert got.shape == ref.shape and mags_err(got, ref) <= 2.0
+    first = int(rng.integers(0, frames))
+    cnt = int(rng.integers(1, frames - first + 1))
+    assert np.array_equal(eng.stft_batch(dev, first_frame=first, max_frames=cnt).cpu().numpy(), got[first:first + cnt])
+    assert torch.equal(eng.stft_batch_f16(dev), torch.from_numpy(got).cuda().to(torch.float16))
+    px = eng.render_batch(dev).cpu().numpy()
+    own = eng.render_mags(torch.from_numpy(got).cuda().reshape(-1, eng.M, 2)).cpu().numpy()
+    assert np.array_equal(px.reshape(own.shape), own)
