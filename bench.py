@@ -587,6 +587,12 @@ def cpu_baseline_leg(args, eng, pcm):
                   f"{cdt * cores:.1f} thread-seconds",
         "parity_on_sample": ok,
     }
+    # the same restatement on ONE thread (a short prefix of the sample: ~2 s)
+    n1 = min(Fc, 8192)
+    host = oracle.white_noise((n1 - 1) * H + W)
+    c0 = time.perf_counter()
+    oracle.stream_process(host, 1, W, H, threads=1)
+    cpu["single_thread"] = {"value": n1 / (time.perf_counter() - c0), "unit": "frames/s", "frames": n1}
     # a second CPU figure for orientation: the FFT call alone through an optimised library FFT (scipy's pocketfft,
     # complex64, all host threads) -- the nearest thing to the reference's FFTW call that this image holds
     try:
