@@ -162,27 +162,27 @@ __device__ __forceinline__ void dft_prime(float2 *x)
 template <int RA, int RB>
 __device__ __forceinline__ void dft_composite(float2 (&x)[RA * RB])
 {
-    if (RB == 1) {
+    if constexpr (RB == 1) {
         dft_prime<RA>(x);
-        return;
-    }
-    constexpr int R = RA * RB;
-    float2 t[RB][RA];
+    } else {
+        constexpr int R = RA * RB;
+        float2 t[RB][RA];
 #pragma unroll
-    for (int qb = 0; qb < RB; ++qb) {
+        for (int qb = 0; qb < RB; ++qb) {
 #pragma unroll
-        for (int qa = 0; qa < RA; ++qa) t[qb][qa] = x[RB * qa + qb];
-        dft_prime<RA>(t[qb]);
-    }
+            for (int qa = 0; qa < RA; ++qa) t[qb][qa] = x[RB * qa + qb];
+            dft_prime<RA>(t[qb]);
+        }
 #pragma unroll
-    for (int ka = 0; ka < RA; ++ka) {
-        float2 c[RB];
-        c[0] = t[0][ka];
+        for (int ka = 0; ka < RA; ++ka) {
+            float2 c[RB];
+            c[0] = t[0][ka];
 #pragma unroll
-        for (int qb = 1; qb < RB; ++qb) c[qb] = ka == 0 ? t[qb][0] : cmul(t[qb][ka], cw<R>((qb * ka) % R));
-        dft_prime<RB>(c);
+            for (int qb = 1; qb < RB; ++qb) c[qb] = ka == 0 ? t[qb][0] : cmul(t[qb][ka], cw<R>((qb * ka) % R));
+            dft_prime<RB>(c);
 #pragma unroll
-        for (int kb = 0; kb < RB; ++kb) x[ka + RA * kb] = c[kb];
+            for (int kb = 0; kb < RB; ++kb) x[ka + RA * kb] = c[kb];
+        }
     }
 }
 
