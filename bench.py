@@ -46,7 +46,11 @@ ALGO_BYTES_STFT = H * 1 * 4 + M * 2 * 4  # 17 400 B / frame: each input sample o
 ALGO_BYTES_PIXEL = H * 1 * 4 + R * 4     # 5 120 B / frame
 W4, H4, C4 = 8192, 512, 8
 ALGO_BYTES_CFG4 = H4 * C4 * 4 + (C4 // 2) * (W4 - 1) * 8  # 278 496 B / hop position
-PROFILE_ROUND = "r02"
+PROFILE_ROUND = "r03"
+W_APP, H_APP = 2400, 93     # the application's own operating point: 48 kHz x 0.05 s (gpu_spectrogram.rs:323), hop (2/1024) s (simple_spectrogram.rs:102)
+ALGO_BYTES_STEREO = H * 2 * 4 + M * 2 * 4                     # 18 424 B / frame: an (l, r) stream, what the reference feeds
+ALGO_BYTES_APP = H_APP * 2 * 4 + (W_APP - 1) * 2 * 4          # 19 936 B / frame
+ALGO_BYTES_APP_PIXEL = H_APP * 2 * 4 + R * 4                  # 4 840 B / frame
 KERNEL_NAMES = {
     0: ("generic power-of-two (workgroup per frame, LDS radix-4)", "sgx::stft_generic_kernel"),
     1: ("stft4096 wave-per-transform", "sgx::stft4096_kernel<6, true>"),
@@ -54,7 +58,8 @@ KERNEL_NAMES = {
         "sgx::wg::stft4096_wg_kernel<true, 0, false, false>"),
     3: ("stft4096 workgroup-per-transform (256 threads x 16 points, radix-16 x3, mono frame pairs), packed (re, im) codelets",
         "sgx::wgp::stft4096_wgp_kernel<true, 0, false, false>"),
-    5: ("stft16384 as four 4096-point residues (512 threads = 256 lane pairs, DPP decimation)", "sgx::q16k::stft16384_q_kernel<false>"),
+    5: ("stft16384 as four 4096-point residues (512 threads = 256 lane pairs, DPP decimation)", "sgx::q16k::stft16384_q_kernel<false, true>"),
+    6: ("mixed radix at the window's own length (compile-time plan)", "sgx::mix::stft_mixed_fixed_kernel"),
     7: ("stft16384 workgroup-per-transform (1024 threads, whole transform in LDS)", "sgx::wg16k::stft16384_wg_kernel<false>"),
 }
 
@@ -68,6 +73,8 @@ def parse(argv=None):
     ap.add_argument("--sustain-s", type=float, default=3.0, help="seconds of back-to-back steps before the timed region (0 = skip)")
     ap.add_argument("--pixel-frames", type=int, default=1_000_000, help="N = 1: frames of the config-3 leg (0 = skip)")
     ap.add_argument("--config4-hops", type=int, default=20_000, help="N = 1: hop positions of the config-4 leg (0 = skip)")
+    ap.add_argument("--stereo-frames", type=int, default=1_000_000, help="N = 1: frames of the stereo 4096-point leg (0 = skip)")
+    ap.add_argument("--app-frames", type=int, default=262_144, help="N = 1: frames of the leg at the application's operating point, W 2400 / hop 93 stereo (0 = skip)")
     ap.add_argument("--config5-frames", type=int, default=100_000_000, help="N > 1: total frames of the config-5 leg (0 = skip)")
     ap.add_argument("--config5-chunk", type=int, default=65_536, help="columns per rank per gather round")
     ap.add_argument("--leg-timeout", type=float, default=600.0, help="seconds after which a stalled collective leg is given up (exit 3)")
@@ -124,7 +131,20 @@ def host_info():
     except OSError:
         pass
     aff = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None
-    return {"nproc": os.cpu_count(), "affinity": aff, "cpu_model": model}
+    quota = None   # a cgroup CPU quota (cpu.max "<quota> <period>" / cfs_quota_us): CPUs' worth of time this container may use
+    for path, v2 in (("/sys/fs/cgroup/cpu.max", True), ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", False)):
+        try:
+            with open(path) as f:
+                txt = f.read().split()
+            if v2 and txt and txt[0] != "max":
+                quota = float(txt[0]) / float(txt[1])
+            elif not v2 and txt and int(txt[0]) > 0:
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                    quota = int(txt[0]) / float(f.read().split()[0])
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return {"nproc": os.cpu_count(), "affinity": aff, "cgroup_cpu_quota": quota, "cpu_model": model}
 
 
 def load_profile_json(name):
@@ -356,6 +376,13 @@ def main_rank(args):
                 extra["config3"] = config3_leg(args, torch, eng, pcm, F)
             if args.config4_hops > 0:
                 extra["config4"] = config4_leg(args, torch, local_rank)
+            del pcm
+            torch.cuda.empty_cache()
+            pcm = None
+            if args.stereo_frames > 0:
+                extra["stereo4096"] = stereo_leg(args, torch, local_rank)
+            if args.app_frames > 0:
+                extra["app_point"] = app_point_leg(args, torch, local_rank)
         elif args.config5_frames > 0:
             extra["config5"] = config5_leg(args, torch, dist, eng, rank, world, backend, barrier, max_over_ranks,
                                            frame_range, stream_columns)
@@ -368,6 +395,8 @@ def main_rank(args):
 
     # ---- CPU baseline: the oracle on this host's cores (rank 0, N = 1 only) ------------------------
     if rank == 0 and world == 1 and args.cpu_frames > 0:
+        if pcm is None:
+            pcm = eng.white_noise(W + 63 * H)     # the parity check of the leg reads the first 64 frames
         extra["cpu_baseline"] = cpu_baseline_leg(args, eng, pcm)
     if rank == 0:
         print(json.dumps(build_line(extra)), flush=True)
@@ -413,6 +442,7 @@ def config3_leg(args, torch, eng, pcm, F):
     ms = event_times(torch, lambda: eng.render_batch(pcm, max_frames=Fp, out=rgba), reps=5, warm=2)
     mean = sum(ms) / len(ms)
     achieved = Fp * ALGO_BYTES_PIXEL / (mean * 1e-3) / 1e9
+    parity = {"cosine": rgba_vs_oracle(torch, eng, pcm, rgba, Fp, interp=1)}
     pipes = load_profile_json("pixel_pipes")
     traffic = load_profile_json("hbm_traffic")
     # the interpolator the reference actually executes (interpolated_frequency_sample.rs:46-48 calls the cubic one; the cosine one
@@ -424,6 +454,7 @@ def config3_leg(args, torch, eng, pcm, F):
         ms3 = event_times(torch, lambda: eng3.render_batch(pcm, max_frames=Fp, out=rgba), reps=5, warm=2)
         cubic = {"frames_per_s": Fp / (sum(ms3) / len(ms3) * 1e-3), "launch_ms": stats_ms(ms3),
                  "what": "the same leg with the cubic interpolator, which is what the reference runs"}
+        parity["cubic"] = rgba_vs_oracle(torch, eng3, pcm, rgba, Fp, interp=0)
         eng3.close()
     except Exception as e:  # noqa: BLE001 -- an extra, never fatal
         cubic = {"error": f"{type(e).__name__}: {e}"}
@@ -432,6 +463,7 @@ def config3_leg(args, torch, eng, pcm, F):
         "frames_per_s": Fp / (mean * 1e-3),
         "launch_ms": stats_ms(ms),
         "cubic": cubic,
+        "rgba_vs_oracle": parity,
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "bytes_per_frame": ALGO_BYTES_PIXEL, "frames_per_launch": Fp,
@@ -443,6 +475,94 @@ def config3_leg(args, torch, eng, pcm, F):
                     "the binding pipes (VALU issue, LDS) are in binding_pipe, from this round's SQ counter pass",
         },
     }
+
+
+def rgba_vs_oracle(torch, eng, pcm, rgba, Fp, interp):
+    """the end-to-end pixel result is REPORTED -- mismatch rate and largest LUT-step delta of the fused
+    kernel's bytes (full-scale noise, the columns just rendered) against the CPU oracle run end to end (its own float32
+    transform, then its pixel stage) on 1 024 sampled frames t = i * 977 mod F.  The stage-wise figure (the oracle's pixel
+    stage over the engine's own magnitudes) is bit-exact by test; it is recomputed here on 128 of the frames."""
+    import numpy as np
+
+    import oracle
+
+    n = min(1024, Fp)
+    ts = [(i * 977) % Fp for i in range(n)]
+    got = rgba[ts, 0].cpu().numpy()
+    host = np.stack([pcm[t * H:t * H + W].cpu().numpy() for t in ts])
+    from spectrogram_rs_amd.engine import builtin_gradient
+    lut_rgb = builtin_gradient("viridis")
+    ref_mags = np.stack([oracle.fft_process(np.stack([h, h], 1), W) for h in host])
+    ref = oracle.render_columns(ref_mags, 48000, lut_rgb, interp=interp)
+    level = {tuple(int(x) for x in c): i for i, c in enumerate(lut_rgb)}
+    bad = np.argwhere((got != ref).any(axis=2))
+    steps = [abs(level.get(tuple(int(x) for x in got[a, b, :3]), 10**6) - level[tuple(int(x) for x in ref[a, b, :3])]) for a, b in bad]
+    own = np.concatenate([eng.stft_batch(pcm, first_frame=t, max_frames=1).cpu().numpy()[:, 0] for t in ts[:128]])
+    stage_ok = bool(np.array_equal(got[:128], oracle.render_columns(own, 48000, lut_rgb, interp=interp)))
+    return {"frames": n, "pixels": int(got.shape[0] * got.shape[1]), "mismatched_pixels": int(len(bad)),
+            "mismatch_rate": float(len(bad)) / float(got.shape[0] * got.shape[1]), "max_lut_step": int(max(steps) if steps else 0),
+            "stage_wise_bit_exact_on_128_frames": stage_ok,
+            "input": "full-scale white noise (the bench stream), frames t = i * 977 mod F"}
+
+
+def stereo_leg(args, torch, device):
+    """The 4096-point transform on an (l, r) stream -- what the reference feeds (audio_input_list_model.rs:66-72): one
+    frame per transform, 18 424 algorithmic bytes per frame."""
+    from spectrogram_rs_amd import SpectrogramEngine
+
+    Fs = args.stereo_frames
+    eng = SpectrogramEngine(48000.0, window_samples=W, hop_samples=H, channels=2, device=device)
+    pcm = eng.white_noise((Fs - 1) * H + W)
+    out = torch.empty((Fs, 1, M, 2), dtype=torch.float32, device=eng.device)
+    out.zero_()
+    ms = event_times(torch, lambda: eng.stft_batch(pcm, out=out), reps=5, warm=2)
+    mean = sum(ms) / len(ms)
+    achieved = Fs * ALGO_BYTES_STEREO / (mean * 1e-3) / 1e9
+    res = {
+        "workload": f"4096-pt Hann STFT, hop 256, {Fs} frames of an (l, r) white-noise stream (2 channels interleaved), one frame per transform",
+        "frames_per_s": Fs / (mean * 1e-3), "launch_ms": stats_ms(ms),
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "bytes_per_frame": ALGO_BYTES_STEREO, "frames_per_launch": Fs,
+                     "kernel": "sgx::wg::stft4096_wg_kernel<false, 1, true, false>",
+                     "note": "bound by the LDS write path of the three exchanges of a transform (DESIGN section 4 K1), not by HBM"},
+    }
+    del out
+    eng.close()
+    return res
+
+
+def app_point_leg(args, torch, device):
+    """The application's own operating point: 48 kHz x 0.05 s -> W 2400 (2W = 4800 = 2^6 3 5^2: mixed radix), hop 93
+    ((2 / 1024) s, simple_spectrogram.rs:102), stereo; float32 rows and PCM -> RGBA columns (Viridis, cubic = what the
+    reference runs)."""
+    from spectrogram_rs_amd import SpectrogramEngine
+
+    Fa = args.app_frames
+    eng = SpectrogramEngine(48000.0, period=0.05, hop_samples=H_APP, channels=2, device=device, interp=0, gradient="viridis")
+    assert eng.W == W_APP and eng.H == H_APP, (eng.W, eng.H)
+    pcm = eng.white_noise((Fa - 1) * H_APP + W_APP)
+    out = torch.empty((Fa, 1, W_APP - 1, 2), dtype=torch.float32, device=eng.device)
+    out.zero_()
+    ms = event_times(torch, lambda: eng.stft_batch(pcm, out=out), reps=5, warm=2)
+    del out
+    rgba = torch.empty((Fa, 1, R, 4), dtype=torch.uint8, device=eng.device)
+    rgba.zero_()
+    msp = event_times(torch, lambda: eng.render_batch(pcm, out=rgba), reps=5, warm=2)
+    mean, meanp = sum(ms) / len(ms), sum(msp) / len(msp)
+    ach, achp = Fa * ALGO_BYTES_APP / (mean * 1e-3) / 1e9, Fa * ALGO_BYTES_APP_PIXEL / (meanp * 1e-3) / 1e9
+    name = KERNEL_NAMES.get(eng.info.stft_kernel, ("?", "?"))
+    res = {
+        "workload": f"the application's operating point: 48 kHz x 0.05 s = W 2400 (4800-point transform), hop 93, (l, r) stream, {Fa} frames",
+        "kernel": name[0], "real_time_factor": Fa / (mean * 1e-3) * H_APP / 48000.0,
+        "rows_f32": {"frames_per_s": Fa / (mean * 1e-3), "launch_ms": stats_ms(ms),
+                     "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                                  "bytes_per_frame": ALGO_BYTES_APP, "frames_per_launch": Fa}},
+        "pcm_to_rgba": {"frames_per_s": Fa / (meanp * 1e-3), "launch_ms": stats_ms(msp), "fused_kernel": bool(eng.info.render_path & 1),
+                        "roofline": {"bound": "hbm", "achieved": achp, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achp / HBM_PEAK_GBS,
+                                     "bytes_per_frame": ALGO_BYTES_APP_PIXEL, "frames_per_launch": Fa}},
+    }
+    eng.close()
+    return res
 
 
 def config4_leg(args, torch, device):
@@ -524,6 +644,20 @@ def config5_leg(args, torch, dist, eng, rank, world, backend, barrier, max_over_
     t_comp, _ = run(produce, None, send=False)                    # render only
     t_xfer, _ = run(None, lambda g0, p: None)                     # gather only (re-sends the ring's last contents)
     t_over, t_comp, t_xfer = max_over_ranks([t_over, t_comp, t_xfer])
+    # every source link on its own: a transfer-only pass in which only rank r sends (a bounded number of chunks), so that a
+    # slow link shows up as itself and not inside an average
+    per_source = []
+    n_alone = min(8 * chunk, min(c for c in counts if c > 0))
+    for r in range(1, world):
+        solo = [n_alone if q == r and counts[q] > 0 else 0 for q in range(world)]
+        torch.cuda.synchronize()
+        barrier()
+        t0 = time.perf_counter()
+        got_r = stream_columns(solo, chunk, None, lambda g0, p: None, like=like, dst=0)
+        torch.cuda.synchronize()
+        barrier()
+        t_r = max_over_ranks([time.perf_counter() - t0])[0]
+        per_source.append({"source": r, "bytes": int(n_alone) * R * 4 if solo[r] else 0, "GBps": (n_alone * R * 4 / t_r / 1e9) if solo[r] else None})
     out = None
     if rank == 0:
         # the sharded bytes equal a single GPU's on a sub-range: the root renders the first chunk of every other rank
@@ -548,6 +682,7 @@ def config5_leg(args, torch, dist, eng, rank, world, backend, barrier, max_over_
             "gathered_bytes": arrived,
             "GBps_into_root": arrived / t_over / 1e9, "GBps_into_root_gather_only": arrived / t_xfer / 1e9,
             "GBps_per_source_link_gather_only": arrived / t_xfer / 1e9 / max(world - 1, 1),
+            "GBps_per_source_alone": per_source,
             "root_consumed": "sgx_checksum_add over every piece (its own included), nothing kept",
             "checksum_all_columns": int(acc[0]) & (2**64 - 1),
             "sharded_equals_single_gpu_on_first_chunk_of_every_rank": bool(ok),
@@ -561,7 +696,11 @@ def cpu_baseline_leg(args, eng, pcm):
     import oracle
 
     info = host_info()
-    cores = min(info["affinity"] or info["nproc"] or 1, 64)   # the threads actually started
+    # the threads actually started: one per CPU this process may run on (its affinity mask), all of them -- the oracle's
+    # frame loop is embarrassingly parallel and every thread owns its scratch
+    cores = info["affinity"] or info["nproc"] or 1
+    if info["cgroup_cpu_quota"]:                       # more threads than the quota's CPUs only take turns
+        cores = max(1, min(cores, int(info["cgroup_cpu_quota"] + 0.5)))
     Fc = args.cpu_frames
     piece = 65_536                       # frames per oracle call: bounds host memory to ~1 GB of output
     host = oracle.white_noise((min(piece, Fc) - 1) * H + W)
@@ -582,7 +721,7 @@ def cpu_baseline_leg(args, eng, pcm):
     ok = bool((np.abs(got - ref[:, 0]) <= 2e-5 * np.maximum(np.abs(ref[:, 0]), 0.02 * peak)).all())
     cpu = {
         "value": Fc / cdt, "unit": "frames/s", "cores": cores, "kind": "port",
-        "nproc": info["nproc"], "cpu_model": info["cpu_model"],
+        "nproc": info["nproc"], "affinity": info["affinity"], "cgroup_cpu_quota": info["cgroup_cpu_quota"], "cpu_model": info["cpu_model"],
         "sample": f"first {Fc} frames of the same white-noise stream, float32 oracle (oracle/spectro_oracle.c), {cores} threads, "
                   f"{cdt * cores:.1f} thread-seconds",
         "parity_on_sample": ok,
@@ -593,6 +732,25 @@ def cpu_baseline_leg(args, eng, pcm):
     c0 = time.perf_counter()
     oracle.stream_process(host, 1, W, H, threads=1)
     cpu["single_thread"] = {"value": n1 / (time.perf_counter() - c0), "unit": "frames/s", "frames": n1}
+    # the reference's own FFT library, if this host has it (dlopen libfftw3f.so.3): "as written" (fft.rs:61,68,76:
+    # per-frame allocations and cosf) and hoisted, all threads
+    try:
+        n_f = min(Fc, 65_536)
+        host = oracle.white_noise((n_f - 1) * H + W)
+        if oracle.fftw_available():
+            fig = {}
+            for key, aw in (("as_written", True), ("hoisted", False)):
+                oracle.fftw_stream_process(host[:W + 64 * H], 1, W, H, threads=cores, as_written=aw)
+                c0 = time.perf_counter()
+                o = oracle.fftw_stream_process(host, 1, W, H, threads=cores, as_written=aw)
+                fig[key] = n_f / (time.perf_counter() - c0)
+                pk = np.abs(ref[:, 0]).max(axis=(1, 2), keepdims=True)
+                fig[key + "_matches_oracle"] = bool((np.abs(o[:64, 0] - ref[:, 0]) <= 2e-5 * np.maximum(np.abs(ref[:, 0]), 0.02 * pk)).all())
+            cpu["fftw"] = dict(fig, unit="frames/s", cores=cores, frames=n_f, plan="fftwf_plan_dft_1d(4096, FORWARD, MEASURE)")
+        else:
+            cpu["fftw"] = "not found (dlopen libfftw3f.so.3 failed on this host; the image ships no FFTW)"
+    except Exception as e:  # noqa: BLE001
+        cpu["fftw"] = {"error": f"{type(e).__name__}: {e}"}
     # a second CPU figure for orientation: the FFT call alone through an optimised library FFT (scipy's pocketfft,
     # complex64, all host threads) -- the nearest thing to the reference's FFTW call that this image holds
     try:

@@ -260,9 +260,9 @@ SGX_API int sgx_set_builtin_gradient(sgx_ctx *ctx, const char *name);
 /* ColorScheme::new_mono / new_stereo (colorscheme.rs:24-39) with one of the gradients this library can evaluate itself:
  * "viridis" "magma" "inferno" "plasma" (256-entry ramps) and colorous' ColorBrewer B-spline gradients "red_yellow_blue"
  * "red_blue" "spectral" "red_yellow_green" "pink_green" "purple_orange" "purple_green" "brown_green" "red_grey" "reds"
- * "blues" "greens" "greys" "oranges" "purples" (continuous: anchors from ColorBrewer, d3's interpolateRgbBasis) --
- * 17 of the 19 entries of default_color_schemes (colorscheme.rs:125-151; Turbo and Cividis are polynomials the host
- * mirror carries, Cubehelix and Cool need colorous' own eval_continuous through sgx_set_gradient_fn).
+ * "blues" "greens" "greys" "oranges" "purples" (continuous: anchors from ColorBrewer, d3's interpolateRgbBasis),
+ * "turbo" "cividis" (d3's quintics) and "cubehelix" "cool" "warm" (d3's interpolateCubehelixLong) -- every one of the
+ * 19 entries of default_color_schemes (colorscheme.rs:125-151).  All [third-party, unpinned]: colorous is not vendored.
  * stereo != 0: the diverging rule of colorscheme.rs:63-66 (colour from l / (|l| + |r|), alpha from the level). */
 SGX_API int sgx_set_builtin_scheme(sgx_ctx *ctx, const char *name, int stereo);
 /* eval_continuous(t) of a built-in gradient on the host (ColorScheme::background / foreground, colorscheme.rs:41-53) */

@@ -52,6 +52,11 @@ def lib():
         L.orc_stream_process.restype = C.c_size_t
         L.orc_stream_process.argtypes = [fp, C.c_size_t, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t,
                                          C.c_int, C.c_int, fp]
+        L.orc_fftw_available.restype = C.c_int
+        L.orc_fftw_available.argtypes = []
+        L.orc_fftw_stream_process.restype = C.c_size_t
+        L.orc_fftw_stream_process.argtypes = [fp, C.c_size_t, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t,
+                                              C.c_int, C.c_int, fp]
         L.orc_period.restype = C.c_float
         L.orc_period.argtypes = [C.c_size_t, C.c_uint32]
         L.orc_index_of.restype = C.c_float
@@ -181,6 +186,25 @@ def stream_process(pcm: np.ndarray, channels: int, W: int, H: int, first: int = 
     if count:
         got = lib().orc_stream_process(_fp(pcm), n, channels, W, H, first, count, precision, threads, _fp(out))
         assert got == count
+    return out
+
+
+def fftw_available() -> bool:
+    """does this host have libfftw3f.so.3 (dlopen)?  The image this was built in does not."""
+    return bool(lib().orc_fftw_available())
+
+
+def fftw_stream_process(pcm: np.ndarray, channels: int, W: int, H: int, threads: int = 1, as_written: bool = True):
+    """stream_process through FFTW itself (fft.rs:20-24,68,76-77); None when the host has no libfftw3f."""
+    pcm = _f32c(pcm).reshape(-1)
+    n = pcm.shape[0] // channels
+    count = num_frames(n, W, H)
+    pairs = 1 if channels == 1 else channels // 2
+    out = np.empty((count, pairs, W - 1, 2), np.float32)
+    got = lib().orc_fftw_stream_process(_fp(pcm), n, channels, W, H, 0, count, threads, int(as_written), _fp(out))
+    if got == C.c_size_t(-1).value:
+        return None
+    assert got == count
     return out
 
 

@@ -349,6 +349,123 @@ size_t orc_stream_process(const float *pcm, size_t n, int channels, size_t W, si
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* The same frame loop through the REAL FFTW, if the host has one (bench.py's cpu_baseline leg)  */
+/* ------------------------------------------------------------------------------------------ */
+/* fft.rs:20-24,68,76-77 call FFTW3 (single precision) through the fftw crate.  No libfftw3f ships in this image, so
+ * nothing here is linked: the library is looked up at run time (dlopen "libfftw3f.so.3") and the function says so when
+ * it is absent.  as_written != 0 keeps what fft.rs does per frame -- two fftwf_malloc'ed zero-filled buffers
+ * (AlignedVec::new, :68,76), the Hann factor through cosf for every sample (:61) -- and 0 hoists both out of the loop
+ * ("as written" and "best case").  Plan: fftwf_plan_dft_1d(2W, FORWARD, FFTW_MEASURE), made once (:20-24). */
+#include <dlfcn.h>
+
+typedef void *(*fftwf_plan_dft_1d_t)(int, void *, void *, int, unsigned);
+typedef void (*fftwf_execute_dft_t)(void *, void *, void *);
+typedef void *(*fftwf_malloc_t)(size_t);
+typedef void (*fftwf_free_t)(void *);
+typedef void (*fftwf_destroy_plan_t)(void *);
+static struct {
+    int tried, ok;
+    fftwf_plan_dft_1d_t plan_dft_1d; fftwf_execute_dft_t execute_dft; fftwf_malloc_t malloc_; fftwf_free_t free_;
+    fftwf_destroy_plan_t destroy_plan;
+} g_fftw;
+
+int orc_fftw_available(void)
+{
+    if (!g_fftw.tried) {
+        g_fftw.tried = 1;
+        void *h = dlopen("libfftw3f.so.3", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("libfftw3f.so", RTLD_NOW | RTLD_GLOBAL);
+        if (h) {
+            g_fftw.plan_dft_1d = (fftwf_plan_dft_1d_t)dlsym(h, "fftwf_plan_dft_1d");
+            g_fftw.execute_dft = (fftwf_execute_dft_t)dlsym(h, "fftwf_execute_dft");
+            g_fftw.malloc_ = (fftwf_malloc_t)dlsym(h, "fftwf_malloc");
+            g_fftw.free_ = (fftwf_free_t)dlsym(h, "fftwf_free");
+            g_fftw.destroy_plan = (fftwf_destroy_plan_t)dlsym(h, "fftwf_destroy_plan");
+            g_fftw.ok = g_fftw.plan_dft_1d && g_fftw.execute_dft && g_fftw.malloc_ && g_fftw.free_ && g_fftw.destroy_plan;
+        }
+    }
+    return g_fftw.ok;
+}
+
+typedef struct { stream_job jb; void *plan; int as_written; } fftw_job;
+
+static void *fftw_worker(void *arg)
+{
+    fftw_job *fj = (fftw_job *)arg;
+    const stream_job *jb = &fj->jb;
+    const size_t W = jb->W, H = jb->H, M = W - 1, P = 2 * W;
+    const int C = jb->channels, pairs = C == 1 ? 1 : C / 2;
+    cf *z = NULL, *F = NULL;
+    float *win = NULL;
+    if (!fj->as_written) {
+        z = (cf *)g_fftw.malloc_(sizeof(cf) * P); F = (cf *)g_fftw.malloc_(sizeof(cf) * P);
+        win = (float *)malloc(sizeof(float) * W);
+        orc_hann_window(W, win);
+        memset(z, 0, sizeof(cf) * P);
+    }
+    const float tau = 6.28318530717958647692f;
+    for (size_t i = jb->begin; i < jb->end; ++i) {
+        const float *base = jb->pcm + ((jb->first + i) * H) * (size_t)C;
+        for (int p = 0; p < pairs; ++p) {
+            const float *l = C == 1 ? base : base + 2 * p, *r = C == 1 ? base : base + 2 * p + 1;
+            if (fj->as_written) {   /* fft.rs:68,76: two fresh zero-initialised aligned buffers per frame */
+                z = (cf *)g_fftw.malloc_(sizeof(cf) * P); F = (cf *)g_fftw.malloc_(sizeof(cf) * P);
+                memset(z, 0, sizeof(cf) * P); memset(F, 0, sizeof(cf) * P);
+            }
+            for (size_t n = 0; n < W; ++n) {
+                const float sfac = fj->as_written ? 0.5f * (1.0f - cosf((tau * (float)n) / (float)W)) : win[n];   /* :61 */
+                z[n].re = l[n * (size_t)C] * sfac; z[n].im = r[n * (size_t)C] * sfac;
+            }
+            g_fftw.execute_dft(fj->plan, z, F);   /* :77 */
+            float *o = jb->out + ((i * (size_t)pairs + (size_t)p) * M) * 2;
+            const float scale = 2.0f / (float)W;
+            for (size_t j = 0; j < M; ++j) {       /* :81-98 */
+                const size_t k = j + 1;
+                const cf a = F[k], b = F[P - k];
+                o[2 * j + 0] = hypotf(a.re + b.re, a.im - b.im) / 2.0f * scale;
+                o[2 * j + 1] = hypotf(a.re - b.re, a.im + b.im) / 2.0f * scale;
+            }
+            if (fj->as_written) { g_fftw.free_(z); g_fftw.free_(F); }
+        }
+    }
+    if (!fj->as_written) { g_fftw.free_(z); g_fftw.free_(F); free(win); }
+    return NULL;
+}
+
+/* returns the number of frames processed, or (size_t)-1 when the host has no libfftw3f */
+size_t orc_fftw_stream_process(const float *pcm, size_t n, int channels, size_t W, size_t H, size_t first, size_t count,
+                               int threads, int as_written, float *out)
+{
+    if (!orc_fftw_available()) return (size_t)-1;
+    if (channels < 1 || (channels > 1 && (channels & 1)) || W < 2 || H < 1) return 0;
+    size_t total = orc_num_frames(n, W, H);
+    if (first >= total) return 0;
+    if (count > total - first) count = total - first;
+    if (threads < 1) threads = 1;
+    if ((size_t)threads > count) threads = (int)(count ? count : 1);
+    /* the planner is not thread-safe and MEASURE overwrites its arrays: plan once, here, on scratch buffers */
+    cf *pa = (cf *)g_fftw.malloc_(sizeof(cf) * 2 * W), *pb = (cf *)g_fftw.malloc_(sizeof(cf) * 2 * W);
+    void *plan = g_fftw.plan_dft_1d((int)(2 * W), pa, pb, -1 /* FFTW_FORWARD */, 0u /* FFTW_MEASURE */);
+    if (!plan) { g_fftw.free_(pa); g_fftw.free_(pb); return 0; }
+    fftw_job *jobs = (fftw_job *)calloc((size_t)threads, sizeof(fftw_job));
+    pthread_t *tids = (pthread_t *)calloc((size_t)threads, sizeof(pthread_t));
+    for (int i = 0; i < threads; ++i) {
+        stream_job *jb = &jobs[i].jb;
+        jb->pcm = pcm; jb->n = n; jb->channels = channels; jb->W = W; jb->H = H; jb->first = first; jb->count = count; jb->out = out;
+        jb->begin = count * (size_t)i / (size_t)threads;
+        jb->end = count * (size_t)(i + 1) / (size_t)threads;
+        jobs[i].plan = plan; jobs[i].as_written = as_written;
+        if (threads == 1) fftw_worker(&jobs[i]);
+        else pthread_create(&tids[i], NULL, fftw_worker, &jobs[i]);
+    }
+    if (threads > 1) for (int i = 0; i < threads; ++i) pthread_join(tids[i], NULL);
+    g_fftw.destroy_plan(plan);
+    g_fftw.free_(pa); g_fftw.free_(pb);
+    free(jobs); free(tids);
+    return count;
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* InterpolatedFrequencySample  (interpolated_frequency_sample.rs)                            */
 /* ------------------------------------------------------------------------------------------ */
 

@@ -72,7 +72,7 @@ class ColorScheme:
 
 
 def _builtin_name(gradient) -> Optional[str]:
-    return gradient if isinstance(gradient, str) and (gradient in _BREWER_ANCHORS or gradient in ("viridis", "magma", "inferno", "plasma")) else None
+    return gradient if isinstance(gradient, str) and (gradient in CONTINUOUS or gradient in ("viridis", "magma", "inferno", "plasma")) else None
 
 
 def _resolve(gradient):
@@ -86,6 +86,8 @@ def _resolve(gradient):
 def _poly_gradient(cr, cg, cb):
     """d3-scale-chromatic style closed forms: per channel a quintic in t (Horner, alternating signs as
     published), clamped to [0, 255] and rounded.  PARITY UNPINNED against colorous (crate not vendored)."""
+    import math
+
     def fn(t):
         t = 0.0 if t != t else max(0.0, min(1.0, t))
         out = []
@@ -93,8 +95,27 @@ def _poly_gradient(cr, cg, cb):
             v = c[5]
             for k in (4, 3, 2, 1, 0):
                 v = c[k] + t * v
-            out.append(int(max(0, min(255, round(v)))))
+            out.append(int(max(0.0, min(255.0, math.floor(v + 0.5)))))   # Math.round: half up
         return tuple(out)
+    return fn
+
+
+def _cubehelix_long(h0, s0, l0, h1, s1, l1):
+    """d3-interpolate's interpolateCubehelixLong((h0, s0, l0), (h1, s1, l1)) -- hue, saturation and lightness each linear
+    in t, no shortest-arc on the hue, gamma 1 -- then d3-color's Cubehelix -> sRGB matrix, bytes by rounding, clamped:
+    what d3-scale-chromatic, which colorous ports, evaluates for CUBEHELIX / COOL / WARM (colorscheme.rs:141,143).  The
+    same arithmetic, in the same order, as helix_eval in csrc/sgx_api.hip.  PARITY UNPINNED against colorous."""
+    import math
+
+    def fn(t):
+        t = 0.0 if t != t else max(0.0, min(1.0, t))
+        h = (h0 + t * (h1 - h0) + 120.0) * (math.pi / 180.0)
+        s, l = s0 + t * (s1 - s0), l0 + t * (l1 - l0)
+        a, ch, sh = s * l * (1.0 - l), math.cos(h), math.sin(h)
+        vals = (255.0 * (l + a * (-0.14861 * ch + 1.78277 * sh)),
+                255.0 * (l + a * (-0.29227 * ch + -0.90649 * sh)),
+                255.0 * (l + a * (1.97294 * ch)))
+        return tuple(int(max(0.0, min(255.0, math.floor(v + 0.5)))) for v in vals)
     return fn
 
 
@@ -142,7 +163,12 @@ CONTINUOUS = {
     "cividis": _poly_gradient((-4.54, -35.34, 2381.73, -6402.7, 7024.72, -2710.57),
                               (32.49, 170.73, 52.82, -131.46, 176.58, -67.37),
                               (81.24, 442.36, -2482.43, 6167.24, -6614.94, 2475.67)),
+    # interpolateCubehelixDefault = cubehelixLong(cubehelix(300, 0.5, 0.0), cubehelix(-240, 0.5, 1.0)); interpolateCool / Warm
+    "cubehelix": _cubehelix_long(300.0, 0.5, 0.0, -240.0, 0.5, 1.0),
+    "cool": _cubehelix_long(260.0, 0.75, 0.35, 80.0, 1.5, 0.8),
+    "warm": _cubehelix_long(-100.0, 0.75, 0.35, 80.0, 1.5, 0.8),
 }
+CLOSED_FORM = tuple(CONTINUOUS)   # evaluated by the engine itself too (poly_eval / helix_eval in csrc/sgx_api.hip)
 
 
 from ._brewer import ANCHORS as _BREWER_ANCHORS  # noqa: E402  (generated)
@@ -152,11 +178,11 @@ BREWER = tuple(_BREWER_ANCHORS)   # names the engine evaluates itself (sgx_set_b
 
 
 def default_color_schemes() -> List[ColorScheme]:
-    """colorscheme.rs:125-151 in the reference's order, restricted to what this package can evaluate itself: the four
-    256-entry ramps (tables), the ColorBrewer B-spline gradients (anchors from ColorBrewer via matplotlib, d3's
-    interpolateRgbBasis) and the closed-form Turbo / Cividis polynomials -- 17 of the 19.  CUBEHELIX and COOL are
-    cubehelix-space interpolations whose parameters cannot be sourced inside this image: they are rendered by handing
-    the engine colorous' own eval_continuous as the callback (ColorScheme(callable, name))."""
+    """colorscheme.rs:125-151: the reference's 19 entries in the reference's order, every one evaluated by the engine
+    itself (sgx_set_builtin_scheme): the four 256-entry ramps (tables), the ColorBrewer B-spline gradients (anchors from
+    ColorBrewer via matplotlib, d3's interpolateRgbBasis), the closed-form Turbo / Cividis polynomials and the
+    cubehelix-space interpolations CUBEHELIX and COOL (d3's interpolateCubehelixLong; the default helix is the curve
+    matplotlib's `cubehelix` traces).  All [third-party, unpinned]: colorous is not vendored in the reference."""
     black = (0, 0, 0)
     return [
         ColorScheme.new_stereo("red_yellow_blue", black, "Blue-Yellow-Red (Stereo)"),
@@ -170,9 +196,9 @@ def default_color_schemes() -> List[ColorScheme]:
         ColorScheme.new_mono("inferno", "Inferno"),
         ColorScheme.new_mono("plasma", "Plasma"),
         ColorScheme.new_mono("cividis", "Cividis"),
-        # ColorScheme.new_mono(CUBEHELIX, "Cube-helix"): callback only
+        ColorScheme.new_mono("cubehelix", "Cube-helix"),
         ColorScheme.new_mono("turbo", "Turbo"),
-        # ColorScheme.new_mono(COOL, "Cool"): callback only
+        ColorScheme.new_mono("cool", "Cool"),
         ColorScheme.new_mono("reds", "Reds"),
         ColorScheme.new_mono("blues", "Blues"),
         ColorScheme.new_mono("greens", "Greens"),

@@ -16,7 +16,11 @@ namespace {
 
 thread_local std::string g_create_error;
 
-const char *kVersion = "sgx 0.1 (hip gfx950)";
+#ifdef SGX_WITH_VARIANTS
+const char *kVersion = "sgx 0.3 (hip gfx950) +variants";
+#else
+const char *kVersion = "sgx 0.3 (hip gfx950)";
+#endif
 
 int fail(sgx_ctx *c, int code, const std::string &msg)
 {
@@ -98,6 +102,73 @@ void brewer_eval(double t, uint8_t out[3], void *user)
         const double r = std::floor(v + 0.5);
         out[ch] = (uint8_t)(r < 0.0 ? 0.0 : (r > 255.0 ? 255.0 : r));
     }
+}
+
+// colorous' closed-form gradients (colorscheme.rs:140-143).  [third-party] colorous 1.0.12 ports d3-scale-chromatic:
+//   TURBO, CIVIDIS: a quintic per channel in t clamped to [0, 1] (d3's interpolateTurbo / interpolateCividis, Horner with
+//     the signs as published), bytes by rounding to nearest, clamped;
+//   CUBEHELIX, COOL (and WARM): d3's interpolateCubehelixLong between two (h, s, l) triples -- h, s, l each linear in t,
+//     no shortest-arc on the hue, gamma 1 -- followed by d3-color's Cubehelix -> sRGB matrix.  The default CUBEHELIX,
+//     (300, 0.5, 0) -> (-240, 0.5, 1), is Green's (2011) helix with start 0.5, -1.5 rotations, hue 1, gamma 1: the curve
+//     matplotlib's `cubehelix` colormap traces (checked in tests/test_host_logic.py against matplotlib._cm.cubehelix).
+// The endpoint triples and the byte rule (round to nearest, clamp) are data of this file: PARITY UNPINNED like every other
+// gradient (the crate is not vendored in the reference), replaceable through sgx_set_gradient_fn.
+struct sgx_poly { const char *name; double r[6], g[6], b[6]; };
+const sgx_poly SGX_POLY[] = {
+    {"turbo", {34.61, 1172.33, -10793.56, 33300.12, -38394.49, 14825.05}, {23.31, 557.33, 1225.33, -3574.96, 1073.77, 707.56},
+     {27.2, 3211.1, -15327.97, 27814.0, -22569.18, 6838.66}},
+    {"cividis", {-4.54, -35.34, 2381.73, -6402.7, 7024.72, -2710.57}, {32.49, 170.73, 52.82, -131.46, 176.58, -67.37},
+     {81.24, 442.36, -2482.43, 6167.24, -6614.94, 2475.67}},
+};
+struct sgx_helix { const char *name; double h0, s0, l0, h1, s1, l1; };
+const sgx_helix SGX_HELIX[] = {
+    {"cubehelix", 300.0, 0.5, 0.0, -240.0, 0.5, 1.0},
+    {"cool", 260.0, 0.75, 0.35, 80.0, 1.5, 0.8},
+    {"warm", -100.0, 0.75, 0.35, 80.0, 1.5, 0.8},
+};
+
+uint8_t byte_round(double v)
+{
+    const double r = std::floor(v + 0.5);
+    if (!(r > 0.0)) return 0;   // negative and NaN
+    return (uint8_t)(r > 255.0 ? 255.0 : r);
+}
+
+void poly_eval(double t, uint8_t out[3], void *user)
+{
+    const sgx_poly *g = static_cast<const sgx_poly *>(user);
+    t = !(t > 0.0) ? 0.0 : (t > 1.0 ? 1.0 : t);   // clamp; NaN -> 0
+    const double *cs[3] = {g->r, g->g, g->b};
+    for (int ch = 0; ch < 3; ++ch) {
+        const double *c = cs[ch];
+        double v = c[5];
+        for (int k = 4; k >= 0; --k) v = c[k] + t * v;
+        out[ch] = byte_round(v);
+    }
+}
+
+void helix_eval(double t, uint8_t out[3], void *user)
+{
+    const sgx_helix *g = static_cast<const sgx_helix *>(user);
+    t = !(t > 0.0) ? 0.0 : (t > 1.0 ? 1.0 : t);
+    const double h = (g->h0 + t * (g->h1 - g->h0) + 120.0) * (M_PI / 180.0);
+    const double s = g->s0 + t * (g->s1 - g->s0), l = g->l0 + t * (g->l1 - g->l0);
+    const double a = s * l * (1.0 - l), ch = std::cos(h), sh = std::sin(h);
+    out[0] = byte_round(255.0 * (l + a * (-0.14861 * ch + 1.78277 * sh)));
+    out[1] = byte_round(255.0 * (l + a * (-0.29227 * ch + -0.90649 * sh)));
+    out[2] = byte_round(255.0 * (l + a * (1.97294 * ch)));
+}
+
+// name -> (evaluator, its data) for every continuous gradient this library evaluates itself
+bool continuous_gradient(const char *name, sgx_gradient_fn *fn, void **user)
+{
+    if (!name) return false;
+    if (const sgx_brewer *b = brewer_gradient(name)) { *fn = brewer_eval; *user = const_cast<sgx_brewer *>(b); return true; }
+    for (const sgx_poly &g : SGX_POLY)
+        if (!std::strcmp(name, g.name)) { *fn = poly_eval; *user = const_cast<sgx_poly *>(&g); return true; }
+    for (const sgx_helix &g : SGX_HELIX)
+        if (!std::strcmp(name, g.name)) { *fn = helix_eval; *user = const_cast<sgx_helix *>(&g); return true; }
+    return false;
 }
 
 int upload_palette(sgx_ctx *c)
@@ -252,6 +323,12 @@ int sgx_create(const sgx_config *cfg, sgx_ctx **out_ctx)
     if (c->device >= n_dev) return bail(SGX_ERR_INVALID_ARG, "sgx_create: device ordinal out of range");
     e = hipSetDevice(c->device);
     if (e != hipSuccess) return bail(SGX_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+    {   // device limits the launchers need: read once, here
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && v > 0) c->n_cu = v;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeSharedMemPerBlockOptin, c->device) == hipSuccess && v > 0) c->lds_optin = (size_t)v;
+        else if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, c->device) == hipSuccess && v > 0) c->lds_optin = (size_t)v;
+    }
 
     sgx::build_tables(c->W, c->R, c->sr_u32, cfg->f_min, cfg->f_max, cfg->interp, c->tab);
     if ((e = upload(&c->d_window, c->tab.window.data(), c->tab.window.size())) != hipSuccess ||
@@ -271,6 +348,11 @@ int sgx_create(const sgx_config *cfg, sgx_ctx **out_ctx)
     if (rc != SGX_OK) { std::string m = c->err; return bail(rc, m); }
 
     c->stft_kernel = 0;
+#ifndef SGX_WITH_VARIANTS
+    if (cfg->flags & (SGX_FLAG_WAVE_KERNEL | SGX_FLAG_PACKED_KERNEL | SGX_FLAG_LEGACY_16K))
+        return bail(SGX_ERR_UNSUPPORTED, "sgx_create: SGX_FLAG_WAVE_KERNEL / SGX_FLAG_PACKED_KERNEL / SGX_FLAG_LEGACY_16K select superseded A/B kernels "
+                                         "that this build leaves out (make -C spectrogram_rs_amd/csrc VARIANTS=1)");
+#endif
     // powers of two from W = 512 on that have no tuned kernel ride the composite-radix stages too (compile-time plans 4 x 16 x 16,
     // 8 x 16 x 16, 4 x 8 x 16 x 16): same-device A/B against the radix-4 ladder of the generic kernel, mono / stereo:
     // W 512 +29 % / +44 %, W 1024 +48 % / +90 %, W 4096 +83 % / +117 %; W 256: -14 %, W 128: -53 % (run-time geometry)
@@ -311,6 +393,8 @@ void sgx_destroy(sgx_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    sgx::detach_views(c);   // views that outlive their context keep their own buffers and answer SGX_ERR_INVALID_ARG from now on
     sgx::fast4096_destroy(c);
     sgx::wg4096_destroy(c->d_fast_wg);
     c->d_fast_wg = nullptr;
@@ -568,7 +652,9 @@ int sgx_set_builtin_scheme(sgx_ctx *c, const char *name, int stereo)
 {
     if (!c) return SGX_ERR_INVALID_ARG;
     if (const unsigned char *g = builtin_gradient(name)) return sgx_set_gradient(c, g, 256, stereo);
-    if (const sgx_brewer *b = brewer_gradient(name)) return sgx_set_gradient_fn(c, brewer_eval, const_cast<sgx_brewer *>(b), stereo);
+    sgx_gradient_fn fn = nullptr;
+    void *user = nullptr;
+    if (continuous_gradient(name, &fn, &user)) return sgx_set_gradient_fn(c, fn, user, stereo);
     return fail(c, SGX_ERR_INVALID_ARG, std::string("sgx_set_builtin_scheme: unknown gradient '") + (name ? name : "(null)") + "'");
 }
 
@@ -577,7 +663,9 @@ int sgx_set_builtin_gradient(sgx_ctx *c, const char *name) { return sgx_set_buil
 int sgx_builtin_gradient_eval(const char *name, double t, uint8_t rgb_out[3])
 {
     if (!rgb_out) return SGX_ERR_INVALID_ARG;
-    if (const sgx_brewer *b = brewer_gradient(name)) { brewer_eval(t, rgb_out, const_cast<sgx_brewer *>(b)); return SGX_OK; }
+    sgx_gradient_fn fn = nullptr;
+    void *user = nullptr;
+    if (continuous_gradient(name, &fn, &user)) { fn(t, rgb_out, user); return SGX_OK; }
     if (const unsigned char *g = builtin_gradient(name)) {
         const int idx = sgx::lut_index_host(t, 256, SGX_LUT_FLOOR_N);
         std::memcpy(rgb_out, g + 3 * idx, 3);

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <array>
 #include <string>
 #include <vector>
 
@@ -120,19 +121,33 @@ struct sgx_ctx {
 
     unsigned long long palette_gen = 0;  // bumped by every palette upload (sgx_view rebuilds its palette texture on a change)
 
+    // device limits, read once at sgx_create (not on the per-tick latency path)
+    int n_cu = 256;
+    size_t lds_optin = 64 * 1024;   // hipDeviceAttributeSharedMemPerBlockOptin: the largest LDS image a workgroup may ask for
+    // resident workgroups per CU of a kernel instantiation at a block size and LDS image (hipOccupancyMaxActiveBlocksPerMultiprocessor, cached)
+    mutable std::vector<std::pair<std::array<size_t, 3>, int>> occupancy_cache;
+    // objects that hold a pointer into this context (sgx_view): sgx_destroy detaches them, their calls then fail cleanly
+    std::vector<struct sgx_view *> views;
+
     std::string err;
 };
 
 namespace sgx {
 
+inline bool fast4096_supported(const sgx_ctx *c) { return c->W == 2048; }   // the tuned 4096-point kernels (stft4096_wg.hip)
 // kernel launchers (each returns hipSuccess or the launch error)
 hipError_t launch_stft_generic(const sgx_ctx *c, const float *d_pcm, uint32_t channels, uint32_t pairs, size_t first_frame,
                                size_t n_frames, size_t total_frames, float *d_mags);
-bool fast4096_supported(const sgx_ctx *c);
+#ifdef SGX_WITH_VARIANTS   // make VARIANTS=1: the superseded A/B kernels (stft4096.hip, stft4096_wgp.hip, stft16384_wg.hip)
 hipError_t fast4096_init(sgx_ctx *c);
 void fast4096_destroy(sgx_ctx *c);
 hipError_t launch_stft_fast4096(const sgx_ctx *c, const float *d_pcm, uint32_t channels, uint32_t pairs, size_t first_frame,
                                 size_t n_frames, size_t total_frames, float *d_mags);
+#else
+inline hipError_t fast4096_init(sgx_ctx *) { return hipSuccess; }
+inline void fast4096_destroy(sgx_ctx *) {}
+inline hipError_t launch_stft_fast4096(const sgx_ctx *, const float *, uint32_t, uint32_t, size_t, size_t, size_t, float *) { return hipErrorNotSupported; }
+#endif
 hipError_t wg4096_init(sgx_ctx *c, void **out);
 void wg4096_destroy(void *tables);
 hipError_t launch_stft_wg4096(const sgx_ctx *c, const void *tables, const float *d_pcm, uint32_t channels, uint32_t pairs,
@@ -145,6 +160,7 @@ void lut_seed_coefficients(const sgx_ctx *c, float &a, float &b);
 namespace wg { bool seed_within_one(const std::vector<float> &thr, double guess_a, double guess_b); }   // stft4096_wg.hip: is floor(log2(p + 1e-7) a + b) within one of the threshold count for every power?   // LUT level ~ floor(log2(power + 1e-7) a + b): the seed of the threshold count
 hipError_t launch_render_wg4096(const sgx_ctx *c, const void *tables, const float *d_pcm, uint32_t channels, uint32_t pairs,
                                 size_t first_frame, size_t n_frames, size_t total_frames, uint8_t *d_rgba);
+#ifdef SGX_WITH_VARIANTS
 hipError_t launch_stft_wgp4096(const sgx_ctx *c, const void *tables, const float *d_pcm, uint32_t channels, uint32_t pairs,
                                size_t first_frame, size_t n_frames, size_t total_frames, float *d_mags);
 hipError_t launch_render_wgp4096(const sgx_ctx *c, const void *tables, const float *d_pcm, uint32_t channels, uint32_t pairs,
@@ -154,6 +170,14 @@ hipError_t wg16384_init(sgx_ctx *c, void **out);
 void wg16384_destroy(void *tables);
 hipError_t launch_stft_wg16384(const sgx_ctx *c, const void *tables, const float *d_pcm, uint32_t channels, uint32_t pairs,
                                size_t first_frame, size_t n_frames, size_t total_frames, float *d_mags);
+#else
+inline hipError_t launch_stft_wgp4096(const sgx_ctx *, const void *, const float *, uint32_t, uint32_t, size_t, size_t, size_t, float *) { return hipErrorNotSupported; }
+inline hipError_t launch_render_wgp4096(const sgx_ctx *, const void *, const float *, uint32_t, uint32_t, size_t, size_t, size_t, uint8_t *) { return hipErrorNotSupported; }
+inline bool wg16384_supported(const sgx_ctx *) { return false; }
+inline hipError_t wg16384_init(sgx_ctx *, void **) { return hipErrorNotSupported; }
+inline void wg16384_destroy(void *) {}
+inline hipError_t launch_stft_wg16384(const sgx_ctx *, const void *, const float *, uint32_t, uint32_t, size_t, size_t, size_t, float *) { return hipErrorNotSupported; }
+#endif
 bool q16384_supported(const sgx_ctx *c);
 hipError_t q16384_init(sgx_ctx *c, void **out);
 void q16384_destroy(void *tables);
@@ -185,6 +209,7 @@ hipError_t launch_to_half(const sgx_ctx *c, const float *d_in, void *d_out, size
 hipError_t launch_render(const sgx_ctx *c, const float *d_mags, size_t n_columns, uint8_t *d_rgba);
 hipError_t launch_magnitude_in(const sgx_ctx *c, const float *d_mags, size_t n_columns, const RowEntry *d_rows,
                                const SampleEntry *d_samples, uint32_t n_ranges, float *d_out);
+void detach_views(sgx_ctx *c);   // sgx_view.hip: every live view of the context forgets it
 hipError_t launch_white_noise(const sgx_ctx *c, float *d_out, uint64_t first, size_t n, uint32_t channels, uint32_t seed);
 hipError_t launch_checksum(const sgx_ctx *c, const uint32_t *d_words, size_t n_words, uint64_t base_word,
                            unsigned long long *d_acc);

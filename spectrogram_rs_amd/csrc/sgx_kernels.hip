@@ -601,21 +601,30 @@ hipError_t launch_render(const sgx_ctx *c, const float *d_mags, size_t n_columns
                                          : (size_t)((c->pal.n + 255 + 1) & ~1u) * sizeof(float) + (size_t)((c->pal.n + 1) & ~1u) * sizeof(uchar4) +
                                                (size_t)c->pal.n * sizeof(double) + (size_t)(kTCells + 4) * sizeof(uint16_t);
     const size_t lds2 = (size_t)(c->M + 1 + n_samples) * sizeof(float2) + tail;
-    if (c->M <= 1024 * 10 && lds2 <= 160 * 1024) {
+    // the largest LDS image a workgroup may ask for on THIS device (read once at sgx_create): a column that does not fit takes
+    // the one-workgroup-per-column kernel below, as it did before the two-pass form accepted images above 64 KB
+    const size_t lds_cap = c->lds_optin < (size_t)160 * 1024 ? c->lds_optin : (size_t)160 * 1024;
+    if (c->M <= 1024 * 10 && lds2 <= lds_cap) {
         // persistent two-pass form: workgroups sized to the LDS image, each walks columns blockIdx.x, + grid, ...
-        int n_cu = 256;
-        (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device);
-        const size_t fit = (160 * 1024) / lds2;
+        const int n_cu = c->n_cu;
+        const size_t fit = lds_cap / lds2;
         unsigned nt = fit >= 4 ? 256u : (fit >= 2 ? 512u : 1024u);
         while (nt < 1024u && (c->M + nt - 1) / nt > 16) nt *= 2;
         auto go = [&](auto kernel) -> hipError_t {
-            if (lds2 > 64 * 1024) {
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-                if (e != hipSuccess) return e;
-            }
-            // as many persistent workgroups as the device keeps resident (LDS image and registers of THIS instantiation)
+            // as many persistent workgroups as the device keeps resident (LDS image and registers of THIS instantiation):
+            // asked once per (instantiation, block size, image size) and kept -- this sits on the per-tick path of a live ring
+            const std::array<size_t, 3> key = {(size_t)reinterpret_cast<uintptr_t>(reinterpret_cast<const void *>(kernel)), (size_t)nt, lds2};
             int per_cu = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, (int)nt, lds2) != hipSuccess || per_cu < 1) per_cu = 1;
+            for (const auto &kv : c->occupancy_cache)
+                if (kv.first == key) per_cu = kv.second;
+            if (per_cu == 0) {
+                if (lds2 > 64 * 1024) {
+                    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+                    if (e != hipSuccess) { (void)hipGetLastError(); return hipErrorNotSupported; }   // -> the per-column kernel below
+                }
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, (int)nt, lds2) != hipSuccess || per_cu < 1) per_cu = 1;
+                c->occupancy_cache.push_back({key, per_cu});
+            }
             size_t blocks = (size_t)n_cu * (size_t)(per_cu > 8 ? 8 : per_cu);
             if (blocks > n_columns) blocks = n_columns;
             hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(nt), lds2, c->stream, p, (unsigned long long)n_columns, (uint32_t)n_samples);
@@ -626,14 +635,15 @@ hipError_t launch_render(const sgx_ctx *c, const float *d_mags, size_t n_columns
         bool in_regs = nt == 256 && n_samples <= 256 * 12 && c->R <= 1024 && n_samples < 65536;
         for (const RowEntry &r : c->tab.rows) in_regs = in_regs && r.count < 65536 && r.first < 65536;
 #define SGX_TWO_PASS(K, S, T) (mode == kMonoSeed ? go(render_two_pass_kernel<K, kMonoSeed, S, T>) : mode == kStereoSeed ? go(render_two_pass_kernel<K, kStereoSeed, S, T>) : go(render_two_pass_kernel<K, kGeneric, S, T>))
+        hipError_t e2;
         if (nt == 256) {
-            if (need <= 8) return in_regs ? SGX_TWO_PASS(8, 12, 256) : SGX_TWO_PASS(8, 0, 256);
-            if (need <= 10) return in_regs ? SGX_TWO_PASS(10, 12, 256) : SGX_TWO_PASS(10, 0, 256);
-            return SGX_TWO_PASS(16, 0, 256);
-        }
-        if (nt == 512) return need <= 8 ? SGX_TWO_PASS(8, 0, 512) : SGX_TWO_PASS(16, 0, 512);
-        return need <= 8 ? SGX_TWO_PASS(8, 0, 1024) : SGX_TWO_PASS(10, 0, 1024);
+            if (need <= 8) e2 = in_regs ? SGX_TWO_PASS(8, 12, 256) : SGX_TWO_PASS(8, 0, 256);
+            else if (need <= 10) e2 = in_regs ? SGX_TWO_PASS(10, 12, 256) : SGX_TWO_PASS(10, 0, 256);
+            else e2 = SGX_TWO_PASS(16, 0, 256);
+        } else if (nt == 512) e2 = need <= 8 ? SGX_TWO_PASS(8, 0, 512) : SGX_TWO_PASS(16, 0, 512);
+        else e2 = need <= 8 ? SGX_TWO_PASS(8, 0, 1024) : SGX_TWO_PASS(10, 0, 1024);
 #undef SGX_TWO_PASS
+        if (e2 != hipErrorNotSupported) return e2;   // (not supported: the image was refused; nothing was launched)
     }
     const size_t lds = (size_t)(c->M + 1) * sizeof(float2) + (size_t)(c->pal.n + 255) * sizeof(float);
     if (lds > 64 * 1024) {  // per launch: the attribute is per device, and a process may hold contexts on several

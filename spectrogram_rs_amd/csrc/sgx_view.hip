@@ -114,6 +114,14 @@ int view_fail_hip(sgx_view *v, hipError_t e, const char *what)
 
 }  // namespace
 
+namespace sgx {
+void detach_views(sgx_ctx *c)
+{
+    for (sgx_view *v : c->views) v->ctx = nullptr;
+    c->views.clear();
+}
+}  // namespace sgx
+
 extern "C" {
 
 int sgx_view_create(sgx_ctx *c, uint32_t viewport_frames, sgx_view **out)
@@ -133,6 +141,7 @@ int sgx_view_create(sgx_ctx *c, uint32_t viewport_frames, sgx_view **out)
         sgx_view_destroy(v);
         return rc;
     }
+    c->views.push_back(v);   // sgx_destroy(ctx) detaches the views still alive: their calls then fail instead of reading freed memory
     *out = v;
     return SGX_OK;
 }
@@ -143,6 +152,9 @@ void sgx_view_destroy(sgx_view *v)
     if (v->ctx) {
         (void)hipSetDevice(v->ctx->device);
         (void)hipStreamSynchronize(v->ctx->stream);
+        auto &vs = v->ctx->views;
+        for (size_t i = 0; i < vs.size(); ++i)
+            if (vs[i] == v) { vs.erase(vs.begin() + (long)i); break; }
     }
     if (v->d_ring) (void)hipFree(v->d_ring);
     if (v->d_palette) (void)hipFree(v->d_palette);
@@ -151,7 +163,7 @@ void sgx_view_destroy(sgx_view *v)
 
 int sgx_view_write_rows(sgx_view *v, const void *d_rows_f16, size_t n_rows, uint32_t *offset_out)
 {
-    if (!v) return SGX_ERR_INVALID_ARG;
+    if (!v || !v->ctx) return SGX_ERR_INVALID_ARG;   // (no context: it was destroyed before this view)
     sgx_ctx *c = v->ctx;
     if (n_rows && !d_rows_f16) { c->err = "sgx_view_write_rows: null buffer"; return SGX_ERR_INVALID_ARG; }
     VIEW_HIP(v, hipSetDevice(c->device));
@@ -172,7 +184,7 @@ int sgx_view_write_rows(sgx_view *v, const void *d_rows_f16, size_t n_rows, uint
 
 int sgx_view_draw(sgx_view *v, uint32_t width, uint32_t height, float *d_rgba_f32)
 {
-    if (!v) return SGX_ERR_INVALID_ARG;
+    if (!v || !v->ctx) return SGX_ERR_INVALID_ARG;
     sgx_ctx *c = v->ctx;
     if (!d_rgba_f32 || width == 0 || height == 0 || height > 65535) { c->err = "sgx_view_draw: bad argument"; return SGX_ERR_INVALID_ARG; }
     VIEW_HIP(v, hipSetDevice(c->device));

@@ -218,7 +218,7 @@ constexpr size_t kLdsBytes = (size_t)(kTwFloats + kWinFloats + kWaves * kPlaneFl
 
 }  // namespace
 
-bool fast4096_supported(const sgx_ctx *c) { return c->W == kW; }
+static_assert(kW == 2048, "fast4096_supported (sgx_internal.hpp) names this window");
 
 hipError_t fast4096_init(sgx_ctx *c)
 {

@@ -147,11 +147,11 @@ __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
                     sa[a] = v.x; sb[a] = v.y;
                 }
             } else {
+                // one channel, every frame its own (s, s) transform (SGX_FLAG_INDEPENDENT_FRAMES; audio_input_list_model.rs:67-69).
+                // (More than two interleaved channels never come here: their pairs are split into planes first and each
+                // plane runs the C2 kernel -- launch_wg.)
 #pragma unroll
-                for (int a = 0; a < 8; ++a) {
-                    const size_t e = (size_t)(tid + 256 * a) * p.C;
-                    sa[a] = s0[e + p.pair_l]; sb[a] = s0[e + p.pair_r];
-                }
+                for (int a = 0; a < 8; ++a) sa[a] = s0[tid + 256 * a];
             }
         }
     };
@@ -217,6 +217,7 @@ __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
         for (int a = 0; a < 8; ++a) {
             er[a] = sa[a] * win[a];
             if (MONO && PAIRING == kPairAdjacentRow) ei[a] = data_second ? sa[a + 1] * win[a] : 0.0f;
+            else if (!MONO && !C2) ei[a] = er[a];   // (s, s)
             else ei[a] = data_second ? sb[a] * win[a] : 0.0f;
         }
         const int col = tid;                           // pass-3 / output column of this thread

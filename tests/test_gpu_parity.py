@@ -40,6 +40,12 @@ def to_dev(torch, a):
     return torch.from_numpy(np.ascontiguousarray(a, np.float32)).cuda().reshape(-1)
 
 
+def has_variants():
+    """make VARIANTS=1 builds the superseded A/B kernels too (wave-per-transform, packed, first 16384-point design)"""
+    from spectrogram_rs_amd import _lib
+    return b"+variants" in _lib.load().sgx_version()
+
+
 # ---- the transform -----------------------------------------------------------------------------
 
 @pytest.mark.parametrize("variant", ["default", "packed", "wave", "generic"])
@@ -49,6 +55,11 @@ def test_stft_batch_matches_oracle(torch_cuda, mags_err, variant, channels):
     # twin, the wave-per-transform kernel, and the generic power-of-two kernel
     torch = torch_cuda
     kw = {"default": {}, "packed": {"packed_kernel": True}, "wave": {"wave_kernel": True}, "generic": {"force_generic": True}}[variant]
+    if variant in ("packed", "wave") and not has_variants():
+        from spectrogram_rs_amd import SgxError
+        with pytest.raises(SgxError, match="VARIANTS=1"):   # the default build leaves the superseded kernels out and says so
+            engine(window_samples=W, hop_samples=H, channels=channels, **kw)
+        pytest.skip("superseded A/B kernel: not in the default build (make VARIANTS=1)")
     eng = engine(window_samples=W, hop_samples=H, channels=channels, **kw)
     assert eng.info.stft_kernel == {"default": 2, "packed": 3, "wave": 1, "generic": 0}[variant]
     n = W + H * 130 + 77
@@ -191,7 +202,7 @@ def test_short_ragged_and_empty_inputs(torch_cuda):
     assert np.array_equal(part, full[3:5])
     assert eng.stft_batch(to_dev(torch, pcm), first_frame=99).shape[0] == 0
     # mono: two frames share a transform, paired by GLOBAL index -- any sub-range gives the same bytes
-    for kw in (dict(), dict(wave_kernel=True), dict(packed_kernel=True)):
+    for kw in (dict(), dict(wave_kernel=True), dict(packed_kernel=True)) if has_variants() else (dict(),):
         mono = engine(window_samples=W, hop_samples=H, channels=1, **kw)
         m = to_dev(torch, oracle.white_noise(W + 12 * H, seed=6))
         full = mono.stft_batch(m)
@@ -348,8 +359,8 @@ def test_full_size_properties(torch_cuda, mags_err):
     assert np.array_equal(pcm[n - 512:].cpu().numpy(), oracle.white_noise(512, first=n - 512))
     mags = eng.stft_batch(pcm)
     assert mags.shape == (F, 1, M, 2) and bool(torch.isfinite(mags).all())
-    # sampled frames against the oracle (t = i*977 mod F)
-    ts = [(i * 977) % F for i in range(64)]
+    # 1 024 sampled frames against the oracle, t = i*977 mod F
+    ts = [(i * 977) % F for i in range(1024)]
     host = pcm.cpu().numpy()
     ref = np.stack([oracle.fft_process(np.stack([host[t * H:t * H + W]] * 2, 1), W) for t in ts])
     got = mags[ts, 0].cpu().numpy()
@@ -376,6 +387,46 @@ def test_full_size_properties(torch_cuda, mags_err):
     words_lo, c_lo = lo.numel(), eng.checksum(lo)
     del lo
     hi = eng.stft_batch(pcm, first_frame=F // 2)
+    assert (c_lo + eng.checksum(hi, base_word=words_lo)) % (1 << 64) == a
+
+
+@pytest.mark.parametrize("interp", [1, 0])
+def test_full_size_pixel_properties(torch_cuda, gradients, interp):
+    # BASELINE config 3 at its own size: 1e6 frames of the same stream -> 1024 log rows -> Viridis RGBA (4.1 GB), fused kernel;
+    # cosine (what BASELINE names) and cubic (what the reference runs)
+    torch = torch_cuda
+    F = 1_000_000
+    eng = engine(window_samples=W, hop_samples=H, channels=1, interp=interp, gradient="viridis")
+    assert eng.info.render_path & 1, "the fused PCM-to-pixel kernel must be the one that runs"
+    pcm = eng.white_noise((F - 1) * H + W)
+    px = eng.render_batch(pcm)
+    assert px.shape == (F, 1, R, 4) and px.dtype == torch.uint8
+    # 1 024 sampled columns, t = i*977 mod F: (a) stage-wise bit-exact -- the oracle's pixel stage over the magnitudes the
+    # engine itself computes for those frames; (b) end to end against the oracle's own float32 transform: a pixel whose
+    # level sits on a LUT boundary may move one step, nothing else may happen
+    ts = [(i * 977) % F for i in range(1024)]
+    got = px[ts, 0].cpu().numpy()
+    host = pcm.cpu().numpy()
+    own_mags = np.concatenate([eng.stft_batch(pcm, first_frame=t, max_frames=1).cpu().numpy()[:, 0] for t in ts[:128]])
+    assert np.array_equal(got[:128], oracle.render_columns(own_mags, SR, gradients["viridis"], interp=interp))
+    ref_mags = np.stack([oracle.fft_process(np.stack([host[t * H:t * H + W]] * 2, 1), W) for t in ts])
+    ref = oracle.render_columns(ref_mags, SR, gradients["viridis"], interp=interp)
+    lut = {tuple(c): i for i, c in enumerate(gradients["viridis"])}
+    diff = np.argwhere((got != ref).any(axis=2))
+    steps = [abs(lut[tuple(got[a, b, :3])] - lut[tuple(ref[a, b, :3])]) for a, b in diff]
+    assert len(diff) <= 2e-3 * got.shape[0] * R and (not steps or max(steps) <= 1), (len(diff), max(steps or [0]))
+    assert (got[..., 3] == 255).all()
+    del host
+    # determinism and shard-independence of the bytes
+    a = eng.checksum(px)
+    del px
+    again = eng.render_batch(pcm)
+    assert eng.checksum(again) == a
+    del again
+    lo = eng.render_batch(pcm, first_frame=0, max_frames=F // 2 + 1)    # an odd split: the boundary cuts a mono frame pair
+    words_lo, c_lo = lo.numel() // 4, eng.checksum(lo)
+    del lo
+    hi = eng.render_batch(pcm, first_frame=F // 2 + 1)
     assert (c_lo + eng.checksum(hi, base_word=words_lo)) % (1 << 64) == a
 
 
@@ -838,11 +889,17 @@ def test_continuous_gradients_through_a_callback(torch_cuda):
         oracle.set_gradient_fn(None)
 
 
-@pytest.mark.parametrize("name,stereo", [("red_yellow_blue", True), ("spectral", True), ("purple_orange", True), ("reds", False), ("greys", False)])
-def test_builtin_colorbrewer_schemes(torch_cuda, name, stereo):
-    # the reference's first list entry is a diverging ColorBrewer gradient (colorscheme.rs:130): the library evaluates
-    # colorous' B-spline gradients itself (anchors from ColorBrewer, d3's interpolateRgbBasis); bytes equal the oracle
-    # driving the Python restatement of the same spline through its callback, mono and diverging rule alike
+@pytest.mark.parametrize("name,stereo", [("red_yellow_blue", True), ("red_blue", True), ("spectral", True), ("red_yellow_green", True),
+                                         ("pink_green", True), ("purple_orange", True), ("cividis", False), ("cubehelix", False),
+                                         ("turbo", False), ("cool", False), ("reds", False), ("blues", False), ("greens", False),
+                                         ("greys", False), ("oranges", False)])
+def test_builtin_continuous_schemes(torch_cuda, name, stereo):
+    # every continuous entry of default_color_schemes (colorscheme.rs:129-149; the four 256-entry ramps have their own
+    # tests): the library evaluates colorous' B-spline gradients (anchors from ColorBrewer, d3's interpolateRgbBasis), the
+    # Turbo / Cividis polynomials and the cubehelix interpolations (Cube-helix, Cool) itself.  The pixel arithmetic is
+    # checked against the oracle; the COLOUR function the oracle is handed is this package's Python restatement of the
+    # same published formula -- restatement against restatement, which pins the engine's thresholding of a gradient and
+    # nothing about colorous (unvendored).
     torch = torch_cuda
     from spectrogram_rs_amd import ColorScheme
     from spectrogram_rs_amd.colorscheme import CONTINUOUS, default_color_schemes

@@ -94,3 +94,27 @@ def test_default_widget_mirror(torch_cuda):
     w.set_sample_rate(44100)
     assert w.engine.W == 2205 and w.texture.offset == 0
     assert w.render(16, 16).shape == (16, 16, 4)
+
+
+def test_a_view_that_outlives_its_context_fails_cleanly(torch_cuda):
+    # C and Rust callers have no weakref list doing the ordering for them: sgx_destroy(ctx) detaches the views still alive,
+    # whose calls then answer SGX_ERR_INVALID_ARG instead of reading freed memory; destroying them afterwards is fine
+    import ctypes as C
+
+    from spectrogram_rs_amd import _lib
+    torch = torch_cuda
+    lib = _lib.load()
+    cfg = _lib.sgx_config()
+    lib.sgx_config_init(C.byref(cfg))
+    cfg.sample_rate, cfg.window_samples, cfg.hop_samples, cfg.channels = 48000.0, 64, 16, 2
+    ctx, view = C.c_void_p(), C.c_void_p()
+    assert lib.sgx_create(C.byref(cfg), C.byref(ctx)) == 0
+    assert lib.sgx_view_create(ctx, 8, C.byref(view)) == 0
+    rows = torch.zeros((2, 63, 2), dtype=torch.float16, device="cuda")
+    off = C.c_uint32(0)
+    assert lib.sgx_view_write_rows(view, C.c_void_p(rows.data_ptr()), 2, C.byref(off)) == 0 and off.value == 2
+    lib.sgx_destroy(ctx)                 # the view is still alive
+    out = torch.zeros((4, 4, 4), dtype=torch.float32, device="cuda")
+    assert lib.sgx_view_write_rows(view, C.c_void_p(rows.data_ptr()), 2, C.byref(off)) == _lib.SGX_ERR_INVALID_ARG
+    assert lib.sgx_view_draw(view, 4, 4, C.c_void_p(out.data_ptr())) == _lib.SGX_ERR_INVALID_ARG
+    lib.sgx_view_destroy(view)

@@ -159,14 +159,15 @@ def test_mixed_radix_plan_and_block_index_arithmetic_for_every_supported_length(
 
 
 def test_default_color_schemes_follow_the_reference_list():
-    # colorscheme.rs:125-151: 19 entries; 17 are evaluated by this package (Cubehelix and Cool need colorous' own
-    # eval_continuous), in the reference's order, the diverging ones as stereo schemes on a black background
+    # colorscheme.rs:125-151: the 19 entries in the reference's order, every one a built-in of the engine, the diverging
+    # ones as stereo schemes on a black background
     from spectrogram_rs_amd.colorscheme import CONTINUOUS, default_color_schemes
     ds = default_color_schemes()
     assert [d.name for d in ds] == ["Blue-Yellow-Red (Stereo)", "Magma", "Viridis", "Blue-Red (Stereo)", "Spectral (Stereo)",
                                     "Green-Yellow-Red (Stereo)", "Green-Pink (Stereo)", "Orange-Purple (Stereo)", "Inferno", "Plasma",
-                                    "Cividis", "Turbo", "Reds", "Blues", "Greens", "Greys", "Oranges"]
-    assert [d.is_stereo for d in ds] == [True, False, False, True, True, True, True, True] + [False] * 9
+                                    "Cividis", "Cube-helix", "Turbo", "Cool", "Reds", "Blues", "Greens", "Greys", "Oranges"]
+    assert [d.is_stereo for d in ds] == [True, False, False, True, True, True, True, True] + [False] * 11
+    assert all(d.builtin is not None for d in ds)
     assert all(d.background() == (0, 0, 0) for d in ds if d.is_stereo)
     # the spline passes near (not through) its interior anchors and exactly through the reflected ends
     ryb = CONTINUOUS["red_yellow_blue"]
@@ -181,11 +182,31 @@ def test_default_color_schemes_follow_the_reference_list():
 def test_builtin_gradient_eval_matches_the_python_restatement():
     # the C++ built-in (csrc/sgx_api.hip: brewer_eval) and colorscheme._basis_gradient are the same arithmetic
     import numpy as np
-    from spectrogram_rs_amd.colorscheme import BREWER, CONTINUOUS
+    from spectrogram_rs_amd.colorscheme import BREWER, CLOSED_FORM, CONTINUOUS
     from spectrogram_rs_amd.engine import builtin_gradient_eval
-    for name in BREWER:
+    assert set(CLOSED_FORM) == {"turbo", "cividis", "cubehelix", "cool", "warm"}
+    for name in BREWER + CLOSED_FORM:
         for t in list(np.linspace(-0.05, 1.05, 1501)) + [float("nan")]:
             assert builtin_gradient_eval(name, t) == CONTINUOUS[name](t), (name, t)
+
+
+def test_cubehelix_default_is_the_curve_matplotlib_traces():
+    # colorscheme.rs:141 CUBEHELIX = d3's interpolateCubehelixDefault: (h, s, l) from (300, 0.5, 0) to (-240, 0.5, 1),
+    # hue linear without shortest-arc.  That is Green's (2011) helix with start 0.5, -1.5 rotations, hue 1, gamma 1 --
+    # the function matplotlib's `cubehelix` colormap samples -- an independent source for the default parameters.
+    import matplotlib._cm as _cm
+    import numpy as np
+    from spectrogram_rs_amd.engine import builtin_gradient_eval
+    fns = _cm.cubehelix(gamma=1.0, s=0.5, r=-1.5, h=1.0)
+    ts = np.linspace(0.0, 1.0, 2049)
+    want = np.stack([np.clip(np.floor(255.0 * np.asarray(fns[k](ts), np.float64) + 0.5), 0, 255) for k in ("red", "green", "blue")], 1)
+    got = np.array([builtin_gradient_eval("cubehelix", float(t)) for t in ts], np.float64)
+    d = np.abs(got - want)
+    assert d.max() <= 1 and (d > 0).mean() < 2e-3, (d.max(), (d > 0).mean())   # same curve; a byte may sit on a rounding tie
+    assert builtin_gradient_eval("cubehelix", 0.0) == (0, 0, 0) and builtin_gradient_eval("cubehelix", 1.0) == (255, 255, 255)
+    # Cool / Warm meet at t = 1 (d3's rainbow is warm(2t) then cool(2 - 2t)): (h, s, l) = (80, 1.5, 0.8)
+    assert builtin_gradient_eval("cool", 1.0) == builtin_gradient_eval("warm", 1.0)
+    assert builtin_gradient_eval("cool", 0.0) == (110, 64, 170) and builtin_gradient_eval("warm", 0.0) == (110, 64, 170)
 
 
 def test_integration_md_shows_the_binding_files_verbatim():

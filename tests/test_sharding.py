@@ -1,4 +1,4 @@
-"""N > 1 path on CPU: world_size-2 gloo.  Each rank computes the pixel columns of its own frame
+"""N > 1 path on CPU: gloo, world sizes 2, 3 and 8.  Each rank computes the pixel columns of its own frame
 range (with the CPU oracle standing in for the GPU) from its own halo-padded slice of the stream;
 the gathered image must equal the single-process result bit for bit."""
 import os
@@ -99,7 +99,9 @@ def _worker(rank, world, port, total_frames, out_path):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,total", [(2, 23), (2, 1), (3, 10)])
+# (8, 45): 23 frame pairs over 8 ranks -> seven ranks of 6 frames (two rounds of the 5-column gather) and a last one of 3 (one
+# round): uneven counts, a total not divisible by 16, one rank with fewer rounds than the others.  (8, 5): five ranks empty.
+@pytest.mark.parametrize("world,total", [(2, 23), (2, 1), (3, 10), (8, 45), (8, 5)])
 def test_gloo_sharded_columns_equal_single_process(tmp_path, world, total):
     import torch.multiprocessing as mp
 
