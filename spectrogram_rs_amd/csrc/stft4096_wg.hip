@@ -59,16 +59,18 @@ __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
     float2 *buf = reinterpret_cast<float2 *>(smem_raw);
     float2 *tw2 = buf + kBufComplex;
 
-    uint2 *pal = reinterpret_cast<uint2 *>(tw2 + 256);          // RENDER only: [256] {threshold, RGBA} (pixel_for)
+    float *pal_thr = reinterpret_cast<float *>(tw2 + 256);      // RENDER only: [256] thresholds, [256] RGBA words (pixel_for)
+    uint32_t *pal_rgba = reinterpret_cast<uint32_t *>(pal_thr + 256);
 
     const int tid = threadIdx.x;
     tw2[tid] = p.tw2[tid];
     uint32_t row_words[4] = {0u, 0u, 0u, 0u};  // RENDER: the table words of this thread's rows tid + 256 i
     if (RENDER) {
-        pal[tid] = make_uint2(__float_as_uint(tid < 255 ? p.lut_thr[tid] : __builtin_nanf("")), *reinterpret_cast<const uint32_t *>(&p.lut_rgba[tid]));
+        pal_thr[tid] = tid < 255 ? p.lut_thr[tid] : __builtin_nanf("");
+        pal_rgba[tid] = *reinterpret_cast<const uint32_t *>(&p.lut_rgba[tid]) | 0xff000000u;   // alpha = 1.0 (colorscheme.rs:68)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            if ((uint32_t)tid + 256u * i < p.R) row_words[i] = p.rows[tid + 256 * i];
+            if ((uint32_t)tid + 256u * i < p.n_rows_b) row_words[i] = p.rows[tid + 256 * i];
     }
 
     // per-thread constants, kept in registers for the life of the (persistent) workgroup
@@ -274,7 +276,11 @@ __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
 #ifndef SGX_ABL_NOFFT
         fft16(xr, xi);
 #endif
-        if (job + 1 < job_end) fetch(job + 1, true);  // ahead of this transform's stores (see above)
+        // ahead of this transform's stores (see above).  The fused pixel path's only stores are the pixels of its row pass: a
+        // window that is loaded whole (16 registers) is requested just in front of that pass instead of here, so that it is not
+        // live through the sample pass (the stereo kernel: 20 -> 12 bytes of scratch per lane)
+        constexpr bool kLateFetch = RENDER && !(MONO && PAIRING == kPairAdjacentRow && kSlideWindow);
+        if (!kLateFetch && job + 1 < job_end) fetch(job + 1, true);
         if (RENDER) __builtin_amdgcn_s_setprio(1);  // the pixel passes are long: 3 only from the row pass (the pixel stores) on
         else __builtin_amdgcn_s_setprio(3);
         lds_barrier();  // everyone has read image 2
@@ -341,11 +347,12 @@ __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
             if (p.interp == SGX_INTERP_COSINE) sample_pass<true>(p, m2, vbuf, tid);
             else sample_pass<false>(p, m2, vbuf, tid);
             lds_barrier();
-            uchar4 *rgba = reinterpret_cast<uchar4 *>(p.rgba);
-            uchar4 *dst_a = rgba + ((size_t)(have_first ? f0 : 0) * p.pairs + p.pair) * (size_t)p.R;
-            uchar4 *dst_b = rgba + ((size_t)f1 * p.pairs + p.pair) * (size_t)p.R;
+            uint32_t *rgba = reinterpret_cast<uint32_t *>(p.rgba);
+            uint32_t *dst_a = rgba + ((size_t)(have_first ? f0 : 0) * p.pairs + p.pair) * (size_t)p.R;
+            uint32_t *dst_b = rgba + ((size_t)f1 * p.pairs + p.pair) * (size_t)p.R;
+            if (kLateFetch && job + 1 < job_end) fetch(job + 1, true);
             __builtin_amdgcn_s_setprio(3);
-            row_pass<MONO>(p, row_words, vbuf, dst_a, dst_b, have_first, have_second, pal, tid);
+            row_pass<MONO>(p, row_words, vbuf, dst_a, dst_b, have_first, have_second, pal_thr, pal_rgba, tid);
         }
     }
 }
@@ -396,28 +403,46 @@ hipError_t wg4096_init(sgx_ctx *c, void **out)
     for (int q = 0; q < 16; ++q)
         for (int t0 = 0; t0 < 16; ++t0) tw2[q * 16 + t0] = unit(t0 * q, 256);
 
-    // packed tables of the fused pixel path: 4 B per row, 8 B per sample (the kernel re-derives
-    // mu^2, mu^3 and 1 - o' with the same single-rounded operations the host table holds)
-    std::vector<uint32_t> rows(c->tab.rows.size());
-    std::vector<PackedSample> samples(c->tab.samples.size());
-    // the interpolated samples of a column sit in LDS behind the column itself
-    bool fusable = c->tab.samples.size() <= (size_t)kMaxFusedSamples && c->tab.rows.size() <= 1024;
+    // packed tables of the fused pixel path (stft4096_wg.hpp: PackedSample, Params::rows): one work item per sample in
+    // lin_space order, 8 B each (the kernel re-derives mu^2, mu^3 and 1 - o' with the same single-rounded operations the
+    // host table holds), a slot in LDS per item -- an odd number of them per row where the count is even and at least 4
+    // (a pad item) -- and a 4-byte word per row
+    std::vector<uint32_t> rows;
+    std::vector<PackedSample> samples;
+    bool fusable = c->tab.rows.size() <= 1024 && c->M == (uint32_t)kM;
     const int32_t last = (int32_t)c->M - 1;
-    for (size_t i = 0; i < rows.size(); ++i) {
-        const auto &r = c->tab.rows[i];
-        if (r.count >= 65536 || r.first >= 65536) fusable = false;
-        rows[i] = (r.first & 0xffffu) | ((r.count & 0xffffu) << 16);
+    uint32_t slot = 0;
+    for (size_t py = 0; py < c->tab.rows.size() && fusable; ++py) {
+        const auto &r = c->tab.rows[py];
+        if (r.count == 0 || r.count >= 1024) { fusable = false; break; }
+        rows.push_back((slot & 0xfffu) | (r.count << 12) | ((uint32_t)py << 22));
+        for (uint32_t i = 0; i < r.count; ++i) {
+            const auto &se = c->tab.samples[r.first + i];
+            const int32_t x1 = se.i0;
+            // interior: no tap of this sample is clamped at either end of the spectrum
+            const bool interior = c->cfg.interp == SGX_INTERP_COSINE ? !(x1 + 1 > last) : !(x1 < 1 || x1 + 2 > last);
+            if (x1 < 0 || x1 > last) { fusable = false; break; }
+            PackedSample ps;
+            ps.word = (uint32_t)x1 | (interior ? 0u : kItemClamped) | (slot << 12);
+            ps.w = c->cfg.interp == SGX_INTERP_COSINE ? se.w2 : se.w0;
+            samples.push_back(ps);
+            ++slot;
+        }
+        if (r.count >= 4 && (r.count & 1u) == 0) {   // keep the next row's first slot at an odd distance
+            PackedSample pad;
+            pad.word = kItemPad;
+            pad.w = 0.0f;
+            samples.push_back(pad);
+            ++slot;
+        }
     }
-    for (size_t i = 0; i < samples.size(); ++i) {
-        const auto &se = c->tab.samples[i];
-        const int32_t x1 = se.i0;
-        // interior: no tap of this sample is clamped at either end of the spectrum
-        const bool interior = c->cfg.interp == SGX_INTERP_COSINE ? !(x1 + 1 > last) : !(x1 < 1 || x1 + 2 > last);
-        samples[i].i0 = interior ? x1 : ~x1;
-        samples[i].w = c->cfg.interp == SGX_INTERP_COSINE ? se.w2 : se.w0;
-    }
+    // the interpolated samples of a column sit in LDS behind the column itself
+    fusable = fusable && slot <= (uint32_t)kMaxFusedSamples && slot < 4096 && samples.size() < (1u << 24);
     t->fusable = fusable;
     t->n_samples = (uint32_t)samples.size();
+    t->n_rows_b = (uint32_t)rows.size();
+    if (rows.empty()) rows.push_back(0);        // (never read: n_rows_b = 0)
+    if (samples.empty()) { PackedSample pad; pad.word = kItemPad; pad.w = 0.0f; samples.push_back(pad); }
 
     auto up = [](auto **dst, const auto &v) {
         hipError_t e = hipMalloc(reinterpret_cast<void **>(dst), v.size() * sizeof(v[0]));
@@ -527,6 +552,7 @@ hipError_t launch_wg(const sgx_ctx *c, const void *tables, const float *d_pcm, u
             p.rows = t->d_rows;
             p.samples = t->d_samples;
             p.n_samples = t->n_samples;
+            p.n_rows_b = t->n_rows_b;
             p.lut_thr = c->d_lut_thr;
             p.lut_rgba = c->d_lut_rgba;
             p.rgba = d_rgba;

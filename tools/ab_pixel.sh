@@ -1,0 +1,9 @@
+#!/bin/bash
+# usage: [REPS=n] tools/ab_pixel.sh [frames]  -- tools/pixel_bench.py under every library in spectrogram_rs_amd/ab/, interleaved,
+# on the SAME device (device-to-device variance on the pool is larger than most kernel deltas)
+for rep in $(seq 1 ${REPS:-2}); do
+  for lib in spectrogram_rs_amd/ab/*.so; do
+    echo "== $lib (rep $rep)"
+    SGX_LIB=$PWD/$lib timeout -k 10 200 python tools/pixel_bench.py "$@" || exit 1
+  done
+done
