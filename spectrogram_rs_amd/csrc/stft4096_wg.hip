@@ -59,18 +59,16 @@ __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
     float2 *buf = reinterpret_cast<float2 *>(smem_raw);
     float2 *tw2 = buf + kBufComplex;
 
-    float *pal_thr = reinterpret_cast<float *>(tw2 + 256);      // RENDER only: [256] thresholds, [256] RGBA words (pixel_for)
-    uint32_t *pal_rgba = reinterpret_cast<uint32_t *>(pal_thr + 256);
+    uint2 *pal = reinterpret_cast<uint2 *>(tw2 + 256);          // RENDER only: [256] {threshold, RGBA} (pixel_for)
 
     const int tid = threadIdx.x;
     tw2[tid] = p.tw2[tid];
     uint32_t row_words[4] = {0u, 0u, 0u, 0u};  // RENDER: the table words of this thread's rows tid + 256 i
     if (RENDER) {
-        pal_thr[tid] = tid < 255 ? p.lut_thr[tid] : __builtin_nanf("");
-        pal_rgba[tid] = *reinterpret_cast<const uint32_t *>(&p.lut_rgba[tid]) | 0xff000000u;   // alpha = 1.0 (colorscheme.rs:68)
+        pal[tid] = make_uint2(__float_as_uint(tid < 255 ? p.lut_thr[tid] : __builtin_nanf("")), *reinterpret_cast<const uint32_t *>(&p.lut_rgba[tid]));
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            if ((uint32_t)tid + 256u * i < p.n_rows_b) row_words[i] = p.rows[tid + 256 * i];
+            if ((uint32_t)tid + 256u * i < p.R) row_words[i] = p.rows[tid + 256 * i];
     }
 
     // per-thread constants, kept in registers for the life of the (persistent) workgroup
@@ -134,19 +132,25 @@ __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
                     sa[8] = second ? s0[tid + 256 * 8] : 0.0f;
                 }
             } else {
-                const float *s1 = second ? p.pcm + fb * p.H : s0;
+                // (a uniform base in a buffer descriptor + one 32-bit lane offset: a per-lane 64-bit pointer kept across the loop is
+                // what the fused variants of this path spilled -- and its reload is a vector-memory load waited for with vmcnt(0))
+                const __amdgpu_buffer_rsrc_t r0 = pcm_rsrc(s0), r1 = pcm_rsrc(second ? p.pcm + fb * p.H : s0);
 #pragma unroll
-                for (int a = 0; a < 8; ++a) { sa[a] = s0[tid + 256 * a]; sb[a] = s1[tid + 256 * a]; }
+                for (int a = 0; a < 8; ++a) {
+                    sa[a] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r0, tid * 4, 1024 * a, 0));
+                    sb[a] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r1, tid * 4, 1024 * a, 0));
+                }
             }
         } else {
             const float *s0 = p.pcm + (p.first_frame + job) * p.H * p.C;
             if (C2) {
                 // (a sliding register window like the mono one was tried here: stereo input is not traffic-bound and
                 // the extra live registers cost more than the saved row loads)
+                const __amdgpu_buffer_rsrc_t r0 = pcm_rsrc(s0);
 #pragma unroll
                 for (int a = 0; a < 8; ++a) {
-                    const float2 v = reinterpret_cast<const float2 *>(s0)[tid + 256 * a];
-                    sa[a] = v.x; sb[a] = v.y;
+                    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r0, tid * 8, 2048 * a, 0);
+                    sa[a] = __uint_as_float(v.x); sb[a] = __uint_as_float(v.y);
                 }
             } else {
                 // one channel, every frame its own (s, s) transform (SGX_FLAG_INDEPENDENT_FRAMES; audio_input_list_model.rs:67-69).
@@ -276,11 +280,7 @@ __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
 #ifndef SGX_ABL_NOFFT
         fft16(xr, xi);
 #endif
-        // ahead of this transform's stores (see above).  The fused pixel path's only stores are the pixels of its row pass: a
-        // window that is loaded whole (16 registers) is requested just in front of that pass instead of here, so that it is not
-        // live through the sample pass (the stereo kernel: 20 -> 12 bytes of scratch per lane)
-        constexpr bool kLateFetch = RENDER && !(MONO && PAIRING == kPairAdjacentRow && kSlideWindow);
-        if (!kLateFetch && job + 1 < job_end) fetch(job + 1, true);
+        if (job + 1 < job_end) fetch(job + 1, true);  // ahead of this transform's stores (see above)
         if (RENDER) __builtin_amdgcn_s_setprio(1);  // the pixel passes are long: 3 only from the row pass (the pixel stores) on
         else __builtin_amdgcn_s_setprio(3);
         lds_barrier();  // everyone has read image 2
@@ -347,12 +347,11 @@ __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
             if (p.interp == SGX_INTERP_COSINE) sample_pass<true>(p, m2, vbuf, tid);
             else sample_pass<false>(p, m2, vbuf, tid);
             lds_barrier();
-            uint32_t *rgba = reinterpret_cast<uint32_t *>(p.rgba);
-            uint32_t *dst_a = rgba + ((size_t)(have_first ? f0 : 0) * p.pairs + p.pair) * (size_t)p.R;
-            uint32_t *dst_b = rgba + ((size_t)f1 * p.pairs + p.pair) * (size_t)p.R;
-            if (kLateFetch && job + 1 < job_end) fetch(job + 1, true);
+            uchar4 *rgba = reinterpret_cast<uchar4 *>(p.rgba);
+            uchar4 *dst_a = rgba + ((size_t)(have_first ? f0 : 0) * p.pairs + p.pair) * (size_t)p.R;
+            uchar4 *dst_b = rgba + ((size_t)f1 * p.pairs + p.pair) * (size_t)p.R;
             __builtin_amdgcn_s_setprio(3);
-            row_pass<MONO>(p, row_words, vbuf, dst_a, dst_b, have_first, have_second, pal_thr, pal_rgba, tid);
+            row_pass<MONO>(p, row_words, vbuf, dst_a, dst_b, have_first, have_second, pal, tid);
         }
     }
 }
@@ -403,46 +402,37 @@ hipError_t wg4096_init(sgx_ctx *c, void **out)
     for (int q = 0; q < 16; ++q)
         for (int t0 = 0; t0 < 16; ++t0) tw2[q * 16 + t0] = unit(t0 * q, 256);
 
-    // packed tables of the fused pixel path (stft4096_wg.hpp: PackedSample, Params::rows): one work item per sample in
-    // lin_space order, 8 B each (the kernel re-derives mu^2, mu^3 and 1 - o' with the same single-rounded operations the
-    // host table holds), a slot in LDS per item -- an odd number of them per row where the count is even and at least 4
-    // (a pad item) -- and a 4-byte word per row
-    std::vector<uint32_t> rows;
+    // packed tables of the fused pixel path: 4 B per row, 8 B per LDS slot (the kernel re-derives mu^2, mu^3 and 1 - o' with the
+    // same single-rounded operations the host table holds).  Slots = the rows' samples in lin_space order; after a row whose
+    // count is even and at least 4 comes one PAD slot -- a repeat of the row's last sample that no row reads -- so that the next
+    // row starts an odd number of slots on: the row pass reads slot first + i of 32 consecutive rows at once, and an even stride
+    // of 8-byte slots folds those 32 addresses onto a few bank pairs (stride 8: four of them).  Host table only: the kernel is
+    // the one of round 2.  SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 0.21 -> 0.13 (profiles/r03_pixel_ab.txt).
+    std::vector<uint32_t> rows(c->tab.rows.size());
     std::vector<PackedSample> samples;
-    bool fusable = c->tab.rows.size() <= 1024 && c->M == (uint32_t)kM;
+    bool fusable = c->tab.rows.size() <= 1024;
     const int32_t last = (int32_t)c->M - 1;
-    uint32_t slot = 0;
-    for (size_t py = 0; py < c->tab.rows.size() && fusable; ++py) {
-        const auto &r = c->tab.rows[py];
-        if (r.count == 0 || r.count >= 1024) { fusable = false; break; }
-        rows.push_back((slot & 0xfffu) | (r.count << 12) | ((uint32_t)py << 22));
-        for (uint32_t i = 0; i < r.count; ++i) {
-            const auto &se = c->tab.samples[r.first + i];
-            const int32_t x1 = se.i0;
-            // interior: no tap of this sample is clamped at either end of the spectrum
-            const bool interior = c->cfg.interp == SGX_INTERP_COSINE ? !(x1 + 1 > last) : !(x1 < 1 || x1 + 2 > last);
-            if (x1 < 0 || x1 > last) { fusable = false; break; }
-            PackedSample ps;
-            ps.word = (uint32_t)x1 | (interior ? 0u : kItemClamped) | (slot << 12);
-            ps.w = c->cfg.interp == SGX_INTERP_COSINE ? se.w2 : se.w0;
-            samples.push_back(ps);
-            ++slot;
-        }
-        if (r.count >= 4 && (r.count & 1u) == 0) {   // keep the next row's first slot at an odd distance
-            PackedSample pad;
-            pad.word = kItemPad;
-            pad.w = 0.0f;
-            samples.push_back(pad);
-            ++slot;
-        }
+    auto packed = [&](const SampleEntry &se) {
+        const int32_t x1 = se.i0;
+        // interior: no tap of this sample is clamped at either end of the spectrum
+        const bool interior = c->cfg.interp == SGX_INTERP_COSINE ? !(x1 + 1 > last) : !(x1 < 1 || x1 + 2 > last);
+        PackedSample ps;
+        ps.i0 = interior ? x1 : ~x1;
+        ps.w = c->cfg.interp == SGX_INTERP_COSINE ? se.w2 : se.w0;
+        return ps;
+    };
+    for (size_t i = 0; i < rows.size(); ++i) {
+        const auto &r = c->tab.rows[i];
+        if (r.count >= 65536 || samples.size() >= 65536) fusable = false;
+        rows[i] = ((uint32_t)samples.size() & 0xffffu) | ((r.count & 0xffffu) << 16);
+        for (uint32_t j = 0; j < r.count; ++j) samples.push_back(packed(c->tab.samples[r.first + j]));
+        if (r.count >= 4 && (r.count & 1u) == 0) samples.push_back(samples.back());   // the pad slot
     }
     // the interpolated samples of a column sit in LDS behind the column itself
-    fusable = fusable && slot <= (uint32_t)kMaxFusedSamples && slot < 4096 && samples.size() < (1u << 24);
+    fusable = fusable && samples.size() <= (size_t)kMaxFusedSamples;
+    if (samples.empty()) samples.push_back(PackedSample{0, 0.0f});
     t->fusable = fusable;
     t->n_samples = (uint32_t)samples.size();
-    t->n_rows_b = (uint32_t)rows.size();
-    if (rows.empty()) rows.push_back(0);        // (never read: n_rows_b = 0)
-    if (samples.empty()) { PackedSample pad; pad.word = kItemPad; pad.w = 0.0f; samples.push_back(pad); }
 
     auto up = [](auto **dst, const auto &v) {
         hipError_t e = hipMalloc(reinterpret_cast<void **>(dst), v.size() * sizeof(v[0]));
@@ -552,7 +542,6 @@ hipError_t launch_wg(const sgx_ctx *c, const void *tables, const float *d_pcm, u
             p.rows = t->d_rows;
             p.samples = t->d_samples;
             p.n_samples = t->n_samples;
-            p.n_rows_b = t->n_rows_b;
             p.lut_thr = c->d_lut_thr;
             p.lut_rgba = c->d_lut_rgba;
             p.rgba = d_rgba;
