@@ -226,6 +226,8 @@ hipError_t run_stft(const sgx_ctx *c, const float *d_pcm, uint32_t channels, uin
     // W = 8192: the four-residue kernel, (l, r) streams and mono frame pairs alike (independent mono frames: generic)
     if (c->stft_kernel == 5 && (channels != 1 || !(c->cfg.flags & SGX_FLAG_INDEPENDENT_FRAMES)))
         return sgx::launch_stft_q16384(c, c->d_q16k, d_pcm, channels, pairs, first, n, total, d_mags);
+    if (c->stft_kernel == 8 && (channels != 1 || !(c->cfg.flags & SGX_FLAG_INDEPENDENT_FRAMES)))
+        return sgx::launch_stft_d16384(c, c->d_d16k, d_pcm, channels, pairs, first, n, total, d_mags);
     if (c->stft_kernel == 7 && (channels != 1 || !(c->cfg.flags & SGX_FLAG_INDEPENDENT_FRAMES)))
         return sgx::launch_stft_wg16384(c, c->d_fast_16k, d_pcm, channels, pairs, first, n, total, d_mags);
     if (c->stft_kernel == 6) return sgx::launch_stft_mixed(c, c->d_mix, d_pcm, channels, pairs, first, n, total, d_mags);
@@ -380,6 +382,10 @@ int sgx_create(const sgx_config *cfg, sgx_ctx **out_ctx)
         e = sgx::wg16384_init(c, &c->d_fast_16k);
         if (e != hipSuccess) return bail(SGX_ERR_HIP, std::string("sgx_create: 16384-point kernel tables: ") + hipGetErrorString(e));
         c->stft_kernel = 7;
+    } else if (!(cfg->flags & (SGX_FLAG_FORCE_GENERIC | SGX_FLAG_RESIDUE_16K)) && sgx::d16384_supported(c)) {
+        e = sgx::d16384_init(c, &c->d_d16k);
+        if (e != hipSuccess) return bail(SGX_ERR_HIP, std::string("sgx_create: 16384-point kernel tables: ") + hipGetErrorString(e));
+        c->stft_kernel = 8;
     } else if (!(cfg->flags & SGX_FLAG_FORCE_GENERIC) && sgx::q16384_supported(c)) {
         e = sgx::q16384_init(c, &c->d_q16k);
         if (e != hipSuccess) return bail(SGX_ERR_HIP, std::string("sgx_create: 16384-point kernel tables: ") + hipGetErrorString(e));
@@ -408,6 +414,8 @@ void sgx_destroy(sgx_ctx *c)
     c->d_fast_16k = nullptr;
     sgx::q16384_destroy(c->d_q16k);
     c->d_q16k = nullptr;
+    sgx::d16384_destroy(c->d_d16k);
+    c->d_d16k = nullptr;
     void *ptrs[] = {c->d_window, c->d_twiddle, c->d_rows, c->d_samples, c->d_lut_thr, c->d_alpha_thr,
                     c->d_lut_rgba, c->d_pal_seed, c->d_t_thr, c->d_t_cell, c->d_band_rows, c->d_band_samples, c->d_levels, c->d_ws_mags, c->d_one_in, c->d_one_out, c->d_cksum};
     for (void *p : ptrs)

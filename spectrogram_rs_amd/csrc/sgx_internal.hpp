@@ -83,7 +83,7 @@ struct sgx_ctx {
     uint32_t W = 0, P = 0, M = 0, H = 0, C = 0, pairs = 0, R = 0, sr_u32 = 0, logP = 0;
     int device = 0;
     hipStream_t stream = nullptr;
-    int stft_kernel = 0;  // 0 generic, 1 tuned 4096 wave-per-transform, 2 tuned 4096 workgroup-per-transform (scalar codelets), 3 the same with packed (re, im) arithmetic, 4 Bluestein (2W not a power of two), 5 tuned 16384 (four 4096-point residues), 6 mixed radix (2W = 2^a 3^b 5^c 7^d), 7 tuned 16384, first design (whole transform in LDS)
+    int stft_kernel = 0;  // 0 generic, 1 tuned 4096 wave-per-transform, 2 tuned 4096 workgroup-per-transform (scalar codelets), 3 the same with packed (re, im) arithmetic, 4 Bluestein (2W not a power of two), 5 tuned 16384, second design (four 4096-point residues), 6 mixed radix (2W = 2^a 3^b 5^c 7^d), 7 tuned 16384, first design (whole transform in LDS), 8 tuned 16384, third design (time-decimated lane quads)
 
     sgx::Tables tab;
     sgx::Palette pal;
@@ -105,7 +105,8 @@ struct sgx_ctx {
     void *d_mix = nullptr;         // tables of the mixed-radix (2, 3, 5, 7-smooth lengths) kernel
     void *d_chz = nullptr;         // chirp-z through the mixed-radix kernel's stages (or null: the radix-4 ladder of stft_bluestein.hip)
     void *d_fast_16k = nullptr;    // tables of the 16384-point kernel, first design (one 1024-thread workgroup per transform)
-    void *d_q16k = nullptr;        // tables of the 16384-point kernel, four 4096-point residues (the default)
+    void *d_q16k = nullptr;        // tables of the 16384-point kernel, four 4096-point residues of the output (SGX_FLAG_RESIDUE_16K)
+    void *d_d16k = nullptr;        // tables of the 16384-point kernel, four time-decimated 4096-point transforms per lane quad (the default)
 
     // workspaces (grown on demand, kept)
     float *d_ws_mags = nullptr;
@@ -178,6 +179,11 @@ inline hipError_t wg16384_init(sgx_ctx *, void **) { return hipErrorNotSupported
 inline void wg16384_destroy(void *) {}
 inline hipError_t launch_stft_wg16384(const sgx_ctx *, const void *, const float *, uint32_t, uint32_t, size_t, size_t, size_t, float *) { return hipErrorNotSupported; }
 #endif
+bool d16384_supported(const sgx_ctx *c);
+hipError_t d16384_init(sgx_ctx *c, void **out);
+void d16384_destroy(void *tables);
+hipError_t launch_stft_d16384(const sgx_ctx *c, void *tables, const float *d_pcm, uint32_t channels, uint32_t pairs,
+                              size_t first_frame, size_t n_frames, size_t total_frames, float *d_mags);
 bool q16384_supported(const sgx_ctx *c);
 hipError_t q16384_init(sgx_ctx *c, void **out);
 void q16384_destroy(void *tables);

@@ -1,0 +1,529 @@
+// stft16384_d.hip -- tuned STFT for W = 8192 (P = 16384), third design: ONE 1024-thread workgroup per transform, the transform cut
+// into four 4096-point transforms by decimation in TIME, one per lane of a lane quad, recombined across the quad with DPP.
+// (BASELINE config 4: 16384-point, hop 512, 8 interleaved channels = 4 (l, r) pairs per hop position.)
+//
+// Replaces FastFourierTransform::process (fft.rs:43-99) + the hop loop (audio_transform.rs:34-42).
+//
+// Why.  The second design (stft16384_q.hip) decimates the OUTPUT by four: residues (0, 2) in one pass of a 512-thread workgroup,
+// (1, 3) in a second pass over the same samples.  A lane's 16 output bytes per row are one 8-byte bin of each pass, so the even
+// bins wait in a parked buffer (1.53 x write amplification, 1.88 x total traffic: profiles/r02_hbm_traffic.json), the samples
+// and the window are read twice, and the pass-1 twiddles (a different 128 bytes per lane for each pass) are fetched from L2
+// sixteen times per transform BEHIND the previous pass's stores (vmcnt retires in order).  Decimating the INPUT by four instead,
+//
+//     F[j + 4096 c] = sum_{r < 4} (-i)^{r c} w_16384^{r j} G_r[j],     G_r[j] = sum_{m < 2048} z[4 m + r] w_4096^{m j},
+//     z[n] = (l[n] + i r[n]) hann[n]   (n >= 8192 is the zero padding, fft.rs:65-69: only m < 2048 is non-zero),
+//
+// every G_r is EXACTLY the transform the headline kernel computes (4096 points, 2048 of them non-zero: stft4096_wg.hip), all four
+// are in flight at once in the four lanes of a quad (lane tid = 4 col + r plays thread col of that kernel for residue r), and the
+// quad holds the four consecutive outputs... no: the four outputs j + 4096 c of one j -- kept bins and their partners P - k alike.
+// Consequences:
+//   * a lane reads the samples n = tid + 1024 a, a < 8: every sample once per transform, 1024 consecutive samples per instruction;
+//   * one pass per transform: the pass-1 twiddles w_16384^{q1 tid} (the 4096-point kernel's w_4096^{col q1} times the first part
+//     of the recombination twiddle) and the Hann factors stay in registers for the life of the workgroup: no table traffic at all;
+//   * nothing is parked: after the recombination and the partner exchange every lane holds 8 finished (l, r) bins of one row;
+//   * 139 KB of LDS for the four interleaved images (element (index, r) at 4 index + r: every access pattern of the 4096-point
+//     kernel stays conflict-free with four times the stride), so ONE workgroup per CU, 16 waves = 4 per SIMD.
+//
+//   sample index  n = tid + 1024 a      (a < 8; m = col + 256 a, r = tid & 3)
+//   pass 1  lane (col, r)    : 16-point DFT over a (8 non-zero inputs = two 8-point FFTs) -> q1; twiddle w_16384^{q1 tid}
+//   pass 2  lane (q1, t0, r) : col = t0 + 16 t1; 16-point FFT over t1 -> q2; twiddle w_1024^{q2 (4 t0 + r)}   (LDS, 8 KB)
+//   pass 3  lane (u, r), u = q1 + 16 q2 : 16-point FFT over t0 -> q3: G_r[j] w_16384^{r (j mod 256)}, j = u + 256 q3;
+//           twiddle w_64^{r q3} (LDS) completes w_16384^{r j}
+//   combine radix-4 across the quad (two DPP stages): lane L ends with F[j + 4096 c]: c = {0, 2, 1, 3}[L] in its registers q3 < 8
+//           and 3 - c in its registers q3 >= 8 -- so every lane holds 8 kept bins (k < 8192) and 8 partners, and the partner of
+//           its kept (u, q3) is register 15 - q3 of the SAME lane of quad 256 - u: the 4096-point kernel's exchange, unchanged
+//   split   (fft.rs:81-98) 8 bins per lane: k = {0, 6144, 4096, 2048}[L] + u + 256 qq
+#include <type_traits>
+
+#include "sgx_internal.hpp"
+
+namespace sgx {
+
+namespace d16k {
+
+typedef float f2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float cl_fma(float a, float c, float u) { return fmaf(a, c, u); }
+__device__ __forceinline__ f2v cl_fma(f2v a, float c, f2v u) { return __builtin_elementwise_fma(a, f2v{c, c}, u); }
+
+#include "fft_codelets.inc"
+
+constexpr int kW = 8192, kP = 16384, kM = 8191;
+constexpr int kS1 = 272;                 // row stride of the pass-1 -> pass-2 image [q1][col]   (as stft4096_wg.hpp)
+constexpr int kS2 = 257;                 // row stride of the pass-2 -> pass-3 image [t0][q1 + 16 q2]
+constexpr int kImg = 16 * kS1;           // indices per residue (4352)
+constexpr int kBufComplex = 4 * kImg;    // 17 408 complex = 139 264 B, the four residues interleaved: (index, r) at 4 index + r
+constexpr size_t kLdsBytes = (size_t)(kBufComplex + 1024 + 64) * sizeof(float2);   // + tw2 [q2][t0][r], tw3 [q3][r]
+
+struct Params {
+    const float *pcm;        // MONO: [n] floats; else per-pair planes of (l, r): plane p starts at pcm + p * plane_floats
+    size_t plane_floats;
+    long long sample_base;   // absolute sample index of pcm[0] (the de-interleaved workspace holds a sub-range)
+    const float2 *T1;        // [16][1024]  w_16384^{q1 tid} at [q1][tid]
+    const float2 *T1hi;      // [4][1024][2] the same for q1 = 8 + 2 g + e at [g][tid][e]: a lane reads two of them as one 16-byte word
+    const float2 *tw2;       // [16][16][4] w_1024^{q2 (4 t0 + r)} at [q2][t0][r]
+    const float2 *tw3;       // [16][4]     w_64^{r q3} at [q3][r]
+    const float *win8;       // [2][1024][4] hann[tid + 1024 a] / W at [a / 4][tid][a % 4]   (fft.rs:61; the scale (hypot / 2) (2 / W) = 2^-13 rides along)
+    float *mags;
+    unsigned long long first_frame, n_frames, total_frames, pair_base, n_jobs, jobs_per_block;
+    uint32_t H, pairs;
+};
+
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+__device__ __forceinline__ float2 cmulf(float2 a, float2 b)
+{
+    return make_float2(fmaf(a.x, b.x, -(a.y * b.y)), fmaf(a.x, b.y, a.y * b.x));
+}
+// the value of another lane of the quad
+template <int PERM>
+__device__ __forceinline__ float quad(float v)
+{
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), PERM, 0xf, 0xf, true));
+}
+constexpr int kSwap2 = 0x4E;   // quad_perm [2, 3, 0, 1]
+constexpr int kSwap1 = 0xB1;   // quad_perm [1, 0, 3, 2]
+
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// every global access goes through a raw buffer descriptor: a wave-uniform base (4 SGPRs) + ONE 32-bit lane offset + a scalar
+// offset (no per-lane 64-bit pointers: they are what spills first, and a spill reload is a vector-memory load)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void *base)
+{
+    const unsigned long long a = (unsigned long long)base;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((unsigned long long)hi << 32) | lo), 0, 0x7fffffff, 0x00020000);
+}
+#ifndef D_OUT_AUX
+#define D_OUT_AUX 2   // nt: a write-once stream (same-device A/B: 0.80 -> 0.73 ms per 20 000 transforms)
+#endif
+#ifdef D_ABL_NOSTORE
+#define D_STORE_OK(v) ((v) == 12345.678f)   // ablation builds: (practically) never true, but the value stays live
+#else
+#define D_STORE_OK(v) true
+#endif
+
+template <bool MONO>
+__global__ void __launch_bounds__(1024, 1) stft16384_d_kernel(Params p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2 *buf = reinterpret_cast<float2 *>(smem_raw);
+    float2 *tw2 = buf + kBufComplex;
+    float2 *tw3 = tw2 + 1024;
+
+    const int tid = threadIdx.x;
+    tw2[tid] = p.tw2[tid];
+    if (tid < 64) tw3[tid] = p.tw3[tid];
+
+    // Per-lane constants.  The pass-1 twiddles of q1 < 8 stay in registers for the life of the (persistent) workgroup; those of
+    // q1 >= 8 and the eight Hann factors are requested again for every transform together with its samples (6 x 16 bytes per
+    // lane from L2, ahead of the previous transform's stores): resident, they are live through the three FFT passes and the
+    // recombination, where nothing needs them, and the kernel spilled 7 registers -- window factors, reloaded at the head of the
+    // loop BEHIND the stores.
+    float2 tw1[16];
+#pragma unroll
+    for (int q = 1; q < 16; ++q) tw1[q] = p.T1[q * 1024 + tid];
+    float win[8];
+    {
+        const __amdgpu_buffer_rsrc_t rw = uniform_rsrc(p.win8);
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(rw, 16 * tid, g * (1024 * 16), 0);
+            win[4 * g] = __uint_as_float(w.x); win[4 * g + 1] = __uint_as_float(w.y);
+            win[4 * g + 2] = __uint_as_float(w.z); win[4 * g + 3] = __uint_as_float(w.w);
+        }
+    }
+    const int L = tid & 3;
+    // signs of the two recombination stages (see `combine` below) and the lanes whose value is turned by -i in between
+    const float sA = L < 2 ? 1.0f : -1.0f, sB = (L & 1) ? -1.0f : 1.0f;
+    const bool rot_lo = L == 3, rot_hi = L == 1, odd = (L & 1) != 0;
+    __syncthreads();
+
+    // Software pipeline: the samples of the NEXT transform are requested before this transform's stores: vmcnt retires in issue
+    // order, so a load issued behind the stores would wait for every one of them to be acknowledged.
+    float pl[8], pr[8];
+    struct JobIn { const float *base; bool data_second; };   // base: wave-uniform
+    auto job_in = [&](unsigned long long job) {
+        JobIn j{nullptr, true};
+        if (MONO) {
+            const unsigned long long f = 2 * (p.pair_base + job);
+            j.data_second = f + 1 < p.total_frames;
+            j.base = p.pcm + ((long long)(f * p.H) - p.sample_base);
+        } else {
+            const unsigned long long hop = job / p.pairs;
+            const uint32_t pair = (uint32_t)(job - hop * p.pairs);
+            j.base = p.pcm + (size_t)pair * p.plane_floats + 2 * ((long long)((p.first_frame + hop) * p.H) - p.sample_base);
+        }
+        return j;
+    };
+    const int second_off = MONO ? (int)(p.H * 4) : 0;   // mono: the pair's second frame starts H samples on
+    auto prefetch = [&](const JobIn &j) {
+        const __amdgpu_buffer_rsrc_t rs = uniform_rsrc(j.base);
+        const int sec = j.data_second ? second_off : 0;
+        {
+            const __amdgpu_buffer_rsrc_t rt = uniform_rsrc(p.T1hi), rw = uniform_rsrc(p.win8);
+(void)rt;
+(void)rw;
+        }
+#pragma unroll
+        for (int a = 0; a < 8; ++a) {
+#ifdef D_ABL_NOLOAD
+            pl[a] = (float)(a + 1); pr[a] = (float)tid;
+            (void)rs; (void)sec;
+#else
+            if (MONO) {
+                pl[a] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, 4 * tid, 4096 * a, 0));
+                pr[a] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, 4 * tid, 4096 * a + sec, 0));
+            } else {
+                const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, 8 * tid, 8192 * a, 0);
+                pl[a] = __uint_as_float(v.x); pr[a] = __uint_as_float(v.y);
+            }
+#endif
+        }
+    };
+
+    // The prefetched values are CONSUMED (Hann, fft.rs:53-63: the product is what the next transform starts from) at the END of the
+    // iteration that requested them, behind its stores, in straight-line code: the compiler then waits for them with
+    // `vmcnt(stores issued since)`.  Consumed at the head of the next iteration, the wait sits at the loop header, where the
+    // entry path is merged in and the compiler falls back to vmcnt(0) -- every transform then waits for the previous one's stores
+    // to be acknowledged (measured: 0.93 ms per 20 000 transforms against 0.61 ms without the stores).
+    float er[8], ei[8];
+    auto take = [&](bool data_second) {
+#pragma unroll
+        for (int a = 0; a < 8; ++a) {
+            er[a] = pl[a] * win[a];
+            ei[a] = (MONO && !data_second) ? 0.0f : pr[a] * win[a];
+        }
+
+    };
+    // every workgroup owns a contiguous run of jobs (hop-major: the pairs of one hop position, then the next hop): consecutive hops
+    // share 15/16 of their samples, and this way they are read again through the L2 of the same XCD -- dealt round-robin over the
+    // workgroups they came back from the Infinity Cache every time
+#ifdef D_ROUND_ROBIN
+    const unsigned long long job_begin = blockIdx.x, job_step = gridDim.x;
+    const unsigned long long job_end = p.n_jobs;
+#else
+    const unsigned long long job_begin = (unsigned long long)blockIdx.x * p.jobs_per_block, job_step = 1;
+    const unsigned long long job_end = job_begin + p.jobs_per_block < p.n_jobs ? job_begin + p.jobs_per_block : p.n_jobs;
+#endif
+    JobIn cur = job_in(job_begin < job_end ? job_begin : 0);
+    if (job_begin < job_end) {
+        prefetch(cur);
+        take(cur.data_second);
+    }
+    for (unsigned long long job = job_begin; job < job_end; job += job_step) {
+        long long f0, f1;
+        bool have_first = true, have_second = true;
+        uint32_t pair = 0;
+        if (MONO) {
+            f0 = (long long)(2 * (p.pair_base + job)) - (long long)p.first_frame;
+            f1 = f0 + 1;
+            have_first = f0 >= 0;
+            have_second = f1 < (long long)p.n_frames;
+        } else {
+            f0 = (long long)(job / p.pairs);
+            f1 = f0;
+            pair = (uint32_t)(job - (unsigned long long)f0 * p.pairs);
+        }
+        const bool more = job + job_step < job_end;
+        const JobIn nxt = job_in(more ? job + job_step : job);
+
+        // ---- Hann (fft.rs:53-63) on the prefetched samples; pass 1: 16-point DFT over a, inputs a >= 8 are the zero padding:
+        //      even q1 = FFT8(z), odd q1 = FFT8(z * w_16^a)                                        (as stft4096_wg.hip)
+        float orr[8], oi[8];
+#pragma unroll
+        for (int a = 0; a < 8; ++a) { orr[a] = er[a]; oi[a] = ei[a]; }
+        pretwiddle8_w16(orr, oi);
+        fft8(er, ei);
+        fft8(orr, oi);
+        lds_barrier();  // the previous transform's partner reads are complete
+        {
+            float2 *w1 = buf + tid;   // element (index, r) at 4 index + r = 4 (q kS1 + col) + r = 4 q kS1 + tid
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int pos = FFT8_OUT[j];
+                const float2 ve = make_float2(er[pos], ei[pos]);
+                const float2 vo = make_float2(orr[pos], oi[pos]);
+                w1[4 * (2 * j) * kS1] = j == 0 ? ve : cmulf(ve, tw1[2 * j]);
+                w1[4 * (2 * j + 1) * kS1] = cmulf(vo, tw1[2 * j + 1]);
+            }
+        }
+        lds_barrier();
+
+        // ---- pass 2: lane (q1, t0, r), col = t0 + 16 t1: FFT16 over t1 -> q2, twiddle w_1024^{q2 (4 t0 + r)}
+        float xr[16], xi[16];
+        {
+            const int q1_2 = tid >> 6, low = tid & 63;   // low = 4 t0 + r
+            const float2 *r2 = buf + 4 * q1_2 * kS1 + low;
+#pragma unroll
+            for (int t1 = 0; t1 < 16; ++t1) {
+                const float2 v = r2[64 * t1];
+                xr[t1] = v.x; xi[t1] = v.y;
+            }
+            fft16(xr, xi);
+            lds_barrier();  // everyone has read image 1
+            float2 *w2 = buf + 4 * ((low >> 2) * kS2 + q1_2) + (low & 3);
+            const float2 *tw = tw2 + low;
+#pragma unroll
+            for (int q2 = 0; q2 < 16; ++q2) {
+                const int pos = FFT16_OUT[q2];
+                const float2 v = make_float2(xr[pos], xi[pos]);
+                w2[4 * 16 * q2] = q2 == 0 ? v : cmulf(v, tw[64 * q2]);
+            }
+        }
+        lds_barrier();
+
+        // ---- pass 3: lane (u, r), u = tid >> 2 = q1 + 16 q2: FFT16 over t0 -> q3
+        {
+            const float2 *r3 = buf + tid;
+#pragma unroll
+            for (int t0 = 0; t0 < 16; ++t0) {
+                const float2 v = r3[4 * t0 * kS2];
+                xr[t0] = v.x; xi[t0] = v.y;
+            }
+        }
+        fft16(xr, xi);
+        // ---- the rest of the recombination twiddle, w_64^{r q3}, and the radix-4 recombination across the quad.
+        //      Lane r holds X_r.  Registers q3 < 8 ("lo"):  stage A: lanes 0, 1: X_r + X_{r+2}; lanes 2, 3: X_{r-2} - X_r
+        //        -> E0, E1, O0, O1; lane 3 turns O1 by -i; stage B: lanes 0, 2: own + partner; lanes 1, 3: partner - own
+        //        -> F[j], F[j + 2*4096], F[j + 4096], F[j + 3*4096] in lanes 0, 1, 2, 3.
+        //      Registers q3 >= 8 ("hi"): the same with the roles of the lane halves exchanged (stage A: lanes 0, 1: own - partner;
+        //        lanes 2, 3: own + partner -> O0, O1, E0, E1; lane 1 turns O1; stage B: lanes 0, 2: own - partner; lanes 1, 3: own +
+        //        partner) -> c = 3, 1, 2, 0 in lanes 0, 1, 2, 3: every lane ends with kept bins in one half and partners in the other.
+#pragma unroll
+        for (int q3 = 0; q3 < 16; ++q3) {
+            const int pos = FFT16_OUT[q3];
+            float ar = xr[pos], ai = xi[pos];
+            if (q3 > 0) {
+                const float2 t = tw3[4 * q3 + L];
+                const float br = fmaf(ar, t.x, -(ai * t.y)), bi = fmaf(ar, t.y, ai * t.x);
+                ar = br; ai = bi;
+            }
+            const float pr_ = quad<kSwap2>(ar), pi_ = quad<kSwap2>(ai);
+            float cr, ci;
+            if (q3 < 8) { cr = fmaf(ar, sA, pr_); ci = fmaf(ai, sA, pi_); }
+            else { cr = fmaf(pr_, -sA, ar); ci = fmaf(pi_, -sA, ai); }
+            const bool rot = q3 < 8 ? rot_lo : rot_hi;
+            const float dr = rot ? ci : cr, di = rot ? -cr : ci;
+            const float qr_ = quad<kSwap1>(dr), qi_ = quad<kSwap1>(di);
+            if (q3 < 8) { xr[pos] = fmaf(dr, sB, qr_); xi[pos] = fmaf(di, sB, qi_); }
+            else { xr[pos] = fmaf(qr_, -sB, dr); xi[pos] = fmaf(qi_, -sB, di); }
+        }
+        // odd lanes hold their kept bins in the hi registers: exchange the halves, so that every lane keeps 0..7 and publishes 8..15
+#pragma unroll
+        for (int h = 0; h < 8; ++h) {
+            const int a = FFT16_OUT[h], b = FFT16_OUT[8 + h];
+            const float ar = xr[a], ai = xi[a], br = xr[b], bi = xi[b];
+            xr[a] = odd ? br : ar; xi[a] = odd ? bi : ai;
+            xr[b] = odd ? ar : br; xi[b] = odd ? ai : bi;
+        }
+        lds_barrier();  // everyone has read image 2
+        {
+            float2 *wp = buf + tid;   // slot (h, u, L) at 1024 h + tid
+#pragma unroll
+            for (int h = 0; h < 8; ++h) {
+                const int pos = FFT16_OUT[8 + h];
+                wp[1024 * h] = make_float2(xr[pos], xi[pos]);
+            }
+        }
+        // the next transform's samples, twiddles and window: ahead of this transform's stores, and once the published half of the
+        // spectrum has left its 16 registers
+        if (more) prefetch(nxt);
+        lds_barrier();
+
+        // ---- split + magnitude (fft.rs:81-98).  Kept (u, qq) of lane L pairs with slot h = 7 - qq of lane L of quad 256 - u;
+        //      quad 0 is its own mirror one row up (h = 8 - qq), and its qq = 0 partners are single values of other lanes of the
+        //      quad: lane 2 (k = 4096) <- lane 3's slot 0; lanes 1, 3 (k = 6144, 2048) <- slot 0 of lanes 2, 0
+        const int u = tid >> 2;
+        const float2 *pp = buf + (u == 0 ? 1024 + L : 4 * (256 - u) + L);                       // + 1024 (7 - qq), qq >= 1
+        const float2 *pp0 = buf + (u == 0 ? (L == 2 ? 3 : (L == 1 ? 2 : 0)) : 1024 * 7 + 4 * (256 - u) + L);   // qq = 0
+        const int kbase = (L == 0 ? 0 : (L == 1 ? 6144 : (L == 2 ? 4096 : 2048))) + u;        // bin k = kbase + 256 qq
+        // rows: bin k lives at byte 8 (k - 1) of its row
+        const __amdgpu_buffer_rsrc_t r0 = uniform_rsrc(p.mags + (((size_t)(have_first ? f0 : 0) * p.pairs + pair) * (size_t)kM) * 2);
+        const __amdgpu_buffer_rsrc_t r1 = uniform_rsrc(p.mags + (((size_t)f1 * p.pairs + pair) * (size_t)kM) * 2);
+        // The row is put together in LDS and leaves as 16 bytes per lane, consecutive lanes consecutive addresses: a wave of this
+        // kernel holds 16 consecutive bins of four distant parts of the row, and storing them as they lie -- 8 bytes per lane,
+        // four 128-byte runs per instruction, 128 instructions per transform -- cost a third of the launch (ablation: 0.90 ms per
+        // 20 000 transforms against 0.61 ms without the stores; profiles/r03_k16_ablation.txt).  Staging area: behind the
+        // partner slots (no barrier between their reads and these writes); bin k at slot (k - 1) + 8 ((k - 1) >> 11): the four
+        // parts of the row a wave writes at once are 2048 bins apart and would meet in the same banks.
+        float2 *stage = buf + 8192;
+#pragma unroll
+        for (int qq = 0; qq < 8; ++qq) {
+            const int pos = FFT16_OUT[qq];
+            const float2 pv = qq == 0 ? pp0[0] : pp[1024 * (7 - qq)];
+            const float ar = xr[pos], ai = xi[pos];
+            const float sr_ = ar + pv.x, si_ = ai - pv.y;   // a + conj(b) = 2 L^
+            const float dr_ = ar - pv.x, di_ = ai + pv.y;   // a - conj(b) = 2i R^
+            const float ml = __builtin_amdgcn_sqrtf(fmaf(sr_, sr_, si_ * si_));  // the scale 1 / W rides on the window
+            const float mr = __builtin_amdgcn_sqrtf(fmaf(dr_, dr_, di_ * di_));
+            const bool dc = qq == 0 && tid == 0;   // k = 0 (DC) is not an output (fft.rs:81)
+            const int b = kbase + 256 * qq - 1;     // 0-based bin
+            if (!dc) stage[b + 8 * (b >> 11)] = make_float2(ml, mr);
+        }
+        lds_barrier();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = tid + 1024 * i;           // bins 2 c, 2 c + 1 (0-based); the last piece of the row holds one bin
+            const float4 v = *reinterpret_cast<const float4 *>(stage + 2 * c + 8 * (c >> 10));
+            if (!D_STORE_OK(v.x)) continue;
+            const bool whole = c != 4095;
+            if (MONO) {
+                if (have_first) {
+                    if (whole) __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v.x), __float_as_uint(v.x), __float_as_uint(v.z), __float_as_uint(v.z)}, r0, 16 * tid, 16384 * i, D_OUT_AUX);
+                    else __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(v.x), __float_as_uint(v.x)}, r0, 16 * tid, 16384 * i, D_OUT_AUX);
+                }
+                if (have_second) {
+                    if (whole) __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v.y), __float_as_uint(v.y), __float_as_uint(v.w), __float_as_uint(v.w)}, r1, 16 * tid, 16384 * i, D_OUT_AUX);
+                    else __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(v.y), __float_as_uint(v.y)}, r1, 16 * tid, 16384 * i, D_OUT_AUX);
+                }
+            } else {
+                if (whole) __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)}, r0, 16 * tid, 16384 * i, D_OUT_AUX);
+                else __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(v.x), __float_as_uint(v.y)}, r0, 16 * tid, 16384 * i, D_OUT_AUX);
+            }
+        }
+        if (more) take(nxt.data_second);
+        cur = nxt;
+    }
+}
+
+struct TablesD {
+    float2 *d_T1 = nullptr, *d_T1hi = nullptr, *d_tw2 = nullptr, *d_tw3 = nullptr;
+    float *d_win8 = nullptr;
+    float *d_planes = nullptr;   // de-interleave workspace, grown on demand
+    size_t planes_floats = 0;
+};
+
+}  // namespace d16k
+
+bool d16384_supported(const sgx_ctx *c)
+{
+    // (l, r) pairs are moved as 8-byte words: the stream must be mono or have an even channel count
+    return c->W == d16k::kW && (c->C == 1 || (c->C & 1) == 0) && c->lds_optin >= d16k::kLdsBytes;
+}
+
+hipError_t d16384_init(sgx_ctx *c, void **out)
+{
+    using namespace d16k;
+    auto *t = new TablesD();
+    auto unit = [](unsigned long long idx, unsigned long long N) {
+        idx %= N;
+        const double ang = -2.0 * M_PI * (double)idx / (double)N;
+        double cs = cos(ang), sn = sin(ang);
+        if (idx == 0) { cs = 1.0; sn = 0.0; }
+        if (4 * idx == N) { cs = 0.0; sn = -1.0; }
+        if (2 * idx == N) { cs = -1.0; sn = 0.0; }
+        if (4 * idx == 3 * N) { cs = 0.0; sn = 1.0; }
+        return make_float2((float)cs, (float)sn);
+    };
+    std::vector<float2> T1(16 * 1024), T1hi(8 * 1024), tw2(1024), tw3(64);
+    std::vector<float> win8((size_t)kW);
+    for (int q = 0; q < 16; ++q)
+        for (int tid = 0; tid < 1024; ++tid) {
+            T1[q * 1024 + tid] = unit((unsigned long long)q * tid, kP);
+            if (q >= 8) T1hi[(((q - 8) >> 1) * 1024 + tid) * 2 + (q & 1)] = T1[q * 1024 + tid];
+        }
+    for (int q2 = 0; q2 < 16; ++q2)
+        for (int t0 = 0; t0 < 16; ++t0)
+            for (int r = 0; r < 4; ++r) tw2[(q2 * 16 + t0) * 4 + r] = unit((unsigned long long)q2 * (4 * t0 + r), 1024);
+    for (int q3 = 0; q3 < 16; ++q3)
+        for (int r = 0; r < 4; ++r) tw3[q3 * 4 + r] = unit((unsigned long long)r * q3, 64);
+    // the scale (hypot / 2) * (2 / W) = 1 / W is a power of two and commutes with every rounding
+    for (int a = 0; a < 8; ++a)
+        for (int tid = 0; tid < 1024; ++tid) win8[((size_t)(a >> 2) * 1024 + tid) * 4 + (a & 3)] = c->tab.window[tid + 1024 * a] * (1.0f / (float)kW);
+    auto up = [](float2 **dst, const std::vector<float2> &v) {
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(dst), v.size() * sizeof(float2));
+        if (e == hipSuccess) e = hipMemcpy(*dst, v.data(), v.size() * sizeof(float2), hipMemcpyHostToDevice);
+        return e;
+    };
+    hipError_t e = up(&t->d_T1, T1);
+    if (e == hipSuccess) e = up(&t->d_T1hi, T1hi);
+    if (e == hipSuccess) e = up(&t->d_tw2, tw2);
+    if (e == hipSuccess) e = up(&t->d_tw3, tw3);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&t->d_win8), win8.size() * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(t->d_win8, win8.data(), win8.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(stft16384_d_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(stft16384_d_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
+    if (e != hipSuccess) {
+        d16384_destroy(t);
+        return e;
+    }
+    *out = t;
+    return hipSuccess;
+}
+
+void d16384_destroy(void *tables)
+{
+    auto *t = static_cast<d16k::TablesD *>(tables);
+    if (!t) return;
+    if (t->d_T1) (void)hipFree(t->d_T1);
+    if (t->d_T1hi) (void)hipFree(t->d_T1hi);
+    if (t->d_tw2) (void)hipFree(t->d_tw2);
+    if (t->d_tw3) (void)hipFree(t->d_tw3);
+    if (t->d_win8) (void)hipFree(t->d_win8);
+    if (t->d_planes) (void)hipFree(t->d_planes);
+    delete t;
+}
+
+hipError_t launch_stft_d16384(const sgx_ctx *c, void *tables, const float *d_pcm, uint32_t channels, uint32_t pairs,
+                              size_t first_frame, size_t n_frames, size_t total_frames, float *d_mags)
+{
+    using namespace d16k;
+    if (n_frames == 0) return hipSuccess;
+    auto *t = static_cast<TablesD *>(tables);
+    Params p{};
+    p.T1 = t->d_T1;
+    p.T1hi = t->d_T1hi;
+    p.tw2 = t->d_tw2;
+    p.tw3 = t->d_tw3;
+    p.win8 = t->d_win8;
+    p.mags = d_mags;
+    p.first_frame = first_frame;
+    p.n_frames = n_frames;
+    p.total_frames = total_frames;
+    p.H = c->H;
+    p.pairs = pairs;
+    const bool mono = channels == 1 && !(c->cfg.flags & SGX_FLAG_INDEPENDENT_FRAMES);
+    if (channels == 1 && !mono) return hipErrorNotSupported;  // caller falls back to the generic kernel
+    p.pair_base = mono ? first_frame / 2 : 0;
+    p.n_jobs = mono ? (first_frame + n_frames + 1) / 2 - first_frame / 2 : (unsigned long long)n_frames * pairs;
+    if (channels > 2) {
+        // per-pair planes of the sample range these frames read: [first_frame H, (first_frame + n - 1) H + W)
+        const size_t first_sample = first_frame * (size_t)c->H;
+        const size_t n_samp = (n_frames - 1) * (size_t)c->H + kW;
+        const size_t plane = (2 * n_samp + 63) & ~(size_t)63;  // floats per plane
+        if (plane * pairs > t->planes_floats) {
+            hipError_t e = hipStreamSynchronize(c->stream);  // a previous launch may still read the old planes
+            if (e != hipSuccess) return e;
+            if (t->d_planes) { (void)hipFree(t->d_planes); t->d_planes = nullptr; t->planes_floats = 0; }
+            e = hipMalloc(reinterpret_cast<void **>(&t->d_planes), plane * pairs * sizeof(float));
+            if (e != hipSuccess) return e;
+            t->planes_floats = plane * pairs;
+        }
+        hipError_t e = launch_deinterleave_pairs(c, d_pcm, t->d_planes, plane, first_sample, n_samp, channels, pairs);
+        if (e != hipSuccess) return e;
+        p.pcm = t->d_planes;
+        p.plane_floats = plane;
+        p.sample_base = (long long)first_sample;
+    } else {
+        p.pcm = d_pcm;
+        p.plane_floats = 0;
+        p.sample_base = 0;
+    }
+    // persistent workgroups, one per CU (145 KB of LDS); jobs are dealt round-robin in output-row order
+    unsigned long long blocks = (unsigned long long)c->n_cu;
+    if (blocks > p.n_jobs) blocks = p.n_jobs;
+    p.jobs_per_block = (p.n_jobs + blocks - 1) / blocks;
+    blocks = (p.n_jobs + p.jobs_per_block - 1) / p.jobs_per_block;
+    const dim3 grid((unsigned)blocks), block(1024);
+    if (mono) hipLaunchKernelGGL((stft16384_d_kernel<true>), grid, block, kLdsBytes, c->stream, p);
+    else hipLaunchKernelGGL((stft16384_d_kernel<false>), grid, block, kLdsBytes, c->stream, p);
+    return hipGetLastError();
+}
+
+}  // namespace sgx

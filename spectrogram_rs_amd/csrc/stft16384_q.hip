@@ -229,8 +229,30 @@ __global__ void __launch_bounds__(512, 4) stft16384_q_kernel(Params p)
         }
     }
 
+    // The pass-1 twiddles T_c[q1][col] of a pass: 128 bytes per lane from a 128 KB table (L2).  Q_T_EARLY: requested for the
+    // NEXT pass in front of this pass's stores (vmcnt retires in order: requested behind them, as the first version did at the
+    // head of the pass, they wait for every store of the previous pass to be acknowledged).
+    float2 tw1[16];
+    auto load_T = [&](int S) {
+        const __amdgpu_buffer_rsrc_t rT = uniform_rsrc(p.T);
+        const int lane_T = 16 * lane();
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+#ifdef Q_ABL_NOT
+            tw1[2 * g] = make_float2(1.0f, 0.25f * (float)g); tw1[2 * g + 1] = make_float2(1.0f, 0.125f * (float)g);
+            (void)rT; (void)lane_T; (void)S;
+#else
+            const u32x4 w = ld_u4(rT, lane_T, (S * 8 + g) * (512 * 16));
+            tw1[2 * g] = make_float2(__uint_as_float(w.x), __uint_as_float(w.y));
+            tw1[2 * g + 1] = make_float2(__uint_as_float(w.z), __uint_as_float(w.w));
+#endif
+        }
+    };
     JobIn cur = job_in(blockIdx.x < p.n_jobs ? blockIdx.x : 0);
     if (blockIdx.x < p.n_jobs) prefetch(cur);
+#ifdef Q_T_EARLY
+    load_T(0);
+#endif
     for (unsigned long long job = blockIdx.x; job < p.n_jobs; job += gridDim.x) {
         long long f0, f1;
         bool have_first = true, have_second = true;
@@ -285,22 +307,9 @@ __global__ void __launch_bounds__(512, 4) stft16384_q_kernel(Params p)
             if (S == 0) front(std::false_type{});
             else front(std::true_type{});
             }
-            float2 tw1[16];
-            {
-                const __amdgpu_buffer_rsrc_t rT = uniform_rsrc(p.T);
-                const int lane_T = 16 * lane();
-#pragma unroll
-                for (int g = 0; g < 8; ++g) {
-#ifdef Q_ABL_NOT
-                    tw1[2 * g] = make_float2(1.0f, 0.25f * (float)g); tw1[2 * g + 1] = make_float2(1.0f, 0.125f * (float)g);
-                    (void)rT; (void)lane_T;
-#else
-                    const u32x4 w = ld_u4(rT, lane_T, (S * 8 + g) * (512 * 16));
-                    tw1[2 * g] = make_float2(__uint_as_float(w.x), __uint_as_float(w.y));
-                    tw1[2 * g + 1] = make_float2(__uint_as_float(w.z), __uint_as_float(w.w));
+#ifndef Q_T_EARLY
+            load_T(S);
 #endif
-                }
-            }
 
             // ---- pass 1: thread col: 16-point FFT over a -> q1, twiddle w_4096^{col q1} w_16384^{c col}
             fft16(xr, xi);
@@ -328,15 +337,16 @@ __global__ void __launch_bounds__(512, 4) stft16384_q_kernel(Params p)
             }
             // the pass's twiddles are requested with its data (the pass-1 twiddle registers are free again): fetched one
             // by one behind the FFT, each would cost the wave an LDS round trip in front of its store
+            float2 tw2r[16];
 #pragma unroll
-            for (int q2 = 1; q2 < 16; ++q2) tw1[q2] = tw2[q2 * 16 + t0_2];
+            for (int q2 = 1; q2 < 16; ++q2) tw2r[q2] = tw2[q2 * 16 + t0_2];
             fft16(xr, xi);
             lds_barrier();  // everyone has read image 1
 #pragma unroll
             for (int q2 = 0; q2 < 16; ++q2) {
                 const int pos = FFT16_OUT[q2];
                 const float2 v = make_float2(xr[pos], xi[pos]);
-                buf[2 * (t0_2 * kS2 + q1_2 + 16 * q2) + b_2] = q2 == 0 ? v : cmulf(v, tw1[q2]);
+                buf[2 * (t0_2 * kS2 + q1_2 + 16 * q2) + b_2] = q2 == 0 ? v : cmulf(v, tw2r[q2]);
             }
             lds_barrier();
 
@@ -416,6 +426,9 @@ __global__ void __launch_bounds__(512, 4) stft16384_q_kernel(Params p)
                 }
 #endif
             }
+#ifdef Q_T_EARLY
+            if (S == 0 || more) load_T(1 - S);
+#endif
 #ifdef Q_STAGE
             // A lane's 16 output bytes per (row, j) are the even bin of pass S = 0 and the odd bin of pass S = 1.  Holding
             // the first in 16 registers across the second pass does not fit beside the software pipeline (spills, and a

@@ -130,13 +130,15 @@ def test_4096_point_kernel_on_interleaved_channel_pairs(torch_cuda, mags_err, gr
     assert px.shape == (14, ch // 2, R, 4) and np.array_equal(px.reshape(own.shape), own)
 
 
-@pytest.mark.parametrize("ch,force_generic", [(8, False), (2, False), (1, False), (8, True)])
-def test_config4_16384_point_kernel(torch_cuda, mags_err, ch, force_generic):
-    # BASELINE config 4: W 8192 / P 16384, hop 512, interleaved channel pairs; tuned kernel vs generic vs oracle
+@pytest.mark.parametrize("ch,variant", [(8, "quad"), (2, "quad"), (1, "quad"), (8, "residue"), (2, "residue"), (1, "residue"), (8, "generic")])
+def test_config4_16384_point_kernel(torch_cuda, mags_err, ch, variant):
+    # BASELINE config 4: W 8192 / P 16384, hop 512, interleaved channel pairs; the time-decimated lane-quad kernel (default), the
+    # four-residue kernel of round 2 (SGX_FLAG_RESIDUE_16K) and the generic kernel, each against the oracle
     torch = torch_cuda
     Wt, Ht = 8192, 512
-    eng = engine(window_samples=Wt, hop_samples=Ht, channels=ch, force_generic=force_generic)
-    assert eng.info.stft_kernel == (0 if force_generic else 5)
+    force_generic = variant == "generic"
+    eng = engine(window_samples=Wt, hop_samples=Ht, channels=ch, force_generic=force_generic, residue_16k=(variant == "residue"))
+    assert eng.info.stft_kernel == {"quad": 8, "residue": 5, "generic": 0}[variant]
     n = Wt + 21 * Ht + 9
     pcm = oracle.white_noise(n * ch, seed=40 + ch)
     dev = to_dev(torch, pcm)
