@@ -61,6 +61,8 @@ KERNEL_NAMES = {
     5: ("stft16384 as four 4096-point residues (512 threads = 256 lane pairs, DPP decimation)", "sgx::q16k::stft16384_q_kernel<false, true>"),
     6: ("mixed radix at the window's own length (compile-time plan)", "sgx::mix::stft_mixed_fixed_kernel"),
     7: ("stft16384 workgroup-per-transform (1024 threads, whole transform in LDS)", "sgx::wg16k::stft16384_wg_kernel<false>"),
+    8: ("stft16384 as four time-decimated 4096-point transforms in the lanes of a quad (1024 threads per transform, DPP recombination)",
+        "sgx::d16k::stft16384_d_kernel<false>"),
 }
 
 
@@ -147,12 +149,30 @@ def host_info():
     return {"nproc": os.cpu_count(), "affinity": aff, "cgroup_cpu_quota": quota, "cpu_model": model}
 
 
+def csrc_sha16():
+    """sha256 over the kernel sources (csrc/*.hip, *.hpp, *.inc, *.cpp, sorted by name): what a committed counter summary is stamped
+    with (tools/pmc_round.py) -- counters of an older kernel are not quoted for a newer one"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for path in sorted(glob.glob(os.path.join(ROOT, "spectrogram_rs_amd", "csrc", "*.*"))):
+        if path.endswith((".hip", ".hpp", ".inc", ".cpp")):
+            with open(path, "rb") as f:
+                h.update(os.path.basename(path).encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
 def load_profile_json(name):
-    """A committed summary of this round's rocprofv3 --pmc passes (profiles/<round>_<name>.json), or None."""
+    """A committed summary of this round's rocprofv3 --pmc passes (profiles/<round>_<name>.json), or None -- also None (with the
+    reason on stderr) when the summary was taken from other kernel sources than the ones in the tree."""
     path = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_{name}.json")
     try:
         with open(path) as f:
             d = json.load(f)
+        if d.get("csrc_sha16") != csrc_sha16():
+            print(f"bench.py: {os.path.relpath(path, ROOT)} was measured on other kernel sources "
+                  f"({d.get('csrc_sha16')} != {csrc_sha16()}): not quoted", file=sys.stderr)
+            return None
         d["source"] = os.path.relpath(path, ROOT)
         return d
     except Exception:

@@ -64,7 +64,8 @@ struct Params {
     const float2 *tw3;       // [16][4]     w_64^{r q3} at [q3][r]
     const float *win8;       // [2][1024][4] hann[tid + 1024 a] / W at [a / 4][tid][a % 4]   (fft.rs:61; the scale (hypot / 2) (2 / W) = 2^-13 rides along)
     float *mags;
-    unsigned long long first_frame, n_frames, total_frames, pair_base, n_jobs, jobs_per_block;
+    unsigned long long first_frame, n_frames, total_frames, pair_base, n_jobs, jobs_per_xcd;
+    uint32_t xcds;           // 8 when the grid is a multiple of 8 workgroups, else 1 (plain round-robin)
     uint32_t H, pairs;
 };
 
@@ -199,16 +200,16 @@ __global__ void __launch_bounds__(1024, 1) stft16384_d_kernel(Params p)
         }
 
     };
-    // every workgroup owns a contiguous run of jobs (hop-major: the pairs of one hop position, then the next hop): consecutive hops
-    // share 15/16 of their samples, and this way they are read again through the L2 of the same XCD -- dealt round-robin over the
-    // workgroups they came back from the Infinity Cache every time
-#ifdef D_ROUND_ROBIN
-    const unsigned long long job_begin = blockIdx.x, job_step = gridDim.x;
-    const unsigned long long job_end = p.n_jobs;
-#else
-    const unsigned long long job_begin = (unsigned long long)blockIdx.x * p.jobs_per_block, job_step = 1;
-    const unsigned long long job_end = job_begin + p.jobs_per_block < p.n_jobs ? job_begin + p.jobs_per_block : p.n_jobs;
-#endif
+    // Job order.  Jobs are hop-major (the pairs of one hop position, then the next hop) and consecutive hop positions share
+    // 15/16 of their samples.  Workgroup i runs on XCD i % 8, each XCD has its own L2: every XCD takes one contiguous eighth of
+    // the jobs and deals it round-robin to its workgroups, so that at any time the 32 CUs of an XCD work on ~8 neighbouring hop
+    // positions and a sample is fetched from the fabric once.  (Measured, FETCH_SIZE per hop position: a contiguous run of
+    // jobs per WORKGROUP 262 KB -- every load a miss: 32 CUs x 4 pairs x 64 KB of window do not fit a 4 MB L2 --, plain
+    // round-robin over all workgroups 87 KB -- every XCD fetches every sample --; the time is the same.)
+    const unsigned long long nx = p.xcds, xcd = blockIdx.x % nx, local = blockIdx.x / nx;
+    const unsigned long long job_step = gridDim.x / nx;
+    const unsigned long long job_begin = xcd * p.jobs_per_xcd + local;
+    const unsigned long long job_end = (xcd + 1) * p.jobs_per_xcd < p.n_jobs ? (xcd + 1) * p.jobs_per_xcd : p.n_jobs;
     JobIn cur = job_in(job_begin < job_end ? job_begin : 0);
     if (job_begin < job_end) {
         prefetch(cur);
@@ -518,8 +519,9 @@ hipError_t launch_stft_d16384(const sgx_ctx *c, void *tables, const float *d_pcm
     // persistent workgroups, one per CU (145 KB of LDS); jobs are dealt round-robin in output-row order
     unsigned long long blocks = (unsigned long long)c->n_cu;
     if (blocks > p.n_jobs) blocks = p.n_jobs;
-    p.jobs_per_block = (p.n_jobs + blocks - 1) / blocks;
-    blocks = (p.n_jobs + p.jobs_per_block - 1) / p.jobs_per_block;
+    p.xcds = (blocks % 8 == 0 && p.n_jobs >= 8 * blocks) ? 8u : 1u;   // (short launches: plain round-robin keeps every workgroup busy)
+    const unsigned long long group = mono ? 1 : pairs;                   // a hop position's pairs stay together
+    p.jobs_per_xcd = ((p.n_jobs + p.xcds - 1) / p.xcds + group - 1) / group * group;
     const dim3 grid((unsigned)blocks), block(1024);
     if (mono) hipLaunchKernelGGL((stft16384_d_kernel<true>), grid, block, kLdsBytes, c->stream, p);
     else hipLaunchKernelGGL((stft16384_d_kernel<false>), grid, block, kLdsBytes, c->stream, p);

@@ -126,7 +126,8 @@ __device__ __forceinline__ void st_f2(__amdgpu_buffer_rsrc_t r, int voff, int so
     __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(a), __float_as_uint(b)}, r, voff, soff, 0);
 }
 #ifndef Q_STAGE_LD_AUX
-#define Q_STAGE_LD_AUX 2
+#define Q_STAGE_LD_AUX 17   // sc0 | sc1 (gfx940 cache policy bits 0 and 4): the read-back of a parked slot is served at system scope, never
+                            // from a line this CU's L1 may still hold from the slot's previous job (nt alone is only a hint)
 #endif
 #ifndef Q_STAGE_ST_AUX
 #define Q_STAGE_ST_AUX 0
@@ -445,7 +446,7 @@ __global__ void __launch_bounds__(512, 4) stft16384_q_kernel(Params p)
                 } else {
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        const u32x4 e = __builtin_amdgcn_raw_buffer_load_b128(rg, lane_out, g * (512 * 16), Q_STAGE_LD_AUX /* nt: not from this CU's L1 (it may still hold the previous job's line), served by L2 */);
+                        const u32x4 e = __builtin_amdgcn_raw_buffer_load_b128(rg, lane_out, g * (512 * 16), Q_STAGE_LD_AUX /* not from this CU's L1 (it may still hold the previous job's line) */);
 #pragma unroll
                         for (int h = 0; h < 2; ++h) {
                             const int q3 = 2 * g + h;
@@ -513,6 +514,20 @@ __global__ void __launch_bounds__(256) deinterleave_pairs_kernel(const float *pc
     }
 }
 
+// the same, two samples per thread and 16 bytes per access: C a multiple of 4, the stream and the planes 16-byte aligned
+__global__ void __launch_bounds__(256) deinterleave_pairs_wide_kernel(const float *pcm, float *planes, size_t plane_floats,
+                                                                      size_t first, size_t n_half, uint32_t C, uint32_t pairs)
+{
+    for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < n_half; j += (size_t)gridDim.x * blockDim.x) {
+        const float4 *s0 = reinterpret_cast<const float4 *>(pcm + (first + 2 * j) * C), *s1 = reinterpret_cast<const float4 *>(pcm + (first + 2 * j + 1) * C);
+        for (uint32_t q = 0; q < pairs / 2; ++q) {
+            const float4 a = s0[q], b = s1[q];
+            reinterpret_cast<float4 *>(planes + (size_t)(2 * q) * plane_floats)[j] = make_float4(a.x, a.y, b.x, b.y);
+            reinterpret_cast<float4 *>(planes + (size_t)(2 * q + 1) * plane_floats)[j] = make_float4(a.z, a.w, b.z, b.w);
+        }
+    }
+}
+
 // row-paired planes (hop a multiple of 512): sample 512 B + 256 h + r of a plane is stored at 512 B + 2 r + h, so the
 // transform kernel reads rows r and 256 + r of a block with one 16-byte load.  One thread moves BOTH samples of a
 // 16-byte piece: every store is a whole piece (8-byte stores at a 16-byte stride double the write traffic -- measured
@@ -553,11 +568,23 @@ struct TablesQ {
 hipError_t launch_deinterleave_pairs(const sgx_ctx *c, const float *d_pcm, float *d_planes, size_t plane_floats, size_t first_sample, size_t n_samples,
                                      uint32_t channels, uint32_t pairs)
 {
-    int n_cu = 256;
-    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device);
-    const unsigned blocks = (unsigned)std::min<size_t>((n_samples + 255) / 256, (size_t)n_cu * 16);
-    hipLaunchKernelGGL(q16k::deinterleave_pairs_kernel, dim3(blocks), dim3(256), 0, c->stream, d_pcm, d_planes, plane_floats, first_sample, n_samples,
-                       channels, pairs);
+    const int n_cu = c->n_cu;
+    const bool wide = channels % 4 == 0 && reinterpret_cast<uintptr_t>(d_pcm) % 16 == 0 && reinterpret_cast<uintptr_t>(d_planes) % 16 == 0 &&
+                      plane_floats % 4 == 0 && (first_sample * channels) % 4 == 0 && n_samples >= 2;
+    size_t done = 0;
+    if (wide) {
+        const size_t n_half = n_samples / 2;
+        const unsigned blocks = (unsigned)std::min<size_t>((n_half + 255) / 256, (size_t)n_cu * 16);
+        hipLaunchKernelGGL(q16k::deinterleave_pairs_wide_kernel, dim3(blocks), dim3(256), 0, c->stream, d_pcm, d_planes, plane_floats, first_sample, n_half,
+                           channels, pairs);
+        done = 2 * n_half;
+    }
+    if (done < n_samples) {   // everything, or the odd sample at the end
+        const size_t rest = n_samples - done;
+        const unsigned blocks = (unsigned)std::min<size_t>((rest + 255) / 256, (size_t)n_cu * 16);
+        hipLaunchKernelGGL(q16k::deinterleave_pairs_kernel, dim3(blocks), dim3(256), 0, c->stream, d_pcm, d_planes + 2 * done, plane_floats,
+                           first_sample + done, rest, channels, pairs);
+    }
     return hipGetLastError();
 }
 

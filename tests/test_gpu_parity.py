@@ -157,6 +157,16 @@ def test_config4_16384_point_kernel(torch_cuda, mags_err, ch, variant):
         shifted[2:] = dev
         assert shifted[2:].data_ptr() % 16 == 8
         assert np.array_equal(eng.stft_batch(shifted[2:]).cpu().numpy(), got)
+    if variant != "generic" and ch == 8:
+        # more jobs than persistent workgroups (142 hop positions x 4 pairs = 568 > 512): every workgroup runs several jobs with
+        # different data -- a stale read of what the previous job left (the four-residue kernel parks half of its magnitudes in a
+        # slot it reads back; both kernels re-use LDS images and prefetch registers across jobs) would show here
+        # 530 hop positions = 2 120 jobs: also past the size from which the lane-quad kernel hands every XCD its own eighth of the jobs
+        for hops in (142, 530):
+            pcm2 = oracle.white_noise((Wt + (hops - 1) * Ht) * ch, seed=77 + hops)
+            got2 = eng.stft_batch(to_dev(torch, pcm2)).cpu().numpy()
+            ref2 = oracle.stream_process(pcm2, ch, Wt, Ht, threads=8)
+            assert got2.shape == ref2.shape == (hops, 4, Wt - 1, 2) and mags_err(got2, ref2) <= 2.0
     # the pixel path rides on it through the two-kernel route
     eng.set_builtin_gradient("viridis")
     rg = eng.render_batch(dev).cpu().numpy()

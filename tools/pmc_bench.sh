@@ -5,8 +5,12 @@ out=$1; shift
 repo=$(cd "$(dirname "$0")/.." && pwd)
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --pmc "$@" --output-format csv -d $repo/gpurun_out/${out}_bench -- python3 $repo/bench.py --steps 3 --warmup 1 --sustain-s 0 --cpu-frames 0 > $repo/gpurun_out/${out}_bench.log 2>&1
-echo "pmc bench $out rc=$?"
+rc=$?
+echo "pmc bench $out rc=$rc"
 if [ -x $repo/tools/bin/microbench ]; then
   timeout -k 10 300 rocprofv3 --pmc "$@" --output-format csv -d $repo/gpurun_out/${out}_micro -- $repo/tools/bin/microbench > $repo/gpurun_out/${out}_micro.log 2>&1
-  echo "pmc micro $out rc=$?"
+  rc2=$?
+  echo "pmc micro $out rc=$rc2"
+  [ $rc -eq 0 ] && rc=$rc2
 fi
+exit $rc   # a failed or timed-out profiler pass is the script's own status

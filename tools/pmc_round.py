@@ -14,6 +14,8 @@ import sys
 
 rnd, fb_d, fm_d, wb_d, wm_d, s1_d, s2_d = sys.argv[1:8]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, root)
+from bench import csrc_sha16  # noqa: E402  (the stamp bench.py checks before it quotes these summaries)
 
 
 def load(d):
@@ -38,7 +40,7 @@ fb, fm, wb, wm, s1, s2 = [load(d) for d in (fb_d, fm_d, wb_d, wm_d, s1_d, s2_d)]
 KIB = 1024.0
 out = {"how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes over `bench.py --steps 3 --warmup 1 --sustain-s 0 "
               "--cpu-frames 0` (tools/pmc_bench.sh); counters are KiB; FETCH_SIZE x 2 (gfx950 tallies 128-B requests at 64 B), WRITE_SIZE x 1",
-       "calibration": {}}
+       "calibration": {}, "csrc_sha16": csrc_sha16()}
 f = pick(fm, "copy_kernel", "FETCH_SIZE")
 if f:
     out["calibration"]["fetch_float4_copy_ratio_raw"] = f * KIB / (262144 * 4096 * 4.0)
@@ -61,7 +63,7 @@ F = 1_000_000
 t2 = traffic("stft4096_wg_kernel<true, 0, false, false>", F, 17400)
 t3 = traffic("stft4096_wg_kernel<true, 0, false, true>", F, 5120)
 hops = 20_000
-t4a = traffic("stft16384_q_kernel<false", hops, 278496)   # <MONO = false, PAIRED = either>
+t4a = traffic("stft16384_d_kernel<false", hops, 278496) or traffic("stft16384_q_kernel<false", hops, 278496)
 t4b = traffic("deinterleave_pa", hops, 278496)   # deinterleave_pairs_kernel or deinterleave_paired_kernel<WIDE>
 out["config2_stft"] = t2
 out["config3_fused_pixel"] = t3
@@ -79,20 +81,15 @@ if t4a:
     write_kb = t4a["WRITE_SIZE_bytes"] / hops / 1e3
     out["note_config4"] = (
         "config 4: FETCH_SIZE / WRITE_SIZE count requests between L2 and the fabric, Infinity-Cache hits included. Per hop position the "
-        f"transform kernel writes {write_kb:.0f} KB = 262 KB of algorithmic output + 131 KB of the even bins' magnitudes parked in the "
-        f"workgroups' slots of a 16 MB buffer (csrc/stft16384_q.hip, Q_STAGE; L2 is write-through, so parked bytes reach the fabric once -- "
-        f"the buffer itself lives in the 256 MB Infinity Cache, not in HBM), and fetches {fetch_kb:.0f} KB: the input (16 KB algorithmic, read "
-        "through the L2s of the XCDs that share a plane's hops) plus whatever part of the 131 KB of parked magnitudes L2 no longer holds when "
-        "they are read back.  With plain output stores that was all of it (fetch 199 KB, total 2.13 x algorithmic): the output stream "
-        "turned a 4 MB L2 over between a slot's write and its read.  The output stores now carry the nt bit (no allocation in L2) and "
-        "the read-back mostly hits.  The alternative without staging (8-byte stores at a 16-byte stride) measured 2.7x algorithmic with "
-        "the excess going to HBM (write amplification 2.0x) and ran 13 % slower.")
+        f"transform kernel writes {write_kb:.0f} KB (262 KB of algorithmic output; nothing is parked since round 3's kernel, csrc/stft16384_d.hip) "
+        f"and fetches {fetch_kb:.0f} KB: the (l, r) planes of the de-interleave pass, every sample wanted by 16 overlapping hop positions and "
+        "served mostly by L2 (16 KB algorithmic).  The de-interleave pass reads the interleaved stream once and writes the planes once.")
 json.dump(out, open(os.path.join(root, "profiles", f"{rnd}_hbm_traffic.json"), "w"), indent=1)
 
 # ---- pipes of the fused pixel kernel -------------------------------------------------------------------------------
 name = "stft4096_wg_kernel<true, 0, false, true>"
 g = lambda acc, c: pick(acc, name, c)  # noqa: E731
-pipes = {"how": "rocprofv3 --pmc SQ counters (two passes) over the same bench.py command; per launch of 1e6 frames = 5e5 transforms; "
+pipes = {"csrc_sha16": csrc_sha16(), "how": "rocprofv3 --pmc SQ counters (two passes) over the same bench.py command; per launch of 1e6 frames = 5e5 transforms; "
                 "SQ_*_CYCLES / ACTIVE counters are in units of 4 clocks summed over waves; GRBM_GUI_ACTIVE summed over the 8 XCDs",
          "kernel": name}
 for c in ("SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "GRBM_GUI_ACTIVE"):
