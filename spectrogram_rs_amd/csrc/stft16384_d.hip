@@ -287,6 +287,10 @@ __global__ void __launch_bounds__(1024, 1) stft16384_d_kernel(Params p)
             }
         }
         fft16(xr, xi);
+        // the next transform's samples: ahead of this transform's stores (vmcnt retires in order), and as early as the registers
+        // allow -- here, before the recombination (same-device A/B against "after the publish": +3 %; after the recombination the
+        // compiler spills 14 registers)
+        if (more) prefetch(nxt);
         // ---- the rest of the recombination twiddle, w_64^{r q3}, and the radix-4 recombination across the quad.
         //      Lane r holds X_r.  Registers q3 < 8 ("lo"):  stage A: lanes 0, 1: X_r + X_{r+2}; lanes 2, 3: X_{r-2} - X_r
         //        -> E0, E1, O0, O1; lane 3 turns O1 by -i; stage B: lanes 0, 2: own + partner; lanes 1, 3: partner - own
@@ -330,9 +334,6 @@ __global__ void __launch_bounds__(1024, 1) stft16384_d_kernel(Params p)
                 wp[1024 * h] = make_float2(xr[pos], xi[pos]);
             }
         }
-        // the next transform's samples, twiddles and window: ahead of this transform's stores, and once the published half of the
-        // spectrum has left its 16 registers
-        if (more) prefetch(nxt);
         lds_barrier();
 
         // ---- split + magnitude (fft.rs:81-98).  Kept (u, qq) of lane L pairs with slot h = 7 - qq of lane L of quad 256 - u;
