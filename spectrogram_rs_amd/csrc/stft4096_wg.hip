@@ -26,6 +26,9 @@
 #ifndef SGX_ABL_NSTORE
 #define SGX_ABL_NSTORE 8
 #endif
+#ifndef SGX_ABL_STAGE_AUX
+#define SGX_ABL_STAGE_AUX 0
+#endif
 
 namespace sgx {
 
@@ -324,10 +327,45 @@ __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
             } else {
                 // byte offset of bin k = 0 of the row (bin k lives 8 k bytes on; k = 0 is never stored)
                 char *base = reinterpret_cast<char *>(p.mags);
-                const long long row0 = (long long)((((size_t)(have_first ? f0 : 0) * p.pairs + p.pair) * (size_t)kM) * 8) - 8;
+#if defined(SGX_ABL_PITCH16K)
+                // A/B only (profiles/r03_k1_slow_box.txt): rows at a pitch of 16 384 bytes -- every 512-byte wave store then starts on a
+                // 128-byte line.  The caller's buffer must hold 16 384 bytes per row.
+                constexpr size_t kPitch = 16384;
+#else
+                constexpr size_t kPitch = (size_t)kM * 8;
+#endif
+                const long long row0 = (long long)(((size_t)(have_first ? f0 : 0) * p.pairs + p.pair) * kPitch) - 8;
+#if defined(SGX_ABL_ALIGNED_STAGE)
+                // A/B only: the two rows of a mono pair staged in LDS and written as 512-byte-ALIGNED wave stores whatever the rows'
+                // own alignment (a 16 376-byte row starts 8 bytes earlier inside its 128-byte line in every row)
+                if (MONO) {
+                    float *st = reinterpret_cast<float *>(buf);   // [2][2048]: bin k of row e at st[2048 e + k]
+                    lds_barrier();   // partner reads done
+#pragma unroll
+                    for (int q3 = 0; q3 < 8; ++q3) { st[col + 256 * q3] = ml[q3]; st[2048 + col + 256 * q3] = mr[q3]; }
+                    lds_barrier();
+                    const int wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        if (e == 0 ? !have_first : !have_second) continue;
+                        const long long rb = e == 0 ? row0 : (long long)((f1 * p.pairs + p.pair) * kPitch) - 8;   // byte of bin 0
+                        // first bin whose address is a multiple of 512
+                        const unsigned long long a1 = (unsigned long long)(base + rb + 8);
+                        const int head = (int)(((512 - (a1 & 511)) & 511) >> 3);     // bins 1 .. head lie in front of it
+                        const __amdgpu_buffer_rsrc_t r = row_rsrc(base, rb);
+                        for (int sgm = wave - 4; sgm * 64 + head < kM; sgm += 4) {
+                            const int k = 1 + head + 64 * sgm + lane;                // segment -1 (wave 3 first): the bins in front
+                            if (k >= 1 && k <= kM) {
+                                const float m = st[2048 * e + k];
+                                __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(m), __float_as_uint(m)}, r, 8 * k, 0, SGX_ABL_STAGE_AUX);
+                            }
+                        }
+                    }
+                } else
+#endif
                 if (MONO) {
                     if (have_first) store_row<true>(base, row0, col, ml, ml);
-                    if (have_second) store_row<true>(base, (long long)(((f1 * p.pairs + p.pair) * (size_t)kM) * 8) - 8, col, mr, mr);
+                    if (have_second) store_row<true>(base, (long long)((f1 * p.pairs + p.pair) * kPitch) - 8, col, mr, mr);
                 } else {
                     store_row<false>(base, row0, col, ml, mr);
                 }
