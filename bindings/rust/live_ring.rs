@@ -9,6 +9,7 @@ use crate::fourier::sgx_sys::SgxCtx;
 use crate::fourier::StereoMagnitude;
 
 #[repr(C)] pub struct SgxLive { _private: [u8; 0] }
+#[repr(C)] pub struct SgxView { _private: [u8; 0] }   // GPUSpectrogram's F16F16 ring texture on the device (sgx_view_create)
 pub const SGX_LIVE_MAGS: c_int = 0;
 pub const SGX_LIVE_MAGS_F16: c_int = 1;
 pub const SGX_LIVE_RGBA: c_int = 2;
@@ -20,6 +21,7 @@ extern "C" {
     pub fn sgx_live_push(live: *mut SgxLive, h_samples: *const f32, n_values: usize, channels: u32) -> c_longlong;
     pub fn sgx_live_occupied(live: *const SgxLive) -> usize;
     pub fn sgx_live_tick(live: *mut SgxLive, what: c_int, h_out: *mut c_void, max_frames: usize, n_frames: *mut usize) -> c_int;
+    pub fn sgx_live_tick_view(live: *mut SgxLive, view: *mut SgxView, max_frames: usize, n_frames: *mut usize) -> c_int;
     pub fn sgx_spectrum_levels(ctx: *mut SgxCtx, d_column: *const f32, n_bars: u32, h_levels: *mut f64) -> c_int;
 }
 
@@ -51,6 +53,15 @@ impl LiveRing {
         assert_eq!(rc, 0);
         flat.truncate(got * self.m);
         flat.chunks(self.m).map(|c| c.to_vec()).collect()
+    }
+
+    /// GPUSpectrogram::render's upload loop (gpu_spectrogram.rs:255-275): this tick's frames as half-pair rows straight into the
+    /// device-resident ring texture; returns the block size the reference adds to `texture_offset`
+    pub fn upload_into(&self, view: *mut SgxView) -> usize {
+        let mut got = 0usize;
+        let rc = unsafe { sgx_live_tick_view(self.raw, view, 2048, &mut got) };
+        assert_eq!(rc, 0);
+        got
     }
 
     /// the pixel columns SimpleSpectrogram::snapshot would put_pixel this tick: [frames][rows][4]

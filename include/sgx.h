@@ -298,6 +298,10 @@ SGX_API void sgx_view_destroy(sgx_view *view);
  * e.g. what sgx_stft_batch_f16 wrote -- at the ring's offset, wrapping at its height; the new offset is returned. */
 SGX_API int sgx_view_write_rows(sgx_view *view, const void *d_rows_f16, size_t n_rows, uint32_t *offset_out);
 SGX_API uint32_t sgx_view_offset(const sgx_view *view);
+/* One GUI tick of the default widget (gpu_spectrogram.rs:255-275: `for frame in fft.process()` -> fft_texture.write): every
+ * complete frame of the live ring, at most max_frames, is transformed and its half-pair row appended to the view's ring texture,
+ * device to device -- the only host traffic of the tick is the new samples going up.  `view` must belong to the ring's context. */
+SGX_API int sgx_live_tick_view(sgx_live *live, sgx_view *view, size_t max_frames, size_t *n_frames);
 /* The fragment program over a width x height viewport: d_rgba_f32 [height][width][4] float = f_color per fragment, row 0
  * at the BOTTOM (GL).  The palette texture is ColorScheme::lookup_table(32) of the context's current colour scheme,
  * min_db / max_db the context's. */

@@ -118,6 +118,7 @@ SIGNATURES = [
     ("sgx_view_destroy", None, [C.c_void_p]),
     ("sgx_view_write_rows", C.c_int, [C.c_void_p, _vp, _sz, C.POINTER(C.c_uint32)]),
     ("sgx_view_offset", C.c_uint32, [C.c_void_p]),
+    ("sgx_live_tick_view", C.c_int, [C.c_void_p, C.c_void_p, _sz, C.POINTER(_sz)]),
     ("sgx_view_draw", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, _vp]),
     ("sgx_checksum", C.c_int, [_ctx, _vp, _sz, C.c_uint64, C.POINTER(C.c_uint64)]),
     ("sgx_checksum_add", C.c_int, [_ctx, _vp, _sz, C.c_uint64, _vp]),

@@ -129,7 +129,22 @@ size_t sgx_live_occupied(const sgx_live *l)
     return (size_t)(head - tail);
 }
 
+static int live_tick(sgx_live *l, int what, void *h_out, sgx_view *view, size_t max_frames, size_t *n_frames);
+
 int sgx_live_tick(sgx_live *l, int what, void *h_out, size_t max_frames, size_t *n_frames)
+{
+    return live_tick(l, what, h_out, nullptr, max_frames, n_frames);
+}
+
+// GPUSpectrogram::render (gpu_spectrogram.rs:255-275): this tick's frames go from the transform straight into the widget's ring
+// texture -- half-pair rows, device to device on the context's stream; nothing crosses the bus but the new samples.
+int sgx_live_tick_view(sgx_live *l, sgx_view *view, size_t max_frames, size_t *n_frames)
+{
+    if (!view) { if (n_frames) *n_frames = 0; return SGX_ERR_INVALID_ARG; }
+    return live_tick(l, SGX_LIVE_MAGS_F16, nullptr, view, max_frames, n_frames);
+}
+
+static int live_tick(sgx_live *l, int what, void *h_out, sgx_view *view, size_t max_frames, size_t *n_frames)
 {
     if (n_frames) *n_frames = 0;
     if (!l) return SGX_ERR_INVALID_ARG;
@@ -163,7 +178,7 @@ int sgx_live_tick(sgx_live *l, int what, void *h_out, size_t max_frames, size_t 
     const bool truncated = frames > max_frames;
     if (truncated) frames = max_frames;
     if (frames) {
-        if (!h_out) return live_fail(l, SGX_ERR_INVALID_ARG, "sgx_live_tick: null output buffer");
+        if (!h_out && !view) return live_fail(l, SGX_ERR_INVALID_ARG, "sgx_live_tick: null output buffer");
         const size_t need = frames * frame_bytes;
         if (need > l->out_bytes) {
             LIVE_HIP(l, hipStreamSynchronize(c->stream));
@@ -180,7 +195,12 @@ int sgx_live_tick(sgx_live *l, int what, void *h_out, size_t max_frames, size_t 
         else rc = sgx_render_batch(c, pcm, n_samples, 0, frames, static_cast<uint8_t *>(l->d_out), &got);
         if (rc != SGX_OK) return rc;
         if (got != frames) return live_fail(l, SGX_ERR_INVALID_ARG, "sgx_live_tick: frame count mismatch");
-        LIVE_HIP(l, hipMemcpyAsync(h_out, l->d_out, need, hipMemcpyDeviceToHost, c->stream));
+        if (view) {
+            rc = sgx_view_write_rows(view, l->d_out, frames, nullptr);   // (answers SGX_ERR_INVALID_ARG for a view of another / a destroyed context)
+            if (rc != SGX_OK) return rc;
+        } else {
+            LIVE_HIP(l, hipMemcpyAsync(h_out, l->d_out, need, hipMemcpyDeviceToHost, c->stream));
+        }
     }
 
     // ring.skip(H) per yielded frame; the reference's loop also skips on the read that returns None

@@ -377,6 +377,16 @@ class LiveRing:
         e._check(self._lib.sgx_live_tick(self._h, code, out.ctypes.data_as(C.c_void_p), max_frames, C.byref(got)))
         return out[:got.value]
 
+    def tick_into(self, view: "ViewRing", max_frames: Optional[int] = None) -> int:
+        """One GUI tick of the default widget (gpu_spectrogram.rs:255-275): every complete frame of the ring goes, as a half-pair
+        row, straight into `view`'s ring texture -- device to device, no host copy.  Returns the number of rows appended."""
+        e = self.engine
+        if max_frames is None:
+            max_frames = e.num_frames(self.capacity)
+        got = C.c_size_t(0)
+        e._check(self._lib.sgx_live_tick_view(self._h, view._h, max_frames, C.byref(got)))
+        return int(got.value)
+
 
 class ViewRing:
     """sgx_view: the VIEWPORT_FRAMES x (W - 1) F16F16 texture of gpu_spectrogram.rs:218-226 used as a ring (:255-275)

@@ -149,11 +149,7 @@ class GPUSpectrogram:
 
     def render(self, width: int, height: int):
         """:208-316 without the GL frame: upload this tick's frames, run the fragment program; [height][width][4] float32"""
-        import torch
-
-        rows = self.live.tick("mags_f16")
-        if rows.shape[0]:
-            self.texture.write_rows(torch.from_numpy(np.ascontiguousarray(rows)).to(self.engine.device))
+        self.live.tick_into(self.texture)      # device to device: the rows never visit the host
         return self.texture.draw(width, height)
 
 

@@ -118,3 +118,29 @@ def test_a_view_that_outlives_its_context_fails_cleanly(torch_cuda):
     assert lib.sgx_view_write_rows(view, C.c_void_p(rows.data_ptr()), 2, C.byref(off)) == _lib.SGX_ERR_INVALID_ARG
     assert lib.sgx_view_draw(view, 4, 4, C.c_void_p(out.data_ptr())) == _lib.SGX_ERR_INVALID_ARG
     lib.sgx_view_destroy(view)
+
+
+def test_tick_into_the_ring_texture_equals_the_host_round_trip(torch_cuda):
+    # the widget's tick (gpu_spectrogram.rs:255-275) device to device (sgx_live_tick_view) against the same tick through a host
+    # array and sgx_view_write_rows: same rows, same offset, same picture
+    torch = torch_cuda
+    rng = np.random.default_rng(5)
+    pics = []
+    for direct in (False, True):
+        eng = engine(period=0.05, hop_samples=58, channels=2, gradient="magma")
+        live, view = eng.live(8192, reference_skip=True), eng.view(64)
+        rng = np.random.default_rng(5)
+        total = 0
+        for n in (2400, 700, 58, 4000, 1):
+            live.push(rng.uniform(-0.5, 0.5, (n, 2)).astype(np.float32), 2)
+            if direct:
+                total += live.tick_into(view)
+            else:
+                rows = live.tick("mags_f16")
+                total += rows.shape[0]
+                if rows.shape[0]:
+                    view.write_rows(torch.from_numpy(np.ascontiguousarray(rows)).cuda())
+        pics.append((total, view.offset, view.draw(96, 40).cpu().numpy()))
+        view.close(); live.close(); eng.close()
+    assert pics[0][0] == pics[1][0] > 64 and pics[0][1] == pics[1][1]       # more rows than the texture holds: it wrapped
+    assert np.array_equal(pics[0][2], pics[1][2])
