@@ -285,30 +285,9 @@ def main_rank(args):
     # life (profiles/r03_k1_slow_box.txt; round 2 took this for a property of the box).  The buffer is the caller's, so the caller
     # chooses: up to --placements candidates are allocated and timed (3 launches each), the fastest is kept, the others are freed.
     # Every candidate's time is reported (roofline.placement); index 0 is what a caller who allocates once gets.
-    cands, cand_ms = [], []
-    for _ in range(max(1, args.placements)):
-        try:
-            buf = torch.empty((F, 1, M, 2), dtype=torch.float32, device=eng.device)
-        except RuntimeError:     # out of memory: what we have is what we compare
-            break
-        buf.zero_()  # first touch of the 16 GB output buffer belongs to the allocation, not to a step
-        eng.stft_batch(pcm, out=buf)
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _i in range(3):
-            eng.stft_batch(pcm, out=buf)
-        e1.record()
-        torch.cuda.synchronize()
-        cands.append(buf)
-        cand_ms.append(e0.elapsed_time(e1) / 3.0)
-    chosen = min(range(len(cands)), key=lambda i: cand_ms[i])
-    mags = cands[chosen]
-    del cands, buf
-    torch.cuda.empty_cache()
-    placement = {"candidates_ms_per_launch": cand_ms, "chosen": chosen,
-                 "frac_of_candidate_0": F * ALGO_BYTES_STFT / (cand_ms[0] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                 "why": "physical placement of the output buffer: profiles/r03_k1_slow_box.txt"}
+    mags, placement = place_output(torch, args.placements,
+                                   lambda: torch.empty((F, 1, M, 2), dtype=torch.float32, device=eng.device),
+                                   lambda buf: eng.stft_batch(pcm, out=buf), F * ALGO_BYTES_STFT)
 
     def timed_launches(n):
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
@@ -454,6 +433,36 @@ def main_rank(args):
     return 0
 
 
+def place_output(torch, n_candidates, alloc, launch, bytes_per_launch):
+    """The rate of a store-heavy launch depends on the physical pages of its output buffer (profiles/r03_k1_slow_box.txt): up to
+    n_candidates buffers are allocated (all alive at once, so that they are different pages) and timed (1 warm-up + 3 launches),
+    the fastest is kept, the others are freed.  Returns (buffer, report); report lists every candidate."""
+    cands, ms = [], []
+    for _ in range(max(1, n_candidates)):
+        try:
+            buf = alloc()
+        except RuntimeError:     # out of memory: what we have is what we compare
+            break
+        buf.zero_()              # first touch belongs to the allocation, not to a step
+        launch(buf)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _i in range(3):
+            launch(buf)
+        e1.record()
+        torch.cuda.synchronize()
+        cands.append(buf)
+        ms.append(e0.elapsed_time(e1) / 3.0)
+    chosen = min(range(len(cands)), key=lambda i: ms[i])
+    keep = cands[chosen]
+    del cands
+    torch.cuda.empty_cache()
+    return keep, {"candidates_ms_per_launch": ms, "chosen": chosen,
+                  "frac_of_candidate_0": bytes_per_launch / (ms[0] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                  "why": "physical placement of the output buffer: profiles/r03_k1_slow_box.txt"}
+
+
 def device_streaming_rates(torch, buf):
     flat = buf.view(-1)
     half = flat.numel() // 2
@@ -562,8 +571,8 @@ def stereo_leg(args, torch, device):
     Fs = args.stereo_frames
     eng = SpectrogramEngine(48000.0, window_samples=W, hop_samples=H, channels=2, device=device)
     pcm = eng.white_noise((Fs - 1) * H + W)
-    out = torch.empty((Fs, 1, M, 2), dtype=torch.float32, device=eng.device)
-    out.zero_()
+    out, placement = place_output(torch, args.placements, lambda: torch.empty((Fs, 1, M, 2), dtype=torch.float32, device=eng.device),
+                                  lambda buf: eng.stft_batch(pcm, out=buf), Fs * ALGO_BYTES_STEREO)
     ms = event_times(torch, lambda: eng.stft_batch(pcm, out=out), reps=5, warm=2)
     mean = sum(ms) / len(ms)
     achieved = Fs * ALGO_BYTES_STEREO / (mean * 1e-3) / 1e9
@@ -572,7 +581,7 @@ def stereo_leg(args, torch, device):
         "frames_per_s": Fs / (mean * 1e-3), "launch_ms": stats_ms(ms),
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "bytes_per_frame": ALGO_BYTES_STEREO, "frames_per_launch": Fs,
-                     "kernel": "sgx::wg::stft4096_wg_kernel<false, 1, true, false>",
+                     "kernel": "sgx::wg::stft4096_wg_kernel<false, 1, true, false>", "placement": placement,
                      "note": "bound by the LDS write path of the three exchanges of a transform (DESIGN section 4 K1), not by HBM"},
     }
     del out
@@ -621,8 +630,9 @@ def config4_leg(args, torch, device):
     hops = args.config4_hops
     eng = SpectrogramEngine(48000.0, window_samples=W4, hop_samples=H4, channels=C4, device=device)
     pcm = eng.white_noise((hops - 1) * H4 + W4)
-    out = torch.empty((hops, C4 // 2, W4 - 1, 2), dtype=torch.float32, device=eng.device)
-    out.zero_()
+    out, placement = place_output(torch, args.placements,
+                                  lambda: torch.empty((hops, C4 // 2, W4 - 1, 2), dtype=torch.float32, device=eng.device),
+                                  lambda buf: eng.stft_batch(pcm, out=buf), hops * ALGO_BYTES_CFG4)
     ms = event_times(torch, lambda: eng.stft_batch(pcm, out=out), reps=5, warm=2)
     mean = sum(ms) / len(ms)
     achieved = hops * ALGO_BYTES_CFG4 / (mean * 1e-3) / 1e9
@@ -637,7 +647,7 @@ def config4_leg(args, torch, device):
             "bytes_per_hop_position": ALGO_BYTES_CFG4, "hop_positions_per_launch": hops,
             "traffic": ((traffic or {}).get("config4_bytes_per_hop") or 0) * hops or None,
             "traffic_source": (traffic or {}).get("source"),
-            "kernel": name[1],
+            "kernel": name[1], "placement": placement,
             "note": "launch = the de-interleave pass + the transform kernel (both inside the timed call)",
         },
     }

@@ -101,6 +101,16 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void *base)
 #ifndef D_OUT_AUX
 #define D_OUT_AUX 2   // nt: a write-once stream (same-device A/B: 0.80 -> 0.73 ms per 20 000 transforms)
 #endif
+// A 16-byte buffer store followed at once by a vector write of one of its data registers: the compiler's hazard table asks for
+// wait states only when the store's scalar offset is an immediate; with the offset in an SGPR it inserts none, and on this device
+// the word then stored was the NEW value (seen as LDS addresses inside stored rows: the address arithmetic of the next piece
+// reuses the data registers of the piece just stored).  Two wait states after every such store.
+__device__ __forceinline__ void store16(u32x4 v, __amdgpu_buffer_rsrc_t r, int voff, int soff, int aux_is_compile_time_below)
+{
+    (void)aux_is_compile_time_below;
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, soff, D_OUT_AUX);
+    asm volatile("s_nop 2");
+}
 #ifdef D_ABL_NOSTORE
 #define D_STORE_OK(v) ((v) == 12345.678f)   // ablation builds: (practically) never true, but the value stays live
 #else
@@ -215,6 +225,38 @@ __global__ void __launch_bounds__(1024, 1) stft16384_d_kernel(Params p)
         prefetch(cur);
         take(cur.data_second);
     }
+    // The finished row of a transform waits in LDS (`stage`) and is read back and stored by the NEXT iteration, behind its first
+    // barrier: the wait for the staging writes and the latency of the read-back then fall on that barrier (which the iteration
+    // needs anyway) and on the twiddle multiplies of the first half of its image, instead of on a barrier of their own at the
+    // end of the transform (same-device A/B: profiles/r03_k16_ablation.txt).
+    constexpr int kStage = 8 * 4 * kS1;   // behind rows 0..7 of the first image (and the partner slots): 8704
+    struct Pending { long long f0, f1; uint32_t pair; bool have_first, have_second, valid; } prev{0, 0, 0, false, false, false};
+    auto flush = [&](const Pending &o) {
+        const float2 *stage = buf + kStage;
+        // rows: bin k lives at byte 8 (k - 1) of its row
+        const __amdgpu_buffer_rsrc_t r0 = uniform_rsrc(p.mags + (((size_t)(o.have_first ? o.f0 : 0) * p.pairs + o.pair) * (size_t)kM) * 2);
+        const __amdgpu_buffer_rsrc_t r1 = uniform_rsrc(p.mags + (((size_t)o.f1 * p.pairs + o.pair) * (size_t)kM) * 2);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = tid + 1024 * i;           // bins 2 c, 2 c + 1 (0-based); the last piece of the row holds one bin
+            const float4 v = *reinterpret_cast<const float4 *>(stage + 2 * c + 8 * (c >> 10));
+            if (!D_STORE_OK(v.x)) continue;
+            const bool whole = c != 4095;
+            if (MONO) {
+                if (o.have_first) {
+                    if (whole) store16(u32x4{__float_as_uint(v.x), __float_as_uint(v.x), __float_as_uint(v.z), __float_as_uint(v.z)}, r0, 16 * tid, 16384 * i, 0);
+                    else __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(v.x), __float_as_uint(v.x)}, r0, 16 * tid, 16384 * i, D_OUT_AUX);
+                }
+                if (o.have_second) {
+                    if (whole) store16(u32x4{__float_as_uint(v.y), __float_as_uint(v.y), __float_as_uint(v.w), __float_as_uint(v.w)}, r1, 16 * tid, 16384 * i, 0);
+                    else __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(v.y), __float_as_uint(v.y)}, r1, 16 * tid, 16384 * i, D_OUT_AUX);
+                }
+            } else {
+                if (whole) store16(u32x4{__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)}, r0, 16 * tid, 16384 * i, 0);
+                else __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(v.x), __float_as_uint(v.y)}, r0, 16 * tid, 16384 * i, D_OUT_AUX);
+            }
+        }
+    };
     for (unsigned long long job = job_begin; job < job_end; job += job_step) {
         long long f0, f1;
         bool have_first = true, have_second = true;
@@ -240,11 +282,13 @@ __global__ void __launch_bounds__(1024, 1) stft16384_d_kernel(Params p)
         pretwiddle8_w16(orr, oi);
         fft8(er, ei);
         fft8(orr, oi);
-        lds_barrier();  // the previous transform's partner reads are complete
+        lds_barrier();  // the previous transform's partner reads are complete, its staged row is complete
+        if (prev.valid) flush(prev);
         {
             float2 *w1 = buf + tid;   // element (index, r) at 4 index + r = 4 (q kS1 + col) + r = 4 q kS1 + tid
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
+                if (j == 4) lds_barrier();   // rows 8..15 of the image lie over the staged row: everyone has read it back
                 const int pos = FFT8_OUT[j];
                 const float2 ve = make_float2(er[pos], ei[pos]);
                 const float2 vo = make_float2(orr[pos], oi[pos]);
@@ -343,16 +387,14 @@ __global__ void __launch_bounds__(1024, 1) stft16384_d_kernel(Params p)
         const float2 *pp = buf + (u == 0 ? 1024 + L : 4 * (256 - u) + L);                       // + 1024 (7 - qq), qq >= 1
         const float2 *pp0 = buf + (u == 0 ? (L == 2 ? 3 : (L == 1 ? 2 : 0)) : 1024 * 7 + 4 * (256 - u) + L);   // qq = 0
         const int kbase = (L == 0 ? 0 : (L == 1 ? 6144 : (L == 2 ? 4096 : 2048))) + u;        // bin k = kbase + 256 qq
-        // rows: bin k lives at byte 8 (k - 1) of its row
-        const __amdgpu_buffer_rsrc_t r0 = uniform_rsrc(p.mags + (((size_t)(have_first ? f0 : 0) * p.pairs + pair) * (size_t)kM) * 2);
-        const __amdgpu_buffer_rsrc_t r1 = uniform_rsrc(p.mags + (((size_t)f1 * p.pairs + pair) * (size_t)kM) * 2);
         // The row is put together in LDS and leaves as 16 bytes per lane, consecutive lanes consecutive addresses: a wave of this
         // kernel holds 16 consecutive bins of four distant parts of the row, and storing them as they lie -- 8 bytes per lane,
         // four 128-byte runs per instruction, 128 instructions per transform -- cost a third of the launch (ablation: 0.90 ms per
         // 20 000 transforms against 0.61 ms without the stores; profiles/r03_k16_ablation.txt).  Staging area: behind the
-        // partner slots (no barrier between their reads and these writes); bin k at slot (k - 1) + 8 ((k - 1) >> 11): the four
-        // parts of the row a wave writes at once are 2048 bins apart and would meet in the same banks.
-        float2 *stage = buf + 8192;
+        // partner slots and the first eight rows of the next image (no barrier between the partner reads and these writes);
+        // bin k at slot (k - 1) + 8 ((k - 1) >> 11): the four parts of the row a wave writes at once are 2048 bins apart and
+        // would meet in the same banks.  The row is read back and stored by the next iteration (`flush`).
+        float2 *stage = buf + kStage;
 #pragma unroll
         for (int qq = 0; qq < 8; ++qq) {
             const int pos = FFT16_OUT[qq];
@@ -366,29 +408,13 @@ __global__ void __launch_bounds__(1024, 1) stft16384_d_kernel(Params p)
             const int b = kbase + 256 * qq - 1;     // 0-based bin
             if (!dc) stage[b + 8 * (b >> 11)] = make_float2(ml, mr);
         }
-        lds_barrier();
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int c = tid + 1024 * i;           // bins 2 c, 2 c + 1 (0-based); the last piece of the row holds one bin
-            const float4 v = *reinterpret_cast<const float4 *>(stage + 2 * c + 8 * (c >> 10));
-            if (!D_STORE_OK(v.x)) continue;
-            const bool whole = c != 4095;
-            if (MONO) {
-                if (have_first) {
-                    if (whole) __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v.x), __float_as_uint(v.x), __float_as_uint(v.z), __float_as_uint(v.z)}, r0, 16 * tid, 16384 * i, D_OUT_AUX);
-                    else __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(v.x), __float_as_uint(v.x)}, r0, 16 * tid, 16384 * i, D_OUT_AUX);
-                }
-                if (have_second) {
-                    if (whole) __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v.y), __float_as_uint(v.y), __float_as_uint(v.w), __float_as_uint(v.w)}, r1, 16 * tid, 16384 * i, D_OUT_AUX);
-                    else __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(v.y), __float_as_uint(v.y)}, r1, 16 * tid, 16384 * i, D_OUT_AUX);
-                }
-            } else {
-                if (whole) __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)}, r0, 16 * tid, 16384 * i, D_OUT_AUX);
-                else __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(v.x), __float_as_uint(v.y)}, r0, 16 * tid, 16384 * i, D_OUT_AUX);
-            }
-        }
+        prev = Pending{f0, f1, pair, have_first, have_second, true};
         if (more) take(nxt.data_second);
         cur = nxt;
+    }
+    if (prev.valid) {   // the last transform's row
+        lds_barrier();
+        flush(prev);
     }
 }
 
