@@ -63,6 +63,7 @@ KERNEL_NAMES = {
     7: ("stft16384 workgroup-per-transform (1024 threads, whole transform in LDS)", "sgx::wg16k::stft16384_wg_kernel<false>"),
     8: ("stft16384 as four time-decimated 4096-point transforms in the lanes of a quad (1024 threads per transform, DPP recombination)",
         "sgx::d16k::stft16384_d_kernel<false>"),
+    9: ("stft4800 workgroup-per-transform (320 threads, 16 x 20 x 15, resident twiddles, mono frame pairs)", "sgx::w48::stft4800_wg_kernel<0, false>"),
 }
 
 

@@ -91,6 +91,7 @@ typedef struct sgx_config {
 #define SGX_FLAG_LUT_WALK 64u      /* fused pixel kernel: walk the dB thresholds from the log2 seed even where the host has shown that one compare pair settles the LUT index (A/B, and the test of the fallback) */
 #define SGX_FLAG_LEGACY_16K 32u    /* W = 8192: the first 16384-point kernel (whole transform in LDS, one workgroup per CU) instead of the four-residue one (A/B) */
 #define SGX_FLAG_RESIDUE_16K 128u  /* W = 8192: the second 16384-point kernel (four 4096-point residues of the OUTPUT, two passes of a 512-thread workgroup) instead of the time-decimated one (A/B) */
+#define SGX_FLAG_MIXED_GENERIC 256u /* W = 2400: the composite-radix kernel (any 2-3-5-7-smooth length) instead of the tuned 4800-point one (A/B) */
 #define SGX_FLAG_WAVE_KERNEL 2u   /* W = 2048: use the wave-per-transform kernel instead of the workgroup-per-transform one (A/B) */
 
 typedef struct sgx_info {
@@ -104,7 +105,7 @@ typedef struct sgx_info {
     uint32_t rows;            /* R */
     uint32_t sample_rate_u32; /* SampleRate(sample_rate as u32)      simple_spectrogram.rs:138 */
     uint32_t total_samples_per_column; /* sum over rows of magnitude_in's sample count */
-    uint32_t stft_kernel;     /* 0 = generic power-of-two, 1 = 4096-point wave-per-transform, 2 = 4096-point workgroup-per-transform (default), 3 = the same with packed (re, im) arithmetic, 4 = Bluestein chirp-z (any 2W), 5 = 16384-point as four 4096-point residues of the output (SGX_FLAG_RESIDUE_16K), 6 = mixed radix (2W = 2^a 3^b 5^c 7^d <= 20480, e.g. the application's 4800, 4410 and 19200), 7 = 16384-point, whole transform in LDS (SGX_FLAG_LEGACY_16K), 8 = 16384-point as four time-decimated 4096-point transforms in the lanes of a quad, one 1024-thread workgroup per transform (default for W = 8192) */
+    uint32_t stft_kernel;     /* 0 = generic power-of-two, 1 = 4096-point wave-per-transform, 2 = 4096-point workgroup-per-transform (default), 3 = the same with packed (re, im) arithmetic, 4 = Bluestein chirp-z (any 2W), 5 = 16384-point as four 4096-point residues of the output (SGX_FLAG_RESIDUE_16K), 6 = mixed radix (2W = 2^a 3^b 5^c 7^d <= 20480, e.g. the application's 4800, 4410 and 19200), 7 = 16384-point, whole transform in LDS (SGX_FLAG_LEGACY_16K), 8 = 16384-point as four time-decimated 4096-point transforms in the lanes of a quad, one 1024-thread workgroup per transform (default for W = 8192), 9 = 4800-point workgroup-per-transform, 16 x 20 x 15 (default for W = 2400, the application's window at 48 kHz; streams of more than two channels run 6) */
     uint32_t render_path;     /* sgx_render_batch as configured NOW (palette included): bit 0 = one fused PCM-to-pixel kernel (the
                                  4096-point kernel, or a compile-time plan of the mixed-radix kernel whose LDS image holds the column),
                                  bit 1 = its LUT index is seed + one compare pair (else seed + walk); neither = two kernels;

@@ -230,7 +230,8 @@ hipError_t run_stft(const sgx_ctx *c, const float *d_pcm, uint32_t channels, uin
         return sgx::launch_stft_d16384(c, c->d_d16k, d_pcm, channels, pairs, first, n, total, d_mags);
     if (c->stft_kernel == 7 && (channels != 1 || !(c->cfg.flags & SGX_FLAG_INDEPENDENT_FRAMES)))
         return sgx::launch_stft_wg16384(c, c->d_fast_16k, d_pcm, channels, pairs, first, n, total, d_mags);
-    if (c->stft_kernel == 6) return sgx::launch_stft_mixed(c, c->d_mix, d_pcm, channels, pairs, first, n, total, d_mags);
+    if (c->stft_kernel == 9 && channels <= 2) return sgx::launch_stft_w4800(c, c->d_w4800, d_pcm, channels, first, n, total, d_mags, false);
+    if (c->stft_kernel == 6 || c->stft_kernel == 9) return sgx::launch_stft_mixed(c, c->d_mix, d_pcm, channels, pairs, first, n, total, d_mags);
     if (c->stft_kernel == 4 && c->d_chz) return sgx::launch_stft_chirpz(c, c->d_chz, d_pcm, channels, pairs, first, n, total, d_mags);
     if (c->stft_kernel == 4) return sgx::launch_stft_bluestein(c, c->d_blu, d_pcm, channels, pairs, first, n, total, d_mags);
     if (c->stft_kernel == 3) return sgx::launch_stft_wgp4096(c, c->d_fast_wg, d_pcm, channels, pairs, first, n, total, d_mags);
@@ -364,6 +365,11 @@ int sgx_create(const sgx_config *cfg, sgx_ctx **out_ctx)
         e = sgx::mixed_init(c, &c->d_mix);
         if (e != hipSuccess) return bail(SGX_ERR_HIP, std::string("sgx_create: mixed-radix tables: ") + hipGetErrorString(e));
         c->stft_kernel = 6;
+        if (!(cfg->flags & (SGX_FLAG_FORCE_GENERIC | SGX_FLAG_MIXED_GENERIC)) && sgx::w4800_supported(c)) {
+            e = sgx::w4800_init(c, &c->d_w4800);
+            if (e != hipSuccess) return bail(SGX_ERR_HIP, std::string("sgx_create: 4800-point kernel tables: ") + hipGetErrorString(e));
+            c->stft_kernel = 9;
+        }
     } else if (!pow2) {
         e = sgx::bluestein_init(c, &c->d_blu);
         if (e != hipSuccess) return bail(SGX_ERR_HIP, std::string("sgx_create: Bluestein tables: ") + hipGetErrorString(e));
@@ -407,6 +413,7 @@ void sgx_destroy(sgx_ctx *c)
     sgx::bluestein_destroy(c->d_blu);
     c->d_blu = nullptr;
     sgx::mixed_destroy(c->d_mix);
+    sgx::w4800_destroy(c->d_w4800);
     c->d_mix = nullptr;
     sgx::chirpz_destroy(c->d_chz);
     c->d_chz = nullptr;
@@ -443,9 +450,9 @@ int sgx_query(const sgx_ctx *c, sgx_info *out)
     out->render_path = 0;
     if ((c->stft_kernel == 2 || c->stft_kernel == 3) && !(c->cfg.flags & SGX_FLAG_NO_FUSED_RENDER) && sgx::wg4096_can_fuse_render(c, c->d_fast_wg))
         out->render_path = 1u | (sgx::wg4096_seed_is_within_one(c) ? 2u : 0u);
-    if (c->stft_kernel == 6 && sgx::mixed_fixed_plan(c->d_mix)) out->render_path |= 4u;
+    if ((c->stft_kernel == 6 || c->stft_kernel == 9) && sgx::mixed_fixed_plan(c->d_mix)) out->render_path |= 4u;
     if (c->stft_kernel == 4 && c->d_chz) out->render_path |= 4u;
-    if (c->stft_kernel == 6 && !(c->cfg.flags & SGX_FLAG_NO_FUSED_RENDER) && sgx::mixed_can_fuse_render(c, c->d_mix)) out->render_path |= 3u;
+    if ((c->stft_kernel == 6 || c->stft_kernel == 9) && !(c->cfg.flags & SGX_FLAG_NO_FUSED_RENDER) && sgx::mixed_can_fuse_render(c, c->d_mix)) out->render_path |= 3u;
     out->mags_bytes_per_frame = (uint64_t)c->pairs * c->M * 2 * sizeof(float);
     out->rgba_bytes_per_frame = (uint64_t)c->pairs * c->R * 4;
     return SGX_OK;
@@ -503,7 +510,10 @@ int sgx_stft_batch_f16(sgx_ctx *c, const float *d_pcm, size_t n_samples, size_t 
     if (c->stft_kernel == 2) {
         hipError_t e = sgx::launch_stft_wg4096_f16(c, c->d_fast_wg, d_pcm, c->C, c->pairs, first_frame, n, total, d_mags_f16);
         if (e != hipSuccess) return fail_hip(c, e, "sgx_stft_batch_f16: kernel launch");
-    } else if (c->stft_kernel == 6) {
+    } else if (c->stft_kernel == 9 && c->C <= 2) {
+        hipError_t e = sgx::launch_stft_w4800(c, c->d_w4800, d_pcm, c->C, first_frame, n, total, static_cast<float *>(d_mags_f16), true);
+        if (e != hipSuccess) return fail_hip(c, e, "sgx_stft_batch_f16: kernel launch");
+    } else if (c->stft_kernel == 6 || c->stft_kernel == 9) {
         // the application's own window lengths: half pairs straight from the split (no float32 round trip)
         hipError_t e = sgx::launch_stft_mixed(c, c->d_mix, d_pcm, c->C, c->pairs, first_frame, n, total, static_cast<float *>(d_mags_f16), true);
         if (e != hipSuccess) return fail_hip(c, e, "sgx_stft_batch_f16: kernel launch");
@@ -572,7 +582,7 @@ int sgx_render_batch(sgx_ctx *c, const float *d_pcm, size_t n_samples, size_t fi
         if (n_out) *n_out = n;
         return SGX_OK;
     }
-    if (c->stft_kernel == 6 && !(c->cfg.flags & SGX_FLAG_NO_FUSED_RENDER) && sgx::mixed_can_fuse_render(c, c->d_mix)) {
+    if ((c->stft_kernel == 6 || c->stft_kernel == 9) && !(c->cfg.flags & SGX_FLAG_NO_FUSED_RENDER) && sgx::mixed_can_fuse_render(c, c->d_mix)) {
         // the application's own window lengths, one kernel from PCM to pixels: the pixel stage runs on the transform's LDS image
         hipError_t e = sgx::launch_render_mixed(c, c->d_mix, d_pcm, c->C, c->pairs, first_frame, n, total, d_rgba);
         if (e != hipSuccess) return fail_hip(c, e, "sgx_render_batch: fused launch");

@@ -83,7 +83,7 @@ struct sgx_ctx {
     uint32_t W = 0, P = 0, M = 0, H = 0, C = 0, pairs = 0, R = 0, sr_u32 = 0, logP = 0;
     int device = 0;
     hipStream_t stream = nullptr;
-    int stft_kernel = 0;  // 0 generic, 1 tuned 4096 wave-per-transform, 2 tuned 4096 workgroup-per-transform (scalar codelets), 3 the same with packed (re, im) arithmetic, 4 Bluestein (2W not a power of two), 5 tuned 16384, second design (four 4096-point residues), 6 mixed radix (2W = 2^a 3^b 5^c 7^d), 7 tuned 16384, first design (whole transform in LDS), 8 tuned 16384, third design (time-decimated lane quads)
+    int stft_kernel = 0;  // 0 generic, 1 tuned 4096 wave-per-transform, 2 tuned 4096 workgroup-per-transform (scalar codelets), 3 the same with packed (re, im) arithmetic, 4 Bluestein (2W not a power of two), 5 tuned 16384, second design (four 4096-point residues), 6 mixed radix (2W = 2^a 3^b 5^c 7^d), 7 tuned 16384, first design (whole transform in LDS), 8 tuned 16384, third design (time-decimated lane quads), 9 tuned 4800 (W = 2400; more than two channels: 6)
 
     sgx::Tables tab;
     sgx::Palette pal;
@@ -103,6 +103,7 @@ struct sgx_ctx {
     void *d_fast_wg = nullptr;     // tables of the workgroup-per-transform kernel
     void *d_blu = nullptr;         // tables of the Bluestein (non-power-of-two) kernel
     void *d_mix = nullptr;         // tables of the mixed-radix (2, 3, 5, 7-smooth lengths) kernel
+    void *d_w4800 = nullptr;       // tables of the tuned 4800-point kernel (W = 2400: the application's window at 48 kHz)
     void *d_chz = nullptr;         // chirp-z through the mixed-radix kernel's stages (or null: the radix-4 ladder of stft_bluestein.hip)
     void *d_fast_16k = nullptr;    // tables of the 16384-point kernel, first design (one 1024-thread workgroup per transform)
     void *d_q16k = nullptr;        // tables of the 16384-point kernel, four 4096-point residues of the output (SGX_FLAG_RESIDUE_16K)
@@ -189,6 +190,13 @@ hipError_t q16384_init(sgx_ctx *c, void **out);
 void q16384_destroy(void *tables);
 hipError_t launch_stft_q16384(const sgx_ctx *c, void *tables, const float *d_pcm, uint32_t channels, uint32_t pairs,
                               size_t first_frame, size_t n_frames, size_t total_frames, float *d_mags);
+// W = 2400 (48 kHz x 0.05 s): persistent 320-thread workgroups, 16 x 20 x 15 (stft4800_wg.hip); rows and half rows of one or two channels -- more
+// channels and the fused PCM-to-pixel path go to the composite-radix kernel, whose tables such a context carries too
+bool w4800_supported(const sgx_ctx *c);
+hipError_t w4800_init(sgx_ctx *c, void **out);
+void w4800_destroy(void *tables);
+hipError_t launch_stft_w4800(const sgx_ctx *c, const void *tables, const float *d_pcm, uint32_t channels, size_t first_frame, size_t n_frames,
+                             size_t total_frames, float *d_mags, bool out_f16);
 bool mixed_supported(uint32_t W);
 hipError_t mixed_init(sgx_ctx *c, void **out);
 void mixed_destroy(void *tables);

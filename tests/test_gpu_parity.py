@@ -130,6 +130,56 @@ def test_4096_point_kernel_on_interleaved_channel_pairs(torch_cuda, mags_err, gr
     assert px.shape == (14, ch // 2, R, 4) and np.array_equal(px.reshape(own.shape), own)
 
 
+@pytest.mark.parametrize("ch,independent", [(2, False), (1, False), (1, True), (4, False)])
+@pytest.mark.parametrize("variant", ["tuned", "composite"])
+def test_app_point_4800_point_kernel(torch_cuda, mags_err, gradients, ch, independent, variant):
+    # The application's own window (48 kHz x 0.05 s = W 2400, 2W = 4800 = 16 x 20 x 15; hop 93 = (2 / 1024) s): the tuned
+    # workgroup-per-transform kernel (default for one and two channels; more channels run the composite-radix kernel of any smooth
+    # length) and that kernel itself (SGX_FLAG_MIXED_GENERIC), each against the oracle -- rows, half rows, pixel columns
+    torch = torch_cuda
+    Wt, Ht = 2400, 93
+    eng = engine(window_samples=Wt, hop_samples=Ht, channels=ch, independent_frames=independent, mixed_generic=(variant == "composite"),
+                 gradient="viridis")
+    assert eng.info.stft_kernel == (9 if variant == "tuned" else 6)
+    frames = 1900   # 768 persistent workgroups on a 256-CU device: mono pairs -> 950 jobs, two per workgroup for some; stereo -> 3 per workgroup
+    n = Wt + (frames - 1) * Ht + 17
+    pcm = oracle.white_noise(n * ch, seed=300 + ch)
+    dev = to_dev(torch, pcm)
+    got = eng.stft_batch(dev).cpu().numpy()
+    ref = oracle.stream_process(pcm, ch, Wt, Ht, threads=8)
+    assert got.shape == ref.shape == (frames, max(ch // 2, 1), Wt - 1, 2)
+    assert mags_err(got, ref) <= 2.0
+    lr = pcm.reshape(-1, ch)
+    for f in (0, 7, frames - 1):
+        truth = oracle.np_truth_frame(np.stack([lr[f * Ht:f * Ht + Wt, 0], lr[f * Ht:f * Ht + Wt, min(1, ch - 1)]], 1), Wt)
+        assert mags_err(got[f, 0], truth) <= 1.0
+    for _ in range(3):   # the same bytes every time
+        assert np.array_equal(eng.stft_batch(dev).cpu().numpy(), got)
+    for first, cnt in ((1, 4), (6, 3), (frames - 1, 1), (3, 1001)):   # sub-ranges give the same bytes (mono pairs by global index)
+        assert np.array_equal(eng.stft_batch(dev, first_frame=first, max_frames=cnt).cpu().numpy(), got[first:first + cnt])
+    assert torch.equal(eng.stft_batch_f16(dev), torch.from_numpy(got).cuda().to(torch.float16))
+    assert torch.equal(eng.stft_batch_f16(dev, first_frame=5, max_frames=77), torch.from_numpy(got[5:82]).cuda().to(torch.float16))
+    # PCM -> RGBA.  One kernel from PCM to pixels is the composite-radix kernel's (the tuned kernel writes rows only), so a default
+    # context renders what a SGX_FLAG_MIXED_GENERIC context renders; the two-kernel route (SGX_FLAG_NO_FUSED_RENDER) runs the pixel
+    # stage on the context's own rows.  Either way: the oracle's pixel stage on the magnitudes that were rendered, byte for byte
+    px = eng.render_batch(dev).cpu().numpy()
+    assert px.shape == (frames, max(ch // 2, 1), R, 4)
+    assert bool(eng.info.render_path & 1)
+    assert np.array_equal(eng.render_batch(dev, first_frame=3, max_frames=50).cpu().numpy(), px[3:53])
+    split = engine(window_samples=Wt, hop_samples=Ht, channels=ch, independent_frames=independent, mixed_generic=(variant == "composite"),
+                   gradient="viridis", fused_render=False)
+    own = oracle.render_columns(got.reshape(-1, Wt - 1, 2), SR, gradients["viridis"])
+    assert np.array_equal(split.render_batch(dev).cpu().numpy().reshape(own.shape), own)
+    split.close()
+    if variant == "composite" or ch > 2:
+        assert np.array_equal(px.reshape(own.shape), own)
+    else:
+        comp = engine(window_samples=Wt, hop_samples=Ht, channels=ch, independent_frames=independent, mixed_generic=True, gradient="viridis")
+        assert np.array_equal(comp.render_batch(dev).cpu().numpy(), px)
+        comp.close()
+    eng.close()
+
+
 @pytest.mark.parametrize("ch,variant", [(8, "quad"), (2, "quad"), (1, "quad"), (8, "residue"), (2, "residue"), (1, "residue"), (8, "generic")])
 def test_config4_16384_point_kernel(torch_cuda, mags_err, ch, variant):
     # BASELINE config 4: W 8192 / P 16384, hop 512, interleaved channel pairs; the time-decimated lane-quad kernel (default), the
@@ -188,7 +238,7 @@ def test_generic_kernel_pairs_mono_frames_by_global_index(torch_cuda, mags_err, 
     dev = to_dev(torch, pcm)
     ref = oracle.stream_process(pcm, 1, Wt, Ht, threads=8)
     eng = engine(window_samples=Wt, hop_samples=Ht, channels=1)
-    assert eng.info.stft_kernel == ((0 if Wt < 512 else 6) if Wt & (Wt - 1) == 0 else (4 if Wt == 1102 else 6))
+    assert eng.info.stft_kernel == ((0 if Wt < 512 else 6) if Wt & (Wt - 1) == 0 else (4 if Wt == 1102 else (9 if Wt == 2400 else 6)))
     tol = 2.0
     got = eng.stft_batch(dev).cpu().numpy()
     assert got.shape == ref.shape == (38, 1, Wt - 1, 2)
@@ -264,7 +314,7 @@ def test_duration_sized_windows_like_the_app(torch_cuda, mags_err, sr, period, W
         pytest.skip("2W = 19 200 is beyond the chirp-z kernel (3W - 1 > 16384): mixed radix only")
     eng = SpectrogramEngine(sr, period=period, stride=2.0 / 1024, channels=2, force_generic=chirp_z)
     smooth = Wexp in (2400, 2205, 480, 100, 9600)
-    assert eng.W == Wexp == oracle.window_samples(sr, period) and eng.info.stft_kernel == (6 if smooth and not chirp_z else 4)
+    assert eng.W == Wexp == oracle.window_samples(sr, period) and eng.info.stft_kernel == ((9 if Wexp == 2400 else 6) if smooth and not chirp_z else 4)
     Ht = eng.H
     assert Ht == oracle.hop_samples(sr, 2.0 / 1024)
     n = Wexp + 12 * Ht + 5
@@ -276,7 +326,7 @@ def test_duration_sized_windows_like_the_app(torch_cuda, mags_err, sr, period, W
     # every kernel, the chirp-z one (two FFTs + three chirp products in float32) included, is held to 1x the tolerance
     # against the float64 truth and 2x against the float32 oracle (two float32 transforms)
     assert mags_err(got[[0, 7, 12], 0], truth) <= 1.0
-    if eng.info.stft_kernel == 6 or max(oracle_prime_factor(2 * Wexp), 2) <= 64:
+    if eng.info.stft_kernel in (6, 9) or max(oracle_prime_factor(2 * Wexp), 2) <= 64:
         assert mags_err(got, ref) <= 2.0   # (a large prime factor is an O(p^2) float32 sum in the float32 oracle: no reference)
     # the pixel path rides on it (two-kernel route) and is bit-exact on the engine's own magnitudes
     eng.set_builtin_gradient("viridis")
@@ -586,7 +636,7 @@ def test_duration_sized_windows_of_the_usual_sample_rates(torch_cuda, mags_err, 
     from spectrogram_rs_amd import SpectrogramEngine
     for ch in (2, 1):
         eng = SpectrogramEngine(float(sr), period=0.05, stride=0.004, channels=ch)
-        assert eng.W == Wexp and eng.info.stft_kernel == 6 and bool(eng.info.render_path & 4) == fixed
+        assert eng.W == Wexp and eng.info.stft_kernel == (9 if Wexp == 2400 else 6) and bool(eng.info.render_path & 4) == fixed
         n = eng.W + 6 * eng.H + 5
         pcm = oracle.white_noise(n * ch, seed=sr % 1000)
         dev = to_dev(torch, pcm)
