@@ -177,6 +177,13 @@ __global__ void __launch_bounds__(kT) __attribute__((amdgpu_waves_per_eu(W48_WAV
     };
     float er[8], ei[8];
     auto take = [&](bool data_second) {
+        // behind the stores: the samples pass through a statement the compiler may not move above them (a memory clobber), so
+        // neither may the products -- nor their wait
+#pragma unroll
+        for (int a = 0; a < 8; ++a) {
+            if (MODE == 2) asm volatile("" : "+v"(pl[a]) :: "memory");
+            else asm volatile("" : "+v"(pl[a]), "+v"(pr[a]) :: "memory");
+        }
         const float *wl = winl + lane1();
 #pragma unroll
         for (int a = 0; a < 8; ++a) {
