@@ -309,11 +309,7 @@ __global__ void __launch_bounds__(1024, 1) stft16384_d_kernel(Params p)
                 xr[t1] = v.x; xi[t1] = v.y;
             }
             fft16(xr, xi);
-#ifdef D_ABL_NOBAR23
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#else
             lds_barrier();  // everyone has read image 1
-#endif
             float2 *w2 = buf + 4 * ((low >> 2) * kS2 + q1_2) + (low & 3);
             const float2 *tw = tw2 + low;
 #pragma unroll
@@ -323,11 +319,7 @@ __global__ void __launch_bounds__(1024, 1) stft16384_d_kernel(Params p)
                 w2[4 * 16 * q2] = q2 == 0 ? v : cmulf(v, tw[64 * q2]);
             }
         }
-#ifdef D_ABL_NOBAR23
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#else
         lds_barrier();
-#endif
 
         // ---- pass 3: lane (u, r), u = tid >> 2 = q1 + 16 q2: FFT16 over t0 -> q3
         {
