@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """K1 / stereo / fused-pixel rates for one run length (SGX_K1_RUN, read by the library once per process) at several places
-inside one 80 GiB allocation (profiles/r03_k1_slow_box.txt, part 6)."""
+inside one 80 GiB allocation (profiles/r03_k1_slow_box.txt, part 6).
+The run-length loop this measured was an experiment and is NOT in the tree (part 6a describes it): against the current library every
+SGX_K1_RUN value reads like the first line of that table."""
 import os
 import sys
 
