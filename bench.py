@@ -610,12 +610,27 @@ def app_point_leg(args, torch, device):
     mean, meanp = sum(ms) / len(ms), sum(msp) / len(msp)
     ach, achp = Fa * ALGO_BYTES_APP / (mean * 1e-3) / 1e9, Fa * ALGO_BYTES_APP_PIXEL / (meanp * 1e-3) / 1e9
     name = KERNEL_NAMES.get(eng.info.stft_kernel, ("?", "?"))
+    # the same point for a mono device (audio_input_list_model.rs:67-69 duplicates the sample into (s, s)): two frames per transform
+    del rgba, pcm
+    mono = SpectrogramEngine(48000.0, period=0.05, hop_samples=H_APP, channels=1, device=device)
+    pcm1 = mono.white_noise((Fa - 1) * H_APP + W_APP)
+    out1 = torch.empty((Fa, 1, W_APP - 1, 2), dtype=torch.float32, device=mono.device)
+    out1.zero_()
+    ms1 = event_times(torch, lambda: mono.stft_batch(pcm1, out=out1), reps=5, warm=2)
+    mean1 = sum(ms1) / len(ms1)
+    bytes1 = H_APP * 4 + (W_APP - 1) * 8
+    ach1 = Fa * bytes1 / (mean1 * 1e-3) / 1e9
+    del out1, pcm1
+    mono.close()
     res = {
         "workload": f"the application's operating point: 48 kHz x 0.05 s = W 2400 (4800-point transform), hop 93, (l, r) stream, {Fa} frames",
         "kernel": name[0], "real_time_factor": Fa / (mean * 1e-3) * H_APP / 48000.0,
         "rows_f32": {"frames_per_s": Fa / (mean * 1e-3), "launch_ms": stats_ms(ms),
                      "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                                   "bytes_per_frame": ALGO_BYTES_APP, "frames_per_launch": Fa}},
+        "mono_rows_f32": {"frames_per_s": Fa / (mean1 * 1e-3), "launch_ms": stats_ms(ms1),
+                          "roofline": {"bound": "hbm", "achieved": ach1, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach1 / HBM_PEAK_GBS,
+                                       "bytes_per_frame": bytes1, "frames_per_launch": Fa}},
         "pcm_to_rgba": {"frames_per_s": Fa / (meanp * 1e-3), "launch_ms": stats_ms(msp), "fused_kernel": bool(eng.info.render_path & 1),
                         "roofline": {"bound": "hbm", "achieved": achp, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achp / HBM_PEAK_GBS,
                                      "bytes_per_frame": ALGO_BYTES_APP_PIXEL, "frames_per_launch": Fa}},
