@@ -84,23 +84,11 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void *base)
 
 // MODE: 0 an (l, r) stream, one frame per transform; 1 a mono stream, frames (2j, 2j+1) per transform; 2 a mono stream, every
 // frame its own (s, s) transform (SGX_FLAG_INDEPENDENT_FRAMES: the reference's dataflow)
-#ifndef W48_WAVES_PER_EU
-#define W48_WAVES_PER_EU 4
-#endif
-// W48_TW_RELOAD: the 15 pass-1 twiddles of a lane are requested again for every transform together with its samples (eight 16-byte
-// words from L2, ahead of the previous transform's stores) instead of staying in 30 registers through passes 2 and 3, where nothing
-// needs them
 #ifndef W48_ABL
 #define W48_ABL 0   // ablation builds (profiles/r03_app_point.txt): 1 no row stores, 2 no sample loads, 4 / 8 no butterfly in pass 2 / 3
 #endif
-#ifndef W48_PREFETCH_AT
-#define W48_PREFETCH_AT 1
-#endif
-#ifndef W48_TW_RELOAD
-#define W48_TW_RELOAD 0
-#endif
 template <int MODE, bool F16>
-__global__ void __launch_bounds__(kT) __attribute__((amdgpu_waves_per_eu(W48_WAVES_PER_EU, W48_WAVES_PER_EU))) stft4800_wg_kernel(Params p)
+__global__ void __launch_bounds__(kT) __attribute__((amdgpu_waves_per_eu(4, 4))) stft4800_wg_kernel(Params p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float2 *buf = reinterpret_cast<float2 *>(smem_raw);
@@ -171,9 +159,6 @@ __global__ void __launch_bounds__(kT) __attribute__((amdgpu_waves_per_eu(W48_WAV
                 if (MODE == 1) pr[a] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, 4 * tl, 4 * kN1 * a + sec, 0));
             }
         }
-#if W48_TW_RELOAD
-        load_tw1();   // (see W48_TW_RELOAD)
-#endif
     };
     float er[8], ei[8];
     auto take = [&](bool data_second) {
@@ -195,15 +180,12 @@ __global__ void __launch_bounds__(kT) __attribute__((amdgpu_waves_per_eu(W48_WAV
         // the prefetch registers and their wait alive across the loop edge)
 #pragma unroll
         for (int a = 0; a < 8; ++a) asm volatile("" : "+v"(er[a]), "+v"(ei[a]));
-#if W48_TW_RELOAD
-        // the twiddles have arrived too: waited for HERE (vmcnt(stores since)), not at the loop header
-#pragma unroll
-        for (int q = 1; q < 16; ++q) asm volatile("" : "+v"(tw1[q].x), "+v"(tw1[q].y));
-#endif
     };
-    JobIn cur = job_in(job_begin);
-    prefetch(cur);
-    take(cur.data_second);
+    {
+        const JobIn first = job_in(job_begin);
+        prefetch(first);
+        take(first.data_second);
+    }
 
     for (unsigned long long job = job_begin; job < job_end; ++job) {
         // local (output) frame indices; mono pairs: f0 may be -1 (the pair's first frame precedes the range)
@@ -221,7 +203,7 @@ __global__ void __launch_bounds__(kT) __attribute__((amdgpu_waves_per_eu(W48_WAV
         pretwiddle8_w16(orr, oi);
         fft8(er, ei);
         fft8(orr, oi);
-        lds_barrier();  // the previous transform's partner reads (its pixel passes) are complete
+        lds_barrier();  // the previous transform's partner reads are complete
         if (const int tid = lane(); tid < kN1) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -260,17 +242,14 @@ __global__ void __launch_bounds__(kT) __attribute__((amdgpu_waves_per_eu(W48_WAV
         // butterfly, where the sixteen extra live registers do not fit)
 #pragma unroll
         for (int i = 0; i < 15; ++i) asm volatile("" : "+v"(y[i].x), "+v"(y[i].y) :: "memory");
-#if W48_PREFETCH_AT == 0
-        prefetch(nxt);   // ahead of this transform's stores (the last transform requests its own samples again: unconditional, so that
-                         // the prefetch registers are dead from `take` to here)
-#endif
         lds_barrier();  // everyone has read image 2
         // partner exchange: publish q3 = 7 .. 14 (the bins P - k of the kept half)
 #pragma unroll
         for (int j = 0; j < 8; ++j) buf[j * kT + lane()] = y[7 + j];
-#if W48_PREFETCH_AT == 1
-        prefetch(nxt);   // ahead of this transform's stores; behind the publish, where eight of the fifteen bins are dead
-#endif
+        // the next transform's samples: ahead of this transform's stores, behind the publish (eight of the fifteen bins are dead there);
+        // unconditional -- the last transform of a run requests its own samples again --, so that the prefetch registers are dead from
+        // `take` to here (with `if (more)` they are a phi of old and new values, live around the whole loop)
+        prefetch(nxt);
         lds_barrier();
 
         // ---- split + magnitude (fft.rs:81-98).  F[P - k] of k = u + 320 q3: thread 320 - u holds it as q3' = 14 - q3 (slot 7 - q3);
@@ -327,7 +306,6 @@ __global__ void __launch_bounds__(kT) __attribute__((amdgpu_waves_per_eu(W48_WAV
             }
         }
         take(nxt.data_second);
-        cur = nxt;
     }
 }
 
