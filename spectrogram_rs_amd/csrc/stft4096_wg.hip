@@ -312,7 +312,11 @@ __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
         // every stored row is 8 store instructions in every wave (the lane of bin 0 is masked, not skipped; the
         // wait below assumes 7, one to spare); the fused pixel path issues table loads and pixel stores of its
         // own: counted as "unknown" = 0
-        issued_since = RENDER ? 0u : 7u * ((have_first ? 1u : 0u) + ((MONO && have_second) ? 1u : 0u));
+        // (the fused pixel path: every wave issues at least n_samples / 256 table loads in the sample pass and R / 256 pixel stores per
+        // stored column in the row pass AFTER the two row loads were requested -- a lower bound is all the wait needs; with "unknown = 0"
+        // the head of the next transform waited for the pixel stores just issued to be acknowledged by memory)
+        issued_since = RENDER ? (p.n_samples >> 8) + (p.R >> 8) * ((have_first ? 1u : 0u) + ((MONO && have_second) ? 1u : 0u))
+                              : 7u * ((have_first ? 1u : 0u) + ((MONO && have_second) ? 1u : 0u));
         if (!RENDER) {
             // ---- store [F][pairs][M][2]: uniform row base (SGPR) + one 32-bit lane offset
             if (p.out_f16) {
