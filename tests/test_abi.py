@@ -47,6 +47,24 @@ def test_struct_layouts_match_the_header():
     assert lib.sgx_version().startswith(b"sgx")
 
 
+def test_python_mirror_constants_match_the_header():
+    # every SGX_FLAG_* / SGX_INTERP_* / SGX_LUT_* / SGX_LIVE_* of include/sgx.h has the same value in the ctypes mirror, flags are
+    # distinct single bits
+    from spectrogram_rs_amd import _lib
+    text = open(os.path.join(ROOT, "include", "sgx.h")).read()
+    defs = {name: int(val) for name, val in re.findall(r"#define\s+SGX_((?:FLAG|INTERP|LUT|LIVE)_\w+)\s+(\d+)u?\b", text)}
+    flags = {k: v for k, v in defs.items() if k.startswith("FLAG_")}
+    assert len(flags) >= 9 and len(set(flags.values())) == len(flags)
+    for name, v in flags.items():
+        assert v & (v - 1) == 0, f"SGX_{name} = {v} is not a single bit"
+    for name, v in defs.items():
+        if hasattr(_lib, name):
+            assert getattr(_lib, name) == v, f"_lib.{name} = {getattr(_lib, name)}, sgx.h says {v}"
+    for must in ("FLAG_FORCE_GENERIC", "FLAG_NO_FUSED_RENDER", "FLAG_INDEPENDENT_FRAMES", "FLAG_RESIDUE_16K", "FLAG_MIXED_GENERIC",
+                 "INTERP_CUBIC", "INTERP_COSINE", "LUT_FLOOR_N"):
+        assert hasattr(_lib, must) and must in defs, must
+
+
 def test_builtin_gradients_match_fixture(gradients):
     import numpy as np
     from spectrogram_rs_amd import builtin_gradient
