@@ -27,8 +27,12 @@
 //   sample index  n = tid + 1024 a      (a < 8; m = col + 256 a, r = tid & 3)
 //   pass 1  lane (col, r)    : 16-point DFT over a (8 non-zero inputs = two 8-point FFTs) -> q1; twiddle w_16384^{q1 tid}
 //   pass 2  lane (q1, t0, r) : col = t0 + 16 t1; 16-point FFT over t1 -> q2; twiddle w_1024^{q2 (4 t0 + r)}   (LDS, 8 KB)
-//   pass 3  lane (u, r), u = q1 + 16 q2 : 16-point FFT over t0 -> q3: G_r[j] w_16384^{r (j mod 256)}, j = u + 256 q3;
-//           twiddle w_64^{r q3} (LDS) completes w_16384^{r j}
+//   pass 3  lane (q1, q2, r), u = q1 + 16 q2 : 16-point FFT over t0 -> q3: G_r[j] w_16384^{r (j mod 256)}, j = u + 256 q3;
+//           twiddle w_64^{r q3} (LDS) completes w_16384^{r j}.  WAVE q1 does both: pass 2 and pass 3 of one q1 exchange through row
+//           q1 of the image, which no other wave touches in between -- no workgroup barrier from the end of pass 1 to the publish
+//           (round 3: -6 % of the launch; until then wave q2 ran pass 3 for all q1, two more barriers).  A wave therefore holds bins
+//           16 apart; rows leave through the LDS staging area anyway, so only LDS index maps changed (partner slots at a stride of 68
+//           per q2, staged row slots swizzled: stage_slot)
 //   combine radix-4 across the quad (two DPP stages): lane L ends with F[j + 4096 c]: c = {0, 2, 1, 3}[L] in its registers q3 < 8
 //           and 3 - c in its registers q3 >= 8 -- so every lane holds 8 kept bins (k < 8192) and 8 partners, and the partner of
 //           its kept (u, q3) is register 15 - q3 of the SAME lane of quad 256 - u: the 4096-point kernel's exchange, unchanged
@@ -49,7 +53,7 @@ __device__ __forceinline__ f2v cl_fma(f2v a, float c, f2v u) { return __builtin_
 
 constexpr int kW = 8192, kP = 16384, kM = 8191;
 constexpr int kS1 = 272;                 // row stride of the pass-1 -> pass-2 image [q1][col]   (as stft4096_wg.hpp)
-constexpr int kS2 = 257;                 // row stride of the pass-2 -> pass-3 image [t0][q1 + 16 q2]
+// (the pass-2 -> pass-3 image lives in the rows of the first: element (q2, t0, r) of row q1 at 68 q2 + 4 t0 + r)
 constexpr int kImg = 16 * kS1;           // indices per residue (4352)
 constexpr int kBufComplex = 4 * kImg;    // 17 408 complex = 139 264 B, the four residues interleaved: (index, r) at 4 index + r
 constexpr size_t kLdsBytes = (size_t)(kBufComplex + 1024 + 64) * sizeof(float2);   // + tw2 [q2][t0][r], tw3 [q3][r]
@@ -116,6 +120,11 @@ __device__ __forceinline__ void store16(u32x4 v, __amdgpu_buffer_rsrc_t r, int v
 #else
 #define D_STORE_OK(v) true
 #endif
+
+// Position of slot i of the staged row.  The lanes of a wave write bins 16 apart (u = q1 + 16 q2) and would meet in two banks; bits
+// 4..6 of the slot index folded into bits 1..3 spread them over sixteen (pairs of slots stay together: the row leaves as 16-byte reads
+// of two consecutive bins, and eight consecutive readers permute among themselves).
+__device__ __forceinline__ int stage_slot(int i) { return i ^ (((i >> 4) & 7) << 1); }
 
 template <bool MONO>
 __global__ void __launch_bounds__(1024, 1) stft16384_d_kernel(Params p)
@@ -239,7 +248,7 @@ __global__ void __launch_bounds__(1024, 1) stft16384_d_kernel(Params p)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int c = tid + 1024 * i;           // bins 2 c, 2 c + 1 (0-based); the last piece of the row holds one bin
-            const float4 v = *reinterpret_cast<const float4 *>(stage + 2 * c + 8 * (c >> 10));
+            const float4 v = *reinterpret_cast<const float4 *>(stage + stage_slot(2 * c + 8 * (c >> 10)));
             if (!D_STORE_OK(v.x)) continue;
             const bool whole = c != 4095;
             if (MONO) {
@@ -309,24 +318,26 @@ __global__ void __launch_bounds__(1024, 1) stft16384_d_kernel(Params p)
                 xr[t1] = v.x; xi[t1] = v.y;
             }
             fft16(xr, xi);
-            lds_barrier();  // everyone has read image 1
-            float2 *w2 = buf + 4 * ((low >> 2) * kS2 + q1_2) + (low & 3);
+            // Row q1 of the image belongs to wave q1 alone from here to the end of pass 3: it read all of it above, writes the pass-2
+            // results back into it (element (q2, t0, r) at 68 q2 + 4 t0 + r: 16 x 68 = the row's 1088 slots) and reads them again as
+            // the pass-3 thread (q1, q2, r) -- LDS instructions of one wave execute in order, so neither the overwrite nor the read-back
+            // needs a workgroup barrier, and the sixteen waves drift apart through two of the three FFT passes.
+            float2 *w2 = buf + 4 * q1_2 * kS1 + low;
             const float2 *tw = tw2 + low;
 #pragma unroll
             for (int q2 = 0; q2 < 16; ++q2) {
                 const int pos = FFT16_OUT[q2];
                 const float2 v = make_float2(xr[pos], xi[pos]);
-                w2[4 * 16 * q2] = q2 == 0 ? v : cmulf(v, tw[64 * q2]);
+                w2[68 * q2] = q2 == 0 ? v : cmulf(v, tw[64 * q2]);
             }
         }
-        lds_barrier();
 
-        // ---- pass 3: lane (u, r), u = tid >> 2 = q1 + 16 q2: FFT16 over t0 -> q3
+        // ---- pass 3: lane (q1, q2, r) = (wave, (tid >> 2) & 15, tid & 3), i.e. u = q1 + 16 q2: FFT16 over t0 -> q3
         {
-            const float2 *r3 = buf + tid;
+            const float2 *r3 = buf + 4 * (tid >> 6) * kS1 + 68 * ((tid >> 2) & 15) + (tid & 3);
 #pragma unroll
             for (int t0 = 0; t0 < 16; ++t0) {
-                const float2 v = r3[4 * t0 * kS2];
+                const float2 v = r3[4 * t0];
                 xr[t0] = v.x; xi[t0] = v.y;
             }
         }
@@ -371,11 +382,13 @@ __global__ void __launch_bounds__(1024, 1) stft16384_d_kernel(Params p)
         }
         lds_barrier();  // everyone has read image 2
         {
-            float2 *wp = buf + tid;   // slot (h, u, L) at 1024 h + tid
+            // slot (h, u, L) at 1088 h + 4 (u & 15) + 68 (u >> 4) + L: the lanes of a wave hold u = q1 + 16 q2 for one q1 -- at a stride of
+            // 68 complex per q2 they fall into different banks, here and in the partner reads below
+            float2 *wp = buf + 4 * (tid >> 6) + 68 * ((tid >> 2) & 15) + L;
 #pragma unroll
             for (int h = 0; h < 8; ++h) {
                 const int pos = FFT16_OUT[8 + h];
-                wp[1024 * h] = make_float2(xr[pos], xi[pos]);
+                wp[1088 * h] = make_float2(xr[pos], xi[pos]);
             }
         }
         lds_barrier();
@@ -383,9 +396,10 @@ __global__ void __launch_bounds__(1024, 1) stft16384_d_kernel(Params p)
         // ---- split + magnitude (fft.rs:81-98).  Kept (u, qq) of lane L pairs with slot h = 7 - qq of lane L of quad 256 - u;
         //      quad 0 is its own mirror one row up (h = 8 - qq), and its qq = 0 partners are single values of other lanes of the
         //      quad: lane 2 (k = 4096) <- lane 3's slot 0; lanes 1, 3 (k = 6144, 2048) <- slot 0 of lanes 2, 0
-        const int u = tid >> 2;
-        const float2 *pp = buf + (u == 0 ? 1024 + L : 4 * (256 - u) + L);                       // + 1024 (7 - qq), qq >= 1
-        const float2 *pp0 = buf + (u == 0 ? (L == 2 ? 3 : (L == 1 ? 2 : 0)) : 1024 * 7 + 4 * (256 - u) + L);   // qq = 0
+        const int u = (tid >> 6) + 16 * ((tid >> 2) & 15);
+        const int up = 256 - u, pslot = 4 * (up & 15) + 68 * ((up >> 4) & 15) + L;   // (u = 0: unused)
+        const float2 *pp = buf + (u == 0 ? 1088 + L : pslot);                                  // + 1088 (7 - qq), qq >= 1
+        const float2 *pp0 = buf + (u == 0 ? (L == 2 ? 3 : (L == 1 ? 2 : 0)) : 1088 * 7 + pslot);   // qq = 0
         const int kbase = (L == 0 ? 0 : (L == 1 ? 6144 : (L == 2 ? 4096 : 2048))) + u;        // bin k = kbase + 256 qq
         // The row is put together in LDS and leaves as 16 bytes per lane, consecutive lanes consecutive addresses: a wave of this
         // kernel holds 16 consecutive bins of four distant parts of the row, and storing them as they lie -- 8 bytes per lane,
@@ -398,7 +412,7 @@ __global__ void __launch_bounds__(1024, 1) stft16384_d_kernel(Params p)
 #pragma unroll
         for (int qq = 0; qq < 8; ++qq) {
             const int pos = FFT16_OUT[qq];
-            const float2 pv = qq == 0 ? pp0[0] : pp[1024 * (7 - qq)];
+            const float2 pv = qq == 0 ? pp0[0] : pp[1088 * (7 - qq)];
             const float ar = xr[pos], ai = xi[pos];
             const float sr_ = ar + pv.x, si_ = ai - pv.y;   // a + conj(b) = 2 L^
             const float dr_ = ar - pv.x, di_ = ai + pv.y;   // a - conj(b) = 2i R^
@@ -406,7 +420,7 @@ __global__ void __launch_bounds__(1024, 1) stft16384_d_kernel(Params p)
             const float mr = __builtin_amdgcn_sqrtf(fmaf(dr_, dr_, di_ * di_));
             const bool dc = qq == 0 && tid == 0;   // k = 0 (DC) is not an output (fft.rs:81)
             const int b = kbase + 256 * qq - 1;     // 0-based bin
-            if (!dc) stage[b + 8 * (b >> 11)] = make_float2(ml, mr);
+            if (!dc) stage[stage_slot(b + 8 * (b >> 11))] = make_float2(ml, mr);
         }
         prev = Pending{f0, f1, pair, have_first, have_second, true};
         if (more) take(nxt.data_second);
