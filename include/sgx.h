@@ -301,7 +301,8 @@ SGX_API int sgx_view_write_rows(sgx_view *view, const void *d_rows_f16, size_t n
 SGX_API uint32_t sgx_view_offset(const sgx_view *view);
 /* One GUI tick of the default widget (gpu_spectrogram.rs:255-275: `for frame in fft.process()` -> fft_texture.write): every
  * complete frame of the live ring, at most max_frames, is transformed and its half-pair row appended to the view's ring texture,
- * device to device -- the only host traffic of the tick is the new samples going up.  `view` must belong to the ring's context. */
+ * device to device -- the only host traffic of the tick is the new samples going up.  `view` must belong to the ring's context: a view of another
+ * (or of a destroyed) context is refused with SGX_ERR_INVALID_ARG before anything is uploaded, transformed or skipped. */
 SGX_API int sgx_live_tick_view(sgx_live *live, sgx_view *view, size_t max_frames, size_t *n_frames);
 /* The fragment program over a width x height viewport: d_rgba_f32 [height][width][4] float = f_color per fragment, row 0
  * at the BOTTOM (GL).  The palette texture is ColorScheme::lookup_table(32) of the context's current colour scheme,

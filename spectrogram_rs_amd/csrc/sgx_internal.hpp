@@ -224,6 +224,7 @@ hipError_t launch_render(const sgx_ctx *c, const float *d_mags, size_t n_columns
 hipError_t launch_magnitude_in(const sgx_ctx *c, const float *d_mags, size_t n_columns, const RowEntry *d_rows,
                                const SampleEntry *d_samples, uint32_t n_ranges, float *d_out);
 void detach_views(sgx_ctx *c);   // sgx_view.hip: every live view of the context forgets it
+sgx_ctx *view_context(const struct sgx_view *v);   // sgx_view.hip: the context a view was created on (nullptr once that context is gone)
 hipError_t launch_white_noise(const sgx_ctx *c, float *d_out, uint64_t first, size_t n, uint32_t channels, uint32_t seed);
 hipError_t launch_checksum(const sgx_ctx *c, const uint32_t *d_words, size_t n_words, uint64_t base_word,
                            unsigned long long *d_acc);

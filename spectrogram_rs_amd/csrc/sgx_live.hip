@@ -149,6 +149,9 @@ static int live_tick(sgx_live *l, int what, void *h_out, sgx_view *view, size_t 
     if (n_frames) *n_frames = 0;
     if (!l) return SGX_ERR_INVALID_ARG;
     sgx_ctx *c = l->ctx;
+    // a view of another context has another row length (its M), another stream and possibly another device: refused before any work
+    if (view && sgx::view_context(view) != c)
+        return live_fail(l, SGX_ERR_INVALID_ARG, "sgx_live_tick_view: the view belongs to another (or a destroyed) context");
     size_t frame_bytes;
     switch (what) {
     case SGX_LIVE_MAGS: frame_bytes = (size_t)c->M * 2 * sizeof(float); break;
@@ -196,7 +199,7 @@ static int live_tick(sgx_live *l, int what, void *h_out, sgx_view *view, size_t 
         if (rc != SGX_OK) return rc;
         if (got != frames) return live_fail(l, SGX_ERR_INVALID_ARG, "sgx_live_tick: frame count mismatch");
         if (view) {
-            rc = sgx_view_write_rows(view, l->d_out, frames, nullptr);   // (answers SGX_ERR_INVALID_ARG for a view of another / a destroyed context)
+            rc = sgx_view_write_rows(view, l->d_out, frames, nullptr);
             if (rc != SGX_OK) return rc;
         } else {
             LIVE_HIP(l, hipMemcpyAsync(h_out, l->d_out, need, hipMemcpyDeviceToHost, c->stream));

@@ -120,6 +120,7 @@ void detach_views(sgx_ctx *c)
     for (sgx_view *v : c->views) v->ctx = nullptr;
     c->views.clear();
 }
+sgx_ctx *view_context(const sgx_view *v) { return v ? v->ctx : nullptr; }
 }  // namespace sgx
 
 extern "C" {

@@ -52,6 +52,7 @@ __device__ __forceinline__ f2v cl_fma(f2v a, float c, f2v u) { return __builtin_
 #include "fft_codelets.inc"
 
 constexpr int kW = 8192, kP = 16384, kM = 8191;
+constexpr uint32_t kXcdHint = 8;         // XCDs of an MI355X (SPX): workgroup i runs on XCD i % 8.  Used for job locality only
 constexpr int kS1 = 272;                 // row stride of the pass-1 -> pass-2 image [q1][col]   (as stft4096_wg.hpp)
 // (the pass-2 -> pass-3 image lives in the rows of the first: element (q2, t0, r) of row q1 at 68 q2 + 4 t0 + r)
 constexpr int kImg = 16 * kS1;           // indices per residue (4352)
@@ -63,13 +64,12 @@ struct Params {
     size_t plane_floats;
     long long sample_base;   // absolute sample index of pcm[0] (the de-interleaved workspace holds a sub-range)
     const float2 *T1;        // [16][1024]  w_16384^{q1 tid} at [q1][tid]
-    const float2 *T1hi;      // [4][1024][2] the same for q1 = 8 + 2 g + e at [g][tid][e]: a lane reads two of them as one 16-byte word
     const float2 *tw2;       // [16][16][4] w_1024^{q2 (4 t0 + r)} at [q2][t0][r]
     const float2 *tw3;       // [16][4]     w_64^{r q3} at [q3][r]
     const float *win8;       // [2][1024][4] hann[tid + 1024 a] / W at [a / 4][tid][a % 4]   (fft.rs:61; the scale (hypot / 2) (2 / W) = 2^-13 rides along)
     float *mags;
     unsigned long long first_frame, n_frames, total_frames, pair_base, n_jobs, jobs_per_xcd;
-    uint32_t xcds;           // 8 when the grid is a multiple of 8 workgroups, else 1 (plain round-robin)
+    uint32_t xcds;           // kXcdHint when the grid is a multiple of it, else 1 (plain round-robin)
     uint32_t H, pairs;
 };
 
@@ -138,11 +138,10 @@ __global__ void __launch_bounds__(1024, 1) stft16384_d_kernel(Params p)
     tw2[tid] = p.tw2[tid];
     if (tid < 64) tw3[tid] = p.tw3[tid];
 
-    // Per-lane constants.  The pass-1 twiddles of q1 < 8 stay in registers for the life of the (persistent) workgroup; those of
-    // q1 >= 8 and the eight Hann factors are requested again for every transform together with its samples (6 x 16 bytes per
-    // lane from L2, ahead of the previous transform's stores): resident, they are live through the three FFT passes and the
-    // recombination, where nothing needs them, and the kernel spilled 7 registers -- window factors, reloaded at the head of the
-    // loop BEHIND the stores.
+    // Per-lane constants: the fifteen pass-1 twiddles and the eight Hann factors stay in registers for the life of the (persistent)
+    // workgroup -- no table traffic per transform.  (An earlier version re-requested the twiddles of q1 >= 8 and the Hann factors
+    // with every transform's samples because, resident, they had been spilled; since the prefetched samples are consumed at the
+    // END of the iteration that requests them -- `take` below -- the registers are there: 128 VGPRs, no scratch.)
     float2 tw1[16];
 #pragma unroll
     for (int q = 1; q < 16; ++q) tw1[q] = p.T1[q * 1024 + tid];
@@ -183,11 +182,6 @@ __global__ void __launch_bounds__(1024, 1) stft16384_d_kernel(Params p)
     auto prefetch = [&](const JobIn &j) {
         const __amdgpu_buffer_rsrc_t rs = uniform_rsrc(j.base);
         const int sec = j.data_second ? second_off : 0;
-        {
-            const __amdgpu_buffer_rsrc_t rt = uniform_rsrc(p.T1hi), rw = uniform_rsrc(p.win8);
-(void)rt;
-(void)rw;
-        }
 #pragma unroll
         for (int a = 0; a < 8; ++a) {
 #ifdef D_ABL_NOLOAD
@@ -220,19 +214,20 @@ __global__ void __launch_bounds__(1024, 1) stft16384_d_kernel(Params p)
 
     };
     // Job order.  Jobs are hop-major (the pairs of one hop position, then the next hop) and consecutive hop positions share
-    // 15/16 of their samples.  Workgroup i runs on XCD i % 8, each XCD has its own L2: every XCD takes one contiguous eighth of
-    // the jobs and deals it round-robin to its workgroups, so that at any time the 32 CUs of an XCD work on ~8 neighbouring hop
-    // positions and a sample is fetched from the fabric once.  (Measured, FETCH_SIZE per hop position: a contiguous run of
+    // 15/16 of their samples.  Workgroup i runs on XCD i % 8 (MI355X in SPX mode: kXcdHint), each XCD has its own L2: every XCD
+    // takes one contiguous eighth of the jobs and deals it round-robin to its workgroups, so that at any time the 32 CUs of an XCD
+    // work on ~8 neighbouring hop positions and a sample is fetched from the fabric once.  The XCD count is a LOCALITY hint only: on
+    // a part with another count (or a CPX partition) every job is still done exactly once, the samples just miss L2 more often.  (Measured, FETCH_SIZE per hop position: a contiguous run of
     // jobs per WORKGROUP 262 KB -- every load a miss: 32 CUs x 4 pairs x 64 KB of window do not fit a 4 MB L2 --, plain
     // round-robin over all workgroups 87 KB -- every XCD fetches every sample --; the time is the same.)
     const unsigned long long nx = p.xcds, xcd = blockIdx.x % nx, local = blockIdx.x / nx;
     const unsigned long long job_step = gridDim.x / nx;
     const unsigned long long job_begin = xcd * p.jobs_per_xcd + local;
     const unsigned long long job_end = (xcd + 1) * p.jobs_per_xcd < p.n_jobs ? (xcd + 1) * p.jobs_per_xcd : p.n_jobs;
-    JobIn cur = job_in(job_begin < job_end ? job_begin : 0);
     if (job_begin < job_end) {
-        prefetch(cur);
-        take(cur.data_second);
+        const JobIn first = job_in(job_begin);
+        prefetch(first);
+        take(first.data_second);
     }
     // The finished row of a transform waits in LDS (`stage`) and is read back and stored by the NEXT iteration, behind its first
     // barrier: the wait for the staging writes and the latency of the read-back then fall on that barrier (which the iteration
@@ -424,7 +419,6 @@ __global__ void __launch_bounds__(1024, 1) stft16384_d_kernel(Params p)
         }
         prev = Pending{f0, f1, pair, have_first, have_second, true};
         if (more) take(nxt.data_second);
-        cur = nxt;
     }
     if (prev.valid) {   // the last transform's row
         lds_barrier();
@@ -433,7 +427,7 @@ __global__ void __launch_bounds__(1024, 1) stft16384_d_kernel(Params p)
 }
 
 struct TablesD {
-    float2 *d_T1 = nullptr, *d_T1hi = nullptr, *d_tw2 = nullptr, *d_tw3 = nullptr;
+    float2 *d_T1 = nullptr, *d_tw2 = nullptr, *d_tw3 = nullptr;
     float *d_win8 = nullptr;
     float *d_planes = nullptr;   // de-interleave workspace, grown on demand
     size_t planes_floats = 0;
@@ -461,13 +455,10 @@ hipError_t d16384_init(sgx_ctx *c, void **out)
         if (4 * idx == 3 * N) { cs = 0.0; sn = 1.0; }
         return make_float2((float)cs, (float)sn);
     };
-    std::vector<float2> T1(16 * 1024), T1hi(8 * 1024), tw2(1024), tw3(64);
+    std::vector<float2> T1(16 * 1024), tw2(1024), tw3(64);
     std::vector<float> win8((size_t)kW);
     for (int q = 0; q < 16; ++q)
-        for (int tid = 0; tid < 1024; ++tid) {
-            T1[q * 1024 + tid] = unit((unsigned long long)q * tid, kP);
-            if (q >= 8) T1hi[(((q - 8) >> 1) * 1024 + tid) * 2 + (q & 1)] = T1[q * 1024 + tid];
-        }
+        for (int tid = 0; tid < 1024; ++tid) T1[q * 1024 + tid] = unit((unsigned long long)q * tid, kP);
     for (int q2 = 0; q2 < 16; ++q2)
         for (int t0 = 0; t0 < 16; ++t0)
             for (int r = 0; r < 4; ++r) tw2[(q2 * 16 + t0) * 4 + r] = unit((unsigned long long)q2 * (4 * t0 + r), 1024);
@@ -482,7 +473,6 @@ hipError_t d16384_init(sgx_ctx *c, void **out)
         return e;
     };
     hipError_t e = up(&t->d_T1, T1);
-    if (e == hipSuccess) e = up(&t->d_T1hi, T1hi);
     if (e == hipSuccess) e = up(&t->d_tw2, tw2);
     if (e == hipSuccess) e = up(&t->d_tw3, tw3);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&t->d_win8), win8.size() * sizeof(float));
@@ -504,7 +494,6 @@ void d16384_destroy(void *tables)
     auto *t = static_cast<d16k::TablesD *>(tables);
     if (!t) return;
     if (t->d_T1) (void)hipFree(t->d_T1);
-    if (t->d_T1hi) (void)hipFree(t->d_T1hi);
     if (t->d_tw2) (void)hipFree(t->d_tw2);
     if (t->d_tw3) (void)hipFree(t->d_tw3);
     if (t->d_win8) (void)hipFree(t->d_win8);
@@ -520,7 +509,6 @@ hipError_t launch_stft_d16384(const sgx_ctx *c, void *tables, const float *d_pcm
     auto *t = static_cast<TablesD *>(tables);
     Params p{};
     p.T1 = t->d_T1;
-    p.T1hi = t->d_T1hi;
     p.tw2 = t->d_tw2;
     p.tw3 = t->d_tw3;
     p.win8 = t->d_win8;
@@ -560,7 +548,7 @@ hipError_t launch_stft_d16384(const sgx_ctx *c, void *tables, const float *d_pcm
     // persistent workgroups, one per CU (145 KB of LDS); jobs are dealt round-robin in output-row order
     unsigned long long blocks = (unsigned long long)c->n_cu;
     if (blocks > p.n_jobs) blocks = p.n_jobs;
-    p.xcds = (blocks % 8 == 0 && p.n_jobs >= 8 * blocks) ? 8u : 1u;   // (short launches: plain round-robin keeps every workgroup busy)
+    p.xcds = (blocks % kXcdHint == 0 && p.n_jobs >= kXcdHint * blocks) ? kXcdHint : 1u;   // (short launches: plain round-robin keeps every workgroup busy)
     const unsigned long long group = mono ? 1 : pairs;                   // a hop position's pairs stay together
     p.jobs_per_xcd = ((p.n_jobs + p.xcds - 1) / p.xcds + group - 1) / group * group;
     const dim3 grid((unsigned)blocks), block(1024);

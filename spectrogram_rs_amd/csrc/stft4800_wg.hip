@@ -274,22 +274,25 @@ __global__ void __launch_bounds__(kT) __attribute__((amdgpu_waves_per_eu(4, 4)))
             // can only count stores it does not have to branch around -- with one branch in here it waits for every store to be
             // acknowledged by memory, once per transform (measured: 3.4 us per transform instead of 1.9).  So:
             //   * lanes whose bin is not an output (bin 0 = lane 0 at q3 = 0; bins >= 2400 = lanes >= 160 at q3 = 7) store a bin they
-            //     do own a second time (lane 0: its q3 = 1 bin; lanes >= 160: their q3 = 6 bin) -- same address, same value;
+            //     do own a second time (lane 0: its q3 = 1 bin; lanes >= 160: their q3 = 6 bin) -- same address, same value.  The
+            //     q3 = 6 bin lies one kT-slab BELOW the q3 = 7 scalar offset: the descriptors start one slab in front of the row and
+            //     every lane offset carries + kT bins, so that no lane offset is ever negative (as the unsigned 32-bit voffset of a
+            //     raw buffer store a negative one is ~4 GiB: dropped by the range check today, a stray write if that ever changed);
             //   * a mono pair whose first or second frame lies outside the requested range stores the other row twice.
             char *base = reinterpret_cast<char *>(p.mags);
             const int bin_bytes = F16 ? 4 : 8;
             const bool sa = have_first, sb = MODE == 1 ? have_second : false;
             const long long fa = sa ? f0 : f1, fb = sb ? f1 : f0;            // (row, values) of the two stores of a mono pair
-            const __amdgpu_buffer_rsrc_t ra = uniform_rsrc(base + ((size_t)fa * p.pairs * (size_t)kM - 1) * bin_bytes);
-            const __amdgpu_buffer_rsrc_t rb = uniform_rsrc(base + ((size_t)fb * p.pairs * (size_t)kM - 1) * bin_bytes);
+            const __amdgpu_buffer_rsrc_t ra = uniform_rsrc(base + ((long long)((size_t)fa * p.pairs * (size_t)kM) - 1 - kT) * bin_bytes);
+            const __amdgpu_buffer_rsrc_t rb = uniform_rsrc(base + ((long long)((size_t)fb * p.pairs * (size_t)kM) - 1 - kT) * bin_bytes);
             const bool drop0 = tid == 0, drop7 = tid >= kW - 7 * kT;
 #pragma unroll
             for (int q3 = 0; q3 < 8; ++q3) {
                 float l = ml[q3], r = mr[q3];
                 if ((W48_ABL & 1) && l != -12345.0f) continue;
-                int lane_off = bin_bytes * tid;
-                if (q3 == 0) { l = drop0 ? ml[1] : l; r = drop0 ? mr[1] : r; lane_off = drop0 ? bin_bytes * kT : lane_off; }
-                if (q3 == 7) { l = drop7 ? ml[6] : l; r = drop7 ? mr[6] : r; lane_off = drop7 ? bin_bytes * (tid - kT) : lane_off; }
+                int lane_off = bin_bytes * (tid + kT);
+                if (q3 == 0) { l = drop0 ? ml[1] : l; r = drop0 ? mr[1] : r; lane_off = drop0 ? bin_bytes * 2 * kT : lane_off; }
+                if (q3 == 7) { l = drop7 ? ml[6] : l; r = drop7 ? mr[6] : r; lane_off = drop7 ? bin_bytes * tid : lane_off; }
                 const float va = MODE == 1 ? (sa ? l : r) : l, vb = MODE == 1 ? (sb ? r : l) : r;
                 if (F16) {
                     const __half2 ha = MODE == 1 ? __floats2half2_rn(va, va) : __floats2half2_rn(l, r);

@@ -144,3 +144,26 @@ def test_tick_into_the_ring_texture_equals_the_host_round_trip(torch_cuda):
         view.close(); live.close(); eng.close()
     assert pics[0][0] == pics[1][0] > 64 and pics[0][1] == pics[1][1]       # more rows than the texture holds: it wrapped
     assert np.array_equal(pics[0][2], pics[1][2])
+
+
+def test_tick_into_a_view_of_another_context_is_refused(torch_cuda):
+    # sgx_live_tick_view's precondition (include/sgx.h): the view belongs to the ring's context.  A view of a context with another
+    # window has another row length, another stream and possibly another device; it is refused before anything is uploaded,
+    # transformed or skipped -- the ring keeps its samples, and the same tick into the ring's own view then yields every frame.
+    from spectrogram_rs_amd import _lib
+    from spectrogram_rs_amd.engine import SgxError
+    a = engine(window_samples=256, hop_samples=64, channels=2)
+    b = engine(window_samples=1024, hop_samples=64, channels=2)      # M = 1023: four times a's row length
+    live, own, foreign = a.live(8192), a.view(16), b.view(16)
+    rng = np.random.default_rng(11)
+    live.push(rng.uniform(-0.5, 0.5, (1000, 2)).astype(np.float32), 2)
+    before = len(live)
+    with pytest.raises(SgxError) as err:
+        live.tick_into(foreign)
+    assert err.value.code == _lib.SGX_ERR_INVALID_ARG and "another" in str(err.value)
+    assert len(live) == before and foreign.offset == 0 and own.offset == 0
+    assert live.tick_into(own) == a.num_frames(1000) == own.offset
+    b.close()                                                        # a destroyed context: the same answer
+    with pytest.raises(SgxError):
+        live.tick_into(foreign)
+    foreign.close(); own.close(); live.close(); a.close()
