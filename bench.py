@@ -14,10 +14,15 @@ float32 magnitudes.  With N GPUs every rank transforms its own 1e6-frame shard o
 frame ranges, sample offset rank * 1e6 * H; no data-path collective: the path shards by frame) => weak scaling;
 value = N * 1e6 * K / t.
 
-Order of a run (every rank): W warm-up steps -> K "burst" steps on the still-cool device (timed per launch, NOT the
-headline) -> back-to-back steps for --sustain-s seconds (per-launch times kept) -> barrier, EXACTLY K timed steps,
-barrier: `value`, `ms_per_step` and `roofline.frac` come from these last K steps, i.e. from a device that has been
-under load for seconds (the first round's headline was a 66 ms burst on an idle device).
+Order of a run (every rank): the output buffer is placed (see place_output: candidates are timed HOT and INTERLEAVED, two
+passes in opposite order; a candidate other than the first allocation is taken only where both passes agree) -> W warm-up
+steps -> K "burst" steps (timed per launch, NOT the headline) -> back-to-back steps for --sustain-s seconds (per-launch
+times kept) -> barrier, EXACTLY K timed steps, barrier: `value`, `ms_per_step` and `roofline.frac` come from these last K
+steps, i.e. from a device that has been under load for seconds.  `roofline.first_allocation` is the first allocation
+under the same protocol (K timed steps on the same hot device) -- what a caller who allocates once gets; it IS `value`
+whenever the first allocation was kept, and always with --placements 1.  Every side leg (config 3 / 4, stereo,
+independent mono frames, the application's operating point) is timed the same way: 5 burst launches, then back-to-back
+launches for --leg-sustain-s seconds; its figure is the mean of the last two thirds of that window.
 
 Extra objects on the same line:
   roofline     -- dominant kernel (the STFT kernel): algorithmic bytes per launch / launch duration (HIP events on the
@@ -25,7 +30,11 @@ Extra objects on the same line:
   cpu_baseline -- the CPU oracle (oracle/, a port of the reference's algorithm; the reference itself is Rust + FFTW and
                   cannot be built in this image) timed on this host's cores, bounded sample (rank 0, N = 1 only)
   config3      -- (N = 1) BASELINE config 3: the same stream -> RGBA pixel columns, with its own roofline
-  config4      -- (N = 1) BASELINE config 4: 16384-point, hop 512, 8 interleaved channels, with its own roofline
+  config4      -- (N = 1) BASELINE config 4 at its own size: 16384-point, hop 512, 8 interleaved channels, 1e5 hop positions
+                  (26 GB of output), with its own roofline
+  mono_independent_frames -- (N = 1) the headline stream with every mono frame as its own (s, s) transform
+                  (SGX_FLAG_INDEPENDENT_FRAMES): the reference's dataflow (audio_input_list_model.rs:67-69), what conformance
+                  to north_star's tolerance on EVERY input costs next to the headline's two-frames-per-transform mode
   config5      -- (N > 1) BASELINE config 5: 1e8 frames frame-sharded over the ranks, PCM generated on device chunk by
                   chunk, pixel columns gathered to rank 0 over RCCL / xGMI, every piece consumed (checksummed) by the root
 """
@@ -46,7 +55,7 @@ ALGO_BYTES_STFT = H * 1 * 4 + M * 2 * 4  # 17 400 B / frame: each input sample o
 ALGO_BYTES_PIXEL = H * 1 * 4 + R * 4     # 5 120 B / frame
 W4, H4, C4 = 8192, 512, 8
 ALGO_BYTES_CFG4 = H4 * C4 * 4 + (C4 // 2) * (W4 - 1) * 8  # 278 496 B / hop position
-PROFILE_ROUND = "r03"
+PROFILE_ROUND = "r04"
 W_APP, H_APP = 2400, 93     # the application's own operating point: 48 kHz x 0.05 s (gpu_spectrogram.rs:323), hop (2/1024) s (simple_spectrogram.rs:102)
 ALGO_BYTES_STEREO = H * 2 * 4 + M * 2 * 4                     # 18 424 B / frame: an (l, r) stream, what the reference feeds
 ALGO_BYTES_APP = H_APP * 2 * 4 + (W_APP - 1) * 2 * 4          # 19 936 B / frame
@@ -73,10 +82,13 @@ def parse(argv=None):
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=1_000_000, help="frames per GPU per step (config 2: 1e6)")
-    ap.add_argument("--placements", type=int, default=4, help="candidate allocations of the output buffer, the fastest is kept (1 = take the first)")
+    ap.add_argument("--placements", type=int, default=4, help="candidate allocations of the output buffer, timed hot and interleaved; another than the first is kept "
+                                                              "only if it is faster by > 2 %% in BOTH passes (1 = take the first, no study)")
+    ap.add_argument("--leg-sustain-s", type=float, default=1.0, help="seconds of back-to-back launches behind the burst of every side leg")
+    ap.add_argument("--independent-frames", type=int, default=1_000_000, help="N = 1: frames of the independent-mono-frames leg (0 = skip)")
     ap.add_argument("--sustain-s", type=float, default=3.0, help="seconds of back-to-back steps before the timed region (0 = skip)")
     ap.add_argument("--pixel-frames", type=int, default=1_000_000, help="N = 1: frames of the config-3 leg (0 = skip)")
-    ap.add_argument("--config4-hops", type=int, default=20_000, help="N = 1: hop positions of the config-4 leg (0 = skip)")
+    ap.add_argument("--config4-hops", type=int, default=100_000, help="N = 1: hop positions of the config-4 leg (BASELINE: 1e5 = 26 GB of output; 0 = skip)")
     ap.add_argument("--stereo-frames", type=int, default=1_000_000, help="N = 1: frames of the stereo 4096-point leg (0 = skip)")
     ap.add_argument("--app-frames", type=int, default=262_144, help="N = 1: frames of the leg at the application's operating point, W 2400 / hop 93 stereo (0 = skip)")
     ap.add_argument("--config5-frames", type=int, default=100_000_000, help="N > 1: total frames of the config-5 leg (0 = skip)")
@@ -281,20 +293,21 @@ def main_rank(args):
     assert n_own == F
     first_sample, n_samples = sample_range(first_frame, F, W, H)
     pcm = eng.white_noise(n_samples, first=first_sample)
-    # Where the 16.4 GB output buffer lies decides K1's rate as much as anything in the kernel: two allocations of the same size at the
-    # same virtual address read 3.30, 3.53 or 3.72 ms per launch depending on their physical pages, and a buffer keeps its class for
-    # life (profiles/r03_k1_slow_box.txt; round 2 took this for a property of the box).  The buffer is the caller's, so the caller
-    # chooses: up to --placements candidates are allocated and timed (3 launches each), the fastest is kept, the others are freed.
-    # Every candidate's time is reported (roofline.placement); index 0 is what a caller who allocates once gets.
-    mags, placement = place_output(torch, args.placements,
-                                   lambda: torch.empty((F, 1, M, 2), dtype=torch.float32, device=eng.device),
-                                   lambda buf: eng.stft_batch(pcm, out=buf), F * ALGO_BYTES_STFT)
+    # Where the 16.4 GB output buffer lies can decide K1's rate: allocations of the same size read 3.30, 3.53 or 3.72 ms per launch on
+    # some devices depending on their physical pages (profiles/r03_k1_slow_box.txt).  The buffer is the caller's, so a caller may
+    # choose -- but a choice must rest on evidence: place_output times the candidates hot and interleaved, twice, and keeps the
+    # first allocation unless another is faster in both passes.  roofline.first_allocation reports the first allocation under the
+    # protocol of `value` either way.
+    mags, mags_first, placement = place_output(torch, args.placements,
+                                               lambda: torch.empty((F, 1, M, 2), dtype=torch.float32, device=eng.device),
+                                               lambda buf: eng.stft_batch(pcm, out=buf), F * ALGO_BYTES_STFT)
 
-    def timed_launches(n):
+    def timed_launches(n, buf=None):
+        buf = mags if buf is None else buf
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
         for a, b in evs:
             a.record()
-            eng.stft_batch(pcm, out=mags)
+            eng.stft_batch(pcm, out=buf)
             b.record()
         torch.cuda.synchronize()
         return [a.elapsed_time(b) for a, b in evs]
@@ -323,7 +336,14 @@ def main_rank(args):
     steady = sustained[len(sustained) // 3:]     # the first third of the window is still heating up
     sustained_ms = (sum(steady) / len(steady)) if steady else kernel_ms
     burst_ms = sum(burst) / max(len(burst), 1)
-    elapsed, kernel_ms, sustained_ms, burst_ms = max_over_ranks([elapsed, kernel_ms, sustained_ms, burst_ms])
+    # the first allocation under the same protocol, on the same hot device: K timed steps right behind the K that count
+    if mags_first is not None:
+        first = timed_launches(args.steps, mags_first)
+        first_ms = sum(first) / max(len(first), 1)
+        del mags_first
+    else:
+        first, first_ms = timed, kernel_ms
+    elapsed, kernel_ms, sustained_ms, burst_ms, first_ms = max_over_ranks([elapsed, kernel_ms, sustained_ms, burst_ms, first_ms])
     checksum = eng.checksum(mags[:4096])
     try:
         sclk = int(torch.cuda.clock_rate())
@@ -359,6 +379,8 @@ def main_rank(args):
                 "workload": f"configs[1]: batched 4096-pt Hann STFT, hop 256, {F} frames/GPU of counter-based white-noise mono PCM resident in HBM",
                 "window": W, "fft_length": 2 * W, "hop": H, "channels": 1, "frames_per_gpu": F,
                 "kernel": KERNEL_NAMES[eng.info.stft_kernel][0],
+                "mono_mode": "two frames per transform: frame 2j in the real part, 2j+1 in the imaginary part (the quieter frame of a pair inherits "
+                             "the louder one's rounding floor; `mono_independent_frames` is the reference's (s, s) dataflow)",
                 "sharding": "contiguous frame ranges per rank, no data-path collective" if world > 1 else "single GPU",
                 "timed_region": f"{args.steps} steps after {args.warmup} warm-up steps, {args.steps} burst steps and {sustain_wall:.1f} s of back-to-back steps",
             },
@@ -372,6 +394,10 @@ def main_rank(args):
                 "kernel": KERNEL_NAMES[eng.info.stft_kernel][1],
                 "launch_ms": kernel_ms, "bytes_per_frame": ALGO_BYTES_STFT, "frames_per_launch": F,
                 "launch_ms_burst": stats_ms(burst), "launch_ms_sustained": stats_ms(steady),
+                "first_allocation": {"launch_ms": first_ms, "frac": frac_of(first_ms), "frames_per_s": F / (first_ms * 1e-3),
+                                     "launch_ms_stats": stats_ms(first), "is_value": placement["chosen"] == 0,
+                                     "what": "the FIRST allocation of the output buffer, K timed steps on the same hot device "
+                                             "(the K steps of `value` themselves when the first allocation was kept)"},
                 "placement": placement,
                 "sustain_s": sustain_wall, "sclk_mhz_after_run": sclk,
                 "measured_device": None if probe is None else dict(
@@ -410,6 +436,8 @@ def main_rank(args):
             pcm = None
             if args.stereo_frames > 0:
                 extra["stereo4096"] = stereo_leg(args, torch, local_rank)
+            if args.independent_frames > 0:
+                extra["mono_independent_frames"] = independent_frames_leg(args, torch, local_rank)
             if args.app_frames > 0:
                 extra["app_point"] = app_point_leg(args, torch, local_rank)
         elif args.config5_frames > 0:
@@ -434,34 +462,87 @@ def main_rank(args):
     return 0
 
 
-def place_output(torch, n_candidates, alloc, launch, bytes_per_launch):
-    """The rate of a store-heavy launch depends on the physical pages of its output buffer (profiles/r03_k1_slow_box.txt): up to
-    n_candidates buffers are allocated (all alive at once, so that they are different pages) and timed (1 warm-up + 3 launches),
-    the fastest is kept, the others are freed.  Returns (buffer, report); report lists every candidate."""
-    cands, ms = [], []
+def group_ms(torch, launch, buf, reps):
+    """mean ms per launch of `reps` back-to-back launches into buf (one event pair around the group)"""
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        launch(buf)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def place_output(torch, n_candidates, alloc, launch, bytes_per_launch, reps=10, heat_s=1.0, margin=0.02):
+    """On some devices the rate of a store-heavy launch depends on the physical pages of its output buffer
+    (profiles/r03_k1_slow_box.txt).  Up to n_candidates buffers are allocated (all alive at once, so that they are different
+    pages) and timed HOT and INTERLEAVED: after heat_s seconds of launches (clocks ramped, every candidate touched) two passes
+    A B C D / D C B A of `reps` launches each.  (Round 3 timed each candidate cold, 1 + 3 launches, right after its allocation:
+    on the driver's box that read 3.71-3.76 ms for a buffer that ran 3.27 ms two seconds later -- clock ramp, not placement.)
+    A candidate other than the first allocation is kept only if BOTH its passes are faster than BOTH passes of the first
+    allocation by more than `margin` and its own two passes agree within `margin`: a stable class difference, not a draw.
+    Returns (chosen buffer, first buffer or None when the first IS the chosen one, report)."""
+    cands = []
     for _ in range(max(1, n_candidates)):
         try:
             buf = alloc()
         except RuntimeError:     # out of memory: what we have is what we compare
             break
         buf.zero_()              # first touch belongs to the allocation, not to a step
-        launch(buf)
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _i in range(3):
-            launch(buf)
-        e1.record()
-        torch.cuda.synchronize()
         cands.append(buf)
-        ms.append(e0.elapsed_time(e1) / 3.0)
-    chosen = min(range(len(cands)), key=lambda i: ms[i])
-    keep = cands[chosen]
-    del cands
+    if not cands:
+        raise RuntimeError(f"bench.py: not even one output buffer ({bytes_per_launch / 1e9:.1f} GB algorithmic per launch) could be allocated on this device")
+    if len(cands) == 1:
+        launch(cands[0])
+        torch.cuda.synchronize()
+        return cands[0], None, {"candidates": 1, "chosen": 0, "kept_selection": False,
+                                "why": "one candidate: the first allocation is the buffer"}
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < heat_s:          # heat: every candidate in turn
+        for buf in cands:
+            launch(buf)
+        torch.cuda.synchronize()
+    order = list(range(len(cands)))
+    p1 = {i: group_ms(torch, launch, cands[i], reps) for i in order}
+    p2 = {i: group_ms(torch, launch, cands[i], reps) for i in reversed(order)}
+    pass1, pass2 = [p1[i] for i in order], [p2[i] for i in order]
+    mean = [(a + b) / 2 for a, b in zip(pass1, pass2)]
+    stable = [abs(a - b) <= margin * m for a, b, m in zip(pass1, pass2, mean)]
+    best = min(order, key=lambda i: mean[i])
+    keep = (best != 0 and stable[best] and stable[0]
+            and max(pass1[best], pass2[best]) < (1.0 - margin) * min(pass1[0], pass2[0]))
+    chosen = best if keep else 0
+    keep_buf, first_buf = cands[chosen], (cands[0] if chosen != 0 else None)
+    del cands, buf
     torch.cuda.empty_cache()
-    return keep, {"candidates_ms_per_launch": ms, "chosen": chosen,
-                  "frac_of_candidate_0": bytes_per_launch / (ms[0] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                  "why": "physical placement of the output buffer: profiles/r03_k1_slow_box.txt"}
+    frac = lambda ms: bytes_per_launch / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+    return keep_buf, first_buf, {
+        "candidates": len(order), "protocol": f"{heat_s:.1f} s of launches over all candidates, then two passes in opposite order, {reps} launches per candidate and pass",
+        "pass1_ms_per_launch": pass1, "pass2_ms_per_launch": pass2, "stable_within_2pct": stable,
+        "spread": (max(mean) - min(mean)) / min(mean), "fastest": best, "chosen": chosen, "kept_selection": bool(keep),
+        "frac_of_candidate_0": frac(mean[0]), "frac_of_fastest": frac(mean[best]),
+        "why": "physical placement of the output buffer (profiles/r03_k1_slow_box.txt): a candidate other than the first allocation is kept "
+               "only if it is > 2 % faster in both passes"}
+
+
+def measure_leg(torch, launch, sustain_s, burst=5, warm=2):
+    """The protocol of every side leg: `warm` untimed launches, `burst` timed launches, then back-to-back launches for
+    sustain_s seconds (per-launch HIP-event times).  The leg's figure is the mean of the last two thirds of the sustained
+    window (the first third is still heating up); with sustain_s = 0 it is the burst."""
+    burst_ms = event_times(torch, launch, reps=burst, warm=warm)
+    sustained, t0 = [], time.perf_counter()
+    while sustain_s > 0 and time.perf_counter() - t0 < sustain_s:
+        n = max(4, min(32, int(0.1 / max(burst_ms[-1] * 1e-3, 1e-6))))      # ~0.1 s per batch: the queue never runs dry for long
+        sustained += event_times(torch, launch, reps=n, warm=0)
+    steady = sustained[len(sustained) // 3:] or burst_ms
+    return {"mean_ms": sum(steady) / len(steady), "launch_ms_sustained": stats_ms(steady), "launch_ms_burst": stats_ms(burst_ms),
+            "sustain_s": time.perf_counter() - t0 if sustain_s > 0 else 0.0}
+
+
+def leg_times(m):
+    """the timing fields every leg carries"""
+    return {"launch_ms": m["launch_ms_sustained"], "launch_ms_sustained": m["launch_ms_sustained"], "launch_ms_burst": m["launch_ms_burst"],
+            "sustain_s": m["sustain_s"]}
 
 
 def device_streaming_rates(torch, buf):
@@ -498,8 +579,8 @@ def config3_leg(args, torch, eng, pcm, F):
     Fp = min(args.pixel_frames, F)
     rgba = torch.empty((Fp, 1, R, 4), dtype=torch.uint8, device=eng.device)
     rgba.zero_()
-    ms = event_times(torch, lambda: eng.render_batch(pcm, max_frames=Fp, out=rgba), reps=5, warm=2)
-    mean = sum(ms) / len(ms)
+    m = measure_leg(torch, lambda: eng.render_batch(pcm, max_frames=Fp, out=rgba), args.leg_sustain_s)
+    mean = m["mean_ms"]
     achieved = Fp * ALGO_BYTES_PIXEL / (mean * 1e-3) / 1e9
     parity = {"cosine": rgba_vs_oracle(torch, eng, pcm, rgba, Fp, interp=1)}
     pipes = load_profile_json("pixel_pipes")
@@ -510,9 +591,9 @@ def config3_leg(args, torch, eng, pcm, F):
     cubic = None
     try:
         eng3 = SpectrogramEngine(48000.0, window_samples=W, hop_samples=H, channels=1, device=eng.device.index, interp=0, gradient="viridis")
-        ms3 = event_times(torch, lambda: eng3.render_batch(pcm, max_frames=Fp, out=rgba), reps=5, warm=2)
-        cubic = {"frames_per_s": Fp / (sum(ms3) / len(ms3) * 1e-3), "launch_ms": stats_ms(ms3),
-                 "what": "the same leg with the cubic interpolator, which is what the reference runs"}
+        m3 = measure_leg(torch, lambda: eng3.render_batch(pcm, max_frames=Fp, out=rgba), args.leg_sustain_s)
+        cubic = dict({"frames_per_s": Fp / (m3["mean_ms"] * 1e-3),
+                      "what": "the same leg with the cubic interpolator, which is what the reference runs"}, **leg_times(m3))
         parity["cubic"] = rgba_vs_oracle(torch, eng3, pcm, rgba, Fp, interp=0)
         eng3.close()
     except Exception as e:  # noqa: BLE001 -- an extra, never fatal
@@ -520,7 +601,7 @@ def config3_leg(args, torch, eng, pcm, F):
     return {
         "workload": f"configs[2]: {Fp} frames of the same stream -> 1024 log rows (cosine interpolation), Viridis RGBA, fused PCM-to-pixel kernel",
         "frames_per_s": Fp / (mean * 1e-3),
-        "launch_ms": stats_ms(ms),
+        **leg_times(m),
         "cubic": cubic,
         "rgba_vs_oracle": parity,
         "roofline": {
@@ -572,20 +653,60 @@ def stereo_leg(args, torch, device):
     Fs = args.stereo_frames
     eng = SpectrogramEngine(48000.0, window_samples=W, hop_samples=H, channels=2, device=device)
     pcm = eng.white_noise((Fs - 1) * H + W)
-    out, placement = place_output(torch, args.placements, lambda: torch.empty((Fs, 1, M, 2), dtype=torch.float32, device=eng.device),
-                                  lambda buf: eng.stft_batch(pcm, out=buf), Fs * ALGO_BYTES_STEREO)
-    ms = event_times(torch, lambda: eng.stft_batch(pcm, out=out), reps=5, warm=2)
-    mean = sum(ms) / len(ms)
+    out, first, placement = place_output(torch, args.placements, lambda: torch.empty((Fs, 1, M, 2), dtype=torch.float32, device=eng.device),
+                                         lambda buf: eng.stft_batch(pcm, out=buf), Fs * ALGO_BYTES_STEREO)
+    m = measure_leg(torch, lambda: eng.stft_batch(pcm, out=out), args.leg_sustain_s)
+    mean = m["mean_ms"]
     achieved = Fs * ALGO_BYTES_STEREO / (mean * 1e-3) / 1e9
     res = {
         "workload": f"4096-pt Hann STFT, hop 256, {Fs} frames of an (l, r) white-noise stream (2 channels interleaved), one frame per transform",
-        "frames_per_s": Fs / (mean * 1e-3), "launch_ms": stats_ms(ms),
+        "frames_per_s": Fs / (mean * 1e-3), **leg_times(m),
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "bytes_per_frame": ALGO_BYTES_STEREO, "frames_per_launch": Fs,
-                     "kernel": "sgx::wg::stft4096_wg_kernel<false, 1, true, false>", "placement": placement,
-                     "note": "bound by the LDS write path of the three exchanges of a transform (DESIGN section 4 K1), not by HBM"},
+                     "kernel": "sgx::wg::stft4096_wg_kernel<false, 1, true, false>",
+                     "first_allocation": first_allocation_of(torch, first, m, lambda buf: eng.stft_batch(pcm, out=buf), Fs * ALGO_BYTES_STEREO, args),
+                     "placement": placement,
+                     "note": "bound by the transform rate of the kernel (LDS exchanges + vector issue, DESIGN section 4 K1), not by HBM"},
     }
-    del out
+    del out, first
+    eng.close()
+    return res
+
+
+def first_allocation_of(torch, first, m_chosen, launch, bytes_per_launch, args):
+    """roofline.first_allocation of a side leg: the first allocation under the leg's own protocol (the chosen buffer's figures when
+    the first allocation was kept)"""
+    m = m_chosen if first is None else measure_leg(torch, lambda: launch(first), min(args.leg_sustain_s, 0.5))
+    return {"launch_ms": m["mean_ms"], "frac": bytes_per_launch / (m["mean_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "is_value": first is None}
+
+
+def independent_frames_leg(args, torch, device):
+    """The headline stream in the reference's own dataflow: a mono sample is duplicated into (s, s) and EVERY frame is one transform
+    (audio_input_list_model.rs:67-69 + fft.rs:81-98; SGX_FLAG_INDEPENDENT_FRAMES).  Same 17 400 algorithmic bytes per frame as the
+    headline; twice the transforms.  This is the mode that meets north_star's tolerance against the frame's OWN peak on every
+    input (tests/test_gpu_parity.py::test_onsets_*); the headline packs two frames per transform."""
+    from spectrogram_rs_amd import SpectrogramEngine
+
+    Fi = args.independent_frames
+    eng = SpectrogramEngine(48000.0, window_samples=W, hop_samples=H, channels=1, device=device, independent_frames=True)
+    pcm = eng.white_noise((Fi - 1) * H + W)
+    out, first, placement = place_output(torch, args.placements, lambda: torch.empty((Fi, 1, M, 2), dtype=torch.float32, device=eng.device),
+                                         lambda buf: eng.stft_batch(pcm, out=buf), Fi * ALGO_BYTES_STFT)
+    m = measure_leg(torch, lambda: eng.stft_batch(pcm, out=out), args.leg_sustain_s)
+    mean = m["mean_ms"]
+    achieved = Fi * ALGO_BYTES_STFT / (mean * 1e-3) / 1e9
+    res = {
+        "workload": f"configs[1] in the reference's dataflow: {Fi} frames of the same mono stream, every frame its own (s, s) transform "
+                    "(SGX_FLAG_INDEPENDENT_FRAMES; audio_input_list_model.rs:67-69)",
+        "frames_per_s": Fi / (mean * 1e-3), **leg_times(m),
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "bytes_per_frame": ALGO_BYTES_STFT, "frames_per_launch": Fi,
+                     "kernel": "sgx::wg::stft4096_wg_kernel<false, 1, false, false>",
+                     "first_allocation": first_allocation_of(torch, first, m, lambda buf: eng.stft_batch(pcm, out=buf), Fi * ALGO_BYTES_STFT, args),
+                     "placement": placement,
+                     "note": "one transform per frame: bound by the kernel's transform rate, as the (l, r) leg"},
+    }
+    del out, first
     eng.close()
     return res
 
@@ -602,12 +723,12 @@ def app_point_leg(args, torch, device):
     pcm = eng.white_noise((Fa - 1) * H_APP + W_APP)
     out = torch.empty((Fa, 1, W_APP - 1, 2), dtype=torch.float32, device=eng.device)
     out.zero_()
-    ms = event_times(torch, lambda: eng.stft_batch(pcm, out=out), reps=5, warm=2)
+    m = measure_leg(torch, lambda: eng.stft_batch(pcm, out=out), args.leg_sustain_s)
     del out
     rgba = torch.empty((Fa, 1, R, 4), dtype=torch.uint8, device=eng.device)
     rgba.zero_()
-    msp = event_times(torch, lambda: eng.render_batch(pcm, out=rgba), reps=5, warm=2)
-    mean, meanp = sum(ms) / len(ms), sum(msp) / len(msp)
+    mp = measure_leg(torch, lambda: eng.render_batch(pcm, out=rgba), args.leg_sustain_s)
+    mean, meanp = m["mean_ms"], mp["mean_ms"]
     ach, achp = Fa * ALGO_BYTES_APP / (mean * 1e-3) / 1e9, Fa * ALGO_BYTES_APP_PIXEL / (meanp * 1e-3) / 1e9
     name = KERNEL_NAMES.get(eng.info.stft_kernel, ("?", "?"))
     # the same point for a mono device (audio_input_list_model.rs:67-69 duplicates the sample into (s, s)): two frames per transform
@@ -616,8 +737,8 @@ def app_point_leg(args, torch, device):
     pcm1 = mono.white_noise((Fa - 1) * H_APP + W_APP)
     out1 = torch.empty((Fa, 1, W_APP - 1, 2), dtype=torch.float32, device=mono.device)
     out1.zero_()
-    ms1 = event_times(torch, lambda: mono.stft_batch(pcm1, out=out1), reps=5, warm=2)
-    mean1 = sum(ms1) / len(ms1)
+    m1 = measure_leg(torch, lambda: mono.stft_batch(pcm1, out=out1), args.leg_sustain_s)
+    mean1 = m1["mean_ms"]
     bytes1 = H_APP * 4 + (W_APP - 1) * 8
     ach1 = Fa * bytes1 / (mean1 * 1e-3) / 1e9
     del out1, pcm1
@@ -625,13 +746,13 @@ def app_point_leg(args, torch, device):
     res = {
         "workload": f"the application's operating point: 48 kHz x 0.05 s = W 2400 (4800-point transform), hop 93, (l, r) stream, {Fa} frames",
         "kernel": name[0], "real_time_factor": Fa / (mean * 1e-3) * H_APP / 48000.0,
-        "rows_f32": {"frames_per_s": Fa / (mean * 1e-3), "launch_ms": stats_ms(ms),
+        "rows_f32": {"frames_per_s": Fa / (mean * 1e-3), **leg_times(m),
                      "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                                   "bytes_per_frame": ALGO_BYTES_APP, "frames_per_launch": Fa}},
-        "mono_rows_f32": {"frames_per_s": Fa / (mean1 * 1e-3), "launch_ms": stats_ms(ms1),
+        "mono_rows_f32": {"frames_per_s": Fa / (mean1 * 1e-3), **leg_times(m1),
                           "roofline": {"bound": "hbm", "achieved": ach1, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach1 / HBM_PEAK_GBS,
                                        "bytes_per_frame": bytes1, "frames_per_launch": Fa}},
-        "pcm_to_rgba": {"frames_per_s": Fa / (meanp * 1e-3), "launch_ms": stats_ms(msp), "fused_kernel": bool(eng.info.render_path & 1),
+        "pcm_to_rgba": {"frames_per_s": Fa / (meanp * 1e-3), **leg_times(mp), "fused_kernel": bool(eng.info.render_path & 1),
                         "roofline": {"bound": "hbm", "achieved": achp, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achp / HBM_PEAK_GBS,
                                      "bytes_per_frame": ALGO_BYTES_APP_PIXEL, "frames_per_launch": Fa}},
     }
@@ -646,24 +767,26 @@ def config4_leg(args, torch, device):
     hops = args.config4_hops
     eng = SpectrogramEngine(48000.0, window_samples=W4, hop_samples=H4, channels=C4, device=device)
     pcm = eng.white_noise((hops - 1) * H4 + W4)
-    out, placement = place_output(torch, args.placements,
-                                  lambda: torch.empty((hops, C4 // 2, W4 - 1, 2), dtype=torch.float32, device=eng.device),
-                                  lambda buf: eng.stft_batch(pcm, out=buf), hops * ALGO_BYTES_CFG4)
-    ms = event_times(torch, lambda: eng.stft_batch(pcm, out=out), reps=5, warm=2)
-    mean = sum(ms) / len(ms)
+    out, first, placement = place_output(torch, args.placements,
+                                         lambda: torch.empty((hops, C4 // 2, W4 - 1, 2), dtype=torch.float32, device=eng.device),
+                                         lambda buf: eng.stft_batch(pcm, out=buf), hops * ALGO_BYTES_CFG4)
+    m = measure_leg(torch, lambda: eng.stft_batch(pcm, out=out), args.leg_sustain_s)
+    mean = m["mean_ms"]
     achieved = hops * ALGO_BYTES_CFG4 / (mean * 1e-3) / 1e9
     traffic = load_profile_json("hbm_traffic")
     name = KERNEL_NAMES.get(eng.info.stft_kernel, ("?", "?"))
     return {
         "workload": f"configs[3]: 16384-pt Hann STFT, hop 512, 8 interleaved channels, {hops} hop positions ({4 * hops} transforms)",
         "hop_positions_per_s": hops / (mean * 1e-3), "transforms_per_s": 4 * hops / (mean * 1e-3),
-        "launch_ms": stats_ms(ms), "kernel": name[0],
+        **leg_times(m), "kernel": name[0], "output_bytes": hops * (C4 // 2) * (W4 - 1) * 8,
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "bytes_per_hop_position": ALGO_BYTES_CFG4, "hop_positions_per_launch": hops,
             "traffic": ((traffic or {}).get("config4_bytes_per_hop") or 0) * hops or None,
             "traffic_source": (traffic or {}).get("source"),
-            "kernel": name[1], "placement": placement,
+            "kernel": name[1],
+            "first_allocation": first_allocation_of(torch, first, m, lambda buf: eng.stft_batch(pcm, out=buf), hops * ALGO_BYTES_CFG4, args),
+            "placement": placement,
             "note": "launch = the de-interleave pass + the transform kernel (both inside the timed call)",
         },
     }

@@ -68,9 +68,9 @@ def test_stft_batch_matches_oracle(torch_cuda, mags_err, variant, channels):
     ref32 = oracle.stream_process(pcm, channels, W, H, threads=8)
     ref64 = np.stack([oracle.np_truth_frame(
         (np.stack([pcm[t * H:t * H + W]] * 2, 1) if channels == 1 else pcm.reshape(-1, 2)[t * H:t * H + W]), W)
-        for t in range(0, 131, 13)])
+        for t in range(131)])
     assert got.shape == ref32.shape == (131, 1, M, 2)
-    assert mags_err(got[::13, 0], ref64) <= 1.0          # against float64 truth
+    assert mags_err(got[:, 0], ref64) <= 1.0             # EVERY frame against the float64 truth, at 1 x north_star's tolerance
     assert mags_err(got, ref32) <= 2.0                   # two float32 FFTs, each within tolerance of the truth
     if channels == 1:
         # mono -> (s, s): both columns are |S^[k]| (computed by different float32 expressions in the
@@ -453,6 +453,53 @@ def test_full_size_properties(torch_cuda, mags_err):
     words_lo, c_lo = lo.numel(), eng.checksum(lo)
     del lo
     hi = eng.stft_batch(pcm, first_frame=F // 2)
+    assert (c_lo + eng.checksum(hi, base_word=words_lo)) % (1 << 64) == a
+
+
+def test_full_size_config4_properties(torch_cuda, mags_err):
+    # BASELINE config 4 at its own size: W 8192 / P 16384, hop 512, 8 interleaved channels, 1e5 hop positions =
+    # 4e5 transforms, 1.64 GB in, 26.2 GB out -- output offsets far past 2^32 bytes (row 16 385 of the output starts there).
+    torch = torch_cuda
+    Wt, Ht, ch, hops = 8192, 512, 8, 100_000
+    Mt = Wt - 1
+    eng = engine(window_samples=Wt, hop_samples=Ht, channels=ch)
+    assert eng.info.stft_kernel == 8, "the lane-quad 16384-point kernel must be the one that runs"
+    n = (hops - 1) * Ht + Wt
+    pcm = eng.white_noise(n)
+    assert pcm.numel() == n * ch
+    mags = eng.stft_batch(pcm)
+    assert mags.shape == (hops, ch // 2, Mt, 2) and mags.numel() * 4 == 26_211_200_000
+    for lo in range(0, hops, 10_000):                   # finite everywhere (in pieces: isfinite materialises a byte per element)
+        assert bool(torch.isfinite(mags[lo:lo + 10_000]).all())
+    # 256 sampled (hop, pair) rows against the oracle: hop = i * 977 * 41 mod 1e5 (spread over the whole range, first and last
+    # included), pair = i mod 4 -- every row at 1 x the tolerance of the float64 truth and 2 x the float32 oracle
+    picks = [((i * 977 * 41) % hops, i % 4) for i in range(254)] + [(0, 0), (hops - 1, 3)]
+    assert max(h for h, _ in picks) * 4 * Mt * 8 > 1 << 34          # rows far past the 4 GiB and 16 GiB byte offsets
+    pcm2d = pcm.view(n, ch)
+    got = np.stack([mags[h, pr].cpu().numpy() for h, pr in picks])
+    host = [pcm2d[h * Ht:h * Ht + Wt, 2 * pr:2 * pr + 2].cpu().numpy() for h, pr in picks]
+    # generator parity at the far end of the stream: channel c is the mono generator seeded seed + c
+    tail = pcm2d[n - 256:].cpu().numpy()
+    for c_ in (0, 3, 7):
+        assert np.array_equal(tail[:, c_], oracle.white_noise(256, first=n - 256, seed=0x5EED0001 + c_))
+    ref32 = np.stack([oracle.fft_process(x, Wt) for x in host])
+    ref64 = np.stack([oracle.np_truth_frame(x, Wt) for x in host])
+    assert mags_err(got, ref64) <= 1.0
+    assert mags_err(got, ref32) <= 2.0
+    # determinism: the same bytes again (the 16-byte store hazard of round 3 showed as a few wrong words per launch, now and then)
+    a = eng.checksum(mags)
+    del mags
+    again = eng.stft_batch(pcm)
+    assert eng.checksum(again) == a
+    del again
+    # shard independence across an ODD split (33 333 / 66 667 hop positions: mid-XCD-eighth, mid-pair-group): the two ranges,
+    # computed by separate calls, checksum to the full run's value
+    cut = 33_333
+    lo = eng.stft_batch(pcm, first_frame=0, max_frames=cut)
+    words_lo, c_lo = lo.numel(), eng.checksum(lo)
+    del lo
+    hi = eng.stft_batch(pcm, first_frame=cut)
+    assert hi.shape[0] == hops - cut
     assert (c_lo + eng.checksum(hi, base_word=words_lo)) % (1 << 64) == a
 
 
@@ -851,6 +898,62 @@ def test_frame_pairing_dynamic_range_and_independent_frames(torch_cuda, mags_err
     # frame 1 rides with the click: its error is bounded relative to the PAIR's peak, not its own
     pair_peak = np.abs(ref[:2]).max()
     assert np.abs(paired[1] - ref[1]).max() <= 1e-6 * pair_peak
+
+
+def _pair_error(x, ref, first_frame=0):
+    """mags_error with the PAIR's peak (frames 2j, 2j+1 by global index) in place of the frame's own: the tolerance a mono
+    frame meets when it shares its transform with its neighbour, as left and right do in the reference (fft.rs:57,87-88)"""
+    from conftest import PEAK_FLOOR, REL_TOL
+    x, ref = np.asarray(x, np.float64), np.asarray(ref, np.float64)
+    own = np.abs(ref).max(axis=(-1, -2))
+    pair = own.copy()
+    for t in range(len(own)):
+        q = (t + first_frame) ^ 1
+        if 0 <= q - first_frame < len(own):
+            pair[t] = max(own[t], own[q - first_frame])
+    allow = np.maximum(REL_TOL * np.maximum(np.abs(ref), PEAK_FLOOR * pair[:, None, None]), 1e-30)
+    return float((np.abs(x - ref) / allow).max())
+
+
+@pytest.mark.parametrize("step_db", [20, 40, 60, None])
+@pytest.mark.parametrize("kind", ["onset", "offset"])
+def test_onsets_inside_one_hop_own_peak_tolerance_and_the_paired_bound(torch_cuda, mags_err, step_db, kind):
+    # What the headline's mono mode costs in conformance, measured and bounded (VERDICT round 3, weak #2).  A level step of
+    # 20 / 40 / 60 dB -- or from digital silence (None) -- to full scale INSIDE ONE HOP, placed so that it falls between the two
+    # frames of a pair: onset in [6H + W, 7H + W) is inside frame 7's last hop and outside frame 6; offset (loud -> quiet) at a
+    # sample in [6H, 7H) leaves its last loud samples in frame 6's first hop and none in frame 7.  Also one step that does NOT
+    # split a pair (between frames 9 and 10), where paired and independent modes must both hold the own-peak tolerance.
+    #   independent frames (the reference's (s, s) dataflow, audio_input_list_model.rs:67-69 + fft.rs:81-98):
+    #       every frame within 1 x north_star's tolerance of the float64 truth against ITS OWN peak -- asserted;
+    #   paired (default): every frame within 1 x the same tolerance against the PAIR's peak -- asserted; against its own peak
+    #       the quiet frame of a split pair is off by up to the level ratio of the pair -- measured, printed, and bounded by
+    #       that ratio (the statement "1e-7 of the pair's peak" of DESIGN section 4 as an assertion).
+    torch = torch_cuda
+    n = W + 15 * H
+    quiet = np.float32(0.0 if step_db is None else 0.9 * 10.0 ** (-step_db / 20.0))
+    loud = np.float32(0.9)
+    noise = oracle.white_noise(n, seed=21)
+    for cut, split_pair in ((6 * H + (W if kind == "onset" else 0) + 100, True), (10 * H + (W if kind == "onset" else 0) - 156, False)):
+        gain = np.where(np.arange(n) < cut, quiet if kind == "onset" else loud, loud if kind == "onset" else quiet).astype(np.float32)
+        x = noise * gain
+        ref = np.stack([oracle.np_truth_frame(np.stack([x[t * H:t * H + W]] * 2, 1), W) for t in range(16)])
+        own_peak = np.abs(ref).max(axis=(1, 2))
+        indep = engine(window_samples=W, hop_samples=H, channels=1, independent_frames=True).stft_batch(to_dev(torch, x)).cpu().numpy()[:, 0]
+        paired = engine(window_samples=W, hop_samples=H, channels=1).stft_batch(to_dev(torch, x)).cpu().numpy()[:, 0]
+        assert mags_err(indep, ref) <= 1.0
+        assert _pair_error(paired, ref) <= 1.0
+        # sub-ranges pair by GLOBAL index: the same bound from an odd first frame
+        part = engine(window_samples=W, hop_samples=H, channels=1).stft_batch(to_dev(torch, x), first_frame=5, max_frames=6).cpu().numpy()[:, 0]
+        assert np.array_equal(part, paired[5:11])
+        per_frame = np.array([mags_err(paired[t], ref[t]) for t in range(16)])
+        worst = int(per_frame.argmax())
+        ratio = np.array([max(own_peak[t], own_peak[t ^ 1]) / max(own_peak[t], 1e-30) for t in range(16)])
+        print(f"  {kind} {step_db} dB, cut {cut} ({'splits a pair' if split_pair else 'between pairs'}): paired own-peak error "
+              f"{per_frame.max():.3g} x tolerance at frame {worst} (pair level ratio {ratio[worst]:.3g}); independent {mags_err(indep, ref):.3g}")
+        if step_db is not None:
+            assert (per_frame <= np.maximum(1.0, ratio)).all()      # never worse than the pair's level ratio
+        frames_far = [t for t in range(16) if ratio[t] < 1.5]
+        assert mags_err(paired[frames_far], ref[frames_far]) <= 1.5   # frames whose partner is at their own level: (about) the own-peak tolerance
 
 
 @pytest.mark.parametrize("kw", [dict(channels=1), dict(channels=2), dict(channels=1, force_generic=True),
