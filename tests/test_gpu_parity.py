@@ -1066,12 +1066,14 @@ def test_builtin_continuous_schemes(torch_cuda, name, stereo):
     # every continuous entry of default_color_schemes (colorscheme.rs:129-149; the four 256-entry ramps have their own
     # tests): the library evaluates colorous' B-spline gradients (anchors from ColorBrewer, d3's interpolateRgbBasis), the
     # Turbo / Cividis polynomials and the cubehelix interpolations (Cube-helix, Cool) itself.  The pixel arithmetic is
-    # checked against the oracle; the COLOUR function the oracle is handed is this package's Python restatement of the
-    # same published formula -- restatement against restatement, which pins the engine's thresholding of a gradient and
-    # nothing about colorous (unvendored).
+    # checked against the oracle; the COLOUR function the oracle is handed is the checker's own restatement of the
+    # published d3 formulas (oracle/gradients.py over tests/golden/brewer_anchors.npz -- nothing of it comes from the
+    # product package).  It pins the engine's evaluation and thresholding of a gradient; about colorous itself
+    # (unvendored) it says only what tests/test_host_logic.py::test_independent_pins_... lists.
     torch = torch_cuda
+    from oracle.gradients import CONTINUOUS
     from spectrogram_rs_amd import ColorScheme
-    from spectrogram_rs_amd.colorscheme import CONTINUOUS, default_color_schemes
+    from spectrogram_rs_amd.colorscheme import default_color_schemes
     from spectrogram_rs_amd.engine import builtin_gradient_eval
     pcm = oracle.white_noise(2 * (W + 15 * H), seed=78).reshape(-1, 2) * np.array([1.0, 0.3], np.float32)
     mags = oracle.stream_process(pcm, 2, W, H)[:, 0]

@@ -161,7 +161,8 @@ def test_mixed_radix_plan_and_block_index_arithmetic_for_every_supported_length(
 def test_default_color_schemes_follow_the_reference_list():
     # colorscheme.rs:125-151: the 19 entries in the reference's order, every one a built-in of the engine, the diverging
     # ones as stereo schemes on a black background
-    from spectrogram_rs_amd.colorscheme import CONTINUOUS, default_color_schemes
+    from oracle.gradients import CONTINUOUS
+    from spectrogram_rs_amd.colorscheme import default_color_schemes
     ds = default_color_schemes()
     assert [d.name for d in ds] == ["Blue-Yellow-Red (Stereo)", "Magma", "Viridis", "Blue-Red (Stereo)", "Spectral (Stereo)",
                                     "Green-Yellow-Red (Stereo)", "Green-Pink (Stereo)", "Orange-Purple (Stereo)", "Inferno", "Plasma",
@@ -179,15 +180,56 @@ def test_default_color_schemes_follow_the_reference_list():
     assert all(a >= b for a, b in zip(vals, vals[1:]))        # monotone ramp
 
 
-def test_builtin_gradient_eval_matches_the_python_restatement():
-    # the C++ built-in (csrc/sgx_api.hip: brewer_eval) and colorscheme._basis_gradient are the same arithmetic
+def test_builtin_gradient_eval_matches_the_oracles_restatement():
+    # the product's half: the C++ built-ins (csrc/sgx_api.hip: brewer_eval / poly_eval / helix_eval over the anchors of
+    # csrc/sgx_gradients.inc), asked through the C ABI.  The checker's half: oracle/gradients.py over tests/golden/brewer_anchors.npz.
+    # The product package holds no colour arithmetic in Python (its ColorScheme mirror asks the library).
     import numpy as np
-    from spectrogram_rs_amd.colorscheme import BREWER, CLOSED_FORM, CONTINUOUS
+    from oracle.gradients import BREWER, CLOSED_FORM, CONTINUOUS
+    from spectrogram_rs_amd import colorscheme
     from spectrogram_rs_amd.engine import builtin_gradient_eval
-    assert set(CLOSED_FORM) == {"turbo", "cividis", "cubehelix", "cool", "warm"}
-    for name in BREWER + CLOSED_FORM:
+    assert set(CLOSED_FORM) == {"turbo", "cividis", "cubehelix", "cool", "warm"} and len(BREWER) == 15
+    assert not any(hasattr(colorscheme, n) for n in ("CONTINUOUS", "_basis_gradient", "_poly_gradient", "_cubehelix_long"))
+    for name in CONTINUOUS:
         for t in list(np.linspace(-0.05, 1.05, 1501)) + [float("nan")]:
             assert builtin_gradient_eval(name, t) == CONTINUOUS[name](t), (name, t)
+    # the mirror's host-side colours come from the library too
+    for d in colorscheme.default_color_schemes():
+        if d.gradient_fn is not None:
+            assert d.foreground() == builtin_gradient_eval(d.builtin, 0.5 if d.is_stereo else 1.0)
+
+
+def test_independent_pins_of_the_colour_schemes_and_which_stay_unpinned():
+    # colorous (un-vendored) is the only authority on the reference's 19 gradients (colorscheme.rs:125-151).  What this image can
+    # pin INDEPENDENTLY of the build's own restatements, and how tightly:
+    #   Cube-helix                      matplotlib's `cubehelix` map (Green 2011: start 0.5, -1.5 rotations, hue 1, gamma 1), the same
+    #                                   published curve d3's interpolateCubehelixDefault traces: +-1 LSB everywhere
+    #   Viridis Magma Inferno Plasma    the tables ARE matplotlib's (d3 and colorous port the same 256 colours: the first five and the
+    #                                   last Viridis entries d3 publishes are checked by tools/gen_gradients.py)
+    #   13 ColorBrewer splines          only the two END colours (a reflected B-spline passes exactly through its end anchors): equal
+    #                                   to ColorBrewer's, read through matplotlib's colormap of the same scheme; the interior is d3's
+    #                                   spline against matplotlib's piecewise-linear ramp over the same anchors -- close, not a pin
+    #   Turbo, Cividis                  d3 publishes POLYNOMIAL FITS of these maps; matplotlib ships the maps themselves (256 entries):
+    #                                   the fit is within 26 / 19 LSB of the map -- the right shape, not a pin
+    #   Cool                            no independent source here (matplotlib's `cool` is another map)
+    # => UNPINNED against anything but this build's reading of the d3 formulas: the 13 splines (interior), Turbo, Cividis, Cool.
+    import matplotlib
+    import numpy as np
+    from spectrogram_rs_amd.engine import builtin_gradient, builtin_gradient_eval
+    ts = (np.arange(256) + 0.5) / 256.0
+    mpl = lambda name: np.rint(np.asarray(matplotlib.colormaps[name](ts))[:, :3] * 255.0).astype(int)
+    lib = lambda name: np.array([builtin_gradient_eval(name, float(t)) for t in ts], int)
+    assert np.abs(lib("cubehelix") - mpl("cubehelix")).max() <= 1
+    for name in ("viridis", "magma", "inferno", "plasma"):
+        assert np.array_equal(builtin_gradient(name), np.rint(np.asarray(matplotlib.colormaps[name].colors) * 255.0).astype(np.uint8))
+    brewer = {"red_yellow_blue": "RdYlBu", "red_blue": "RdBu", "spectral": "Spectral", "red_yellow_green": "RdYlGn", "pink_green": "PiYG",
+              "purple_orange": "PuOr", "reds": "Reds", "blues": "Blues", "greens": "Greens", "greys": "Greys", "oranges": "Oranges"}
+    for name, m in brewer.items():
+        cm = matplotlib.colormaps[m]
+        for t in (0.0, 1.0):
+            assert builtin_gradient_eval(name, t) == tuple(int(v) for v in np.rint(np.asarray(cm(t))[:3] * 255.0)), (name, t)
+        assert np.abs(lib(name) - mpl(m)).max() <= 16, name          # spline vs piecewise-linear over the same anchors (worst: 15, Spectral)
+    assert np.abs(lib("turbo") - mpl("turbo")).max() <= 26 and np.abs(lib("cividis") - mpl("cividis")).max() <= 19
 
 
 def test_cubehelix_default_is_the_curve_matplotlib_traces():
