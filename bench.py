@@ -836,7 +836,8 @@ def config5_leg(args, torch, dist, eng, rank, world, backend, barrier, max_over_
     ranks_seen = sorted(int(t[0]) for t in seen)
 
     # one small untimed round first: RCCL builds its point-to-point connections lazily on first use
-    stream_columns([min(1024, c) for c in counts], 1024, produce, lambda g0, p: None, like=like, dst=0)
+    warm = min(1024, chunk)        # (the sample buffer and the rings hold `chunk` frames: never more per round)
+    stream_columns([min(warm, c) for c in counts], warm, produce, lambda g0, p: None, like=like, dst=0)
     acc.zero_()
     t_over, arrived = run(produce, consume)                       # the run that counts: render + gather, overlapped
     t_comp, _ = run(produce, None, send=False)                    # render only

@@ -23,12 +23,6 @@
 #include <cmath>
 
 #include "stft4096_wg.hpp"
-#ifndef SGX_ABL_NSTORE
-#define SGX_ABL_NSTORE 8
-#endif
-#ifndef SGX_ABL_STAGE_AUX
-#define SGX_ABL_STAGE_AUX 0
-#endif
 
 namespace sgx {
 
@@ -39,16 +33,6 @@ __device__ __forceinline__ float cl_fma(float a, float c, float u) { return fmaf
 __device__ __forceinline__ f2v cl_fma(f2v a, float c, f2v u) { return __builtin_elementwise_fma(a, f2v{c, c}, u); }
 
 #include "fft_codelets.inc"
-
-__device__ __forceinline__ void store2(float *row, int j, float a, float b)
-{
-#ifdef SGX_NT_STORES
-    typedef float f2s __attribute__((ext_vector_type(2)));
-    __builtin_nontemporal_store(f2s{a, b}, reinterpret_cast<f2s *>(row) + j);
-#else
-    reinterpret_cast<float2 *>(row)[j] = make_float2(a, b);
-#endif
-}
 
 __device__ __forceinline__ float2 cmulf(float2 a, float2 b)
 {
@@ -75,7 +59,6 @@ __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
     }
 
     // per-thread constants, kept in registers for the life of the (persistent) workgroup
-#ifndef SGX_WIN_RELOAD
     // the output scale (hypot / 2) * (2 / W) = 2^-11 rides on the window: a power of two commutes with every
     // rounding below (products, sums, the square root of a sum of squares), so the bits are the same and the
     // 16 multiplies per thread after the square roots are gone
@@ -84,7 +67,6 @@ __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
     float win[8];
 #pragma unroll
     for (int a = 0; a < 8; ++a) win[a] = p.window[tid + 256 * a] * inv_w;
-#endif
     float2 tw1[16];
 #pragma unroll
     for (int q = 1; q < 16; ++q) tw1[q] = p.tw1[q * 256 + tid];
@@ -210,12 +192,6 @@ __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
         }
         // ---- Hann (fft.rs:53-63) on the prefetched samples
         float er[8], ei[8];
-#ifdef SGX_WIN_RELOAD
-        // the Hann factors are re-read (L1-resident 8 KB table) instead of pinning 8 VGPRs
-        float win[8];
-#pragma unroll
-        for (int a = 0; a < 8; ++a) win[a] = p.window[tid + 256 * a] * (1.0f / (float)kW);
-#endif
         // local (output) frame indices; for mono f0 may be -1 (the pair's first frame precedes the range)
         const long long f0 = MONO ? (long long)(2 * (p.pair_base + job)) - (long long)p.first_frame : (long long)job;
         const long long f1 = f0 + 1;
@@ -260,9 +236,7 @@ __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
             const float2 v = buf[q1_2 * kS1 + t0_2 + 16 * t1];
             xr[t1] = v.x; xi[t1] = v.y;
         }
-#ifndef SGX_ABL_NOFFT
         fft16(xr, xi);
-#endif
         if (!MONO) __builtin_amdgcn_s_setprio(1);
         lds_barrier();  // everyone has read image 1
 #pragma unroll
@@ -280,9 +254,7 @@ __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
             const float2 v = buf[t0 * kS2 + col];
             xr[t0] = v.x; xi[t0] = v.y;
         }
-#ifndef SGX_ABL_NOFFT
         fft16(xr, xi);
-#endif
         if (job + 1 < job_end) fetch(job + 1, true);  // ahead of this transform's stores (see above)
         if (RENDER) __builtin_amdgcn_s_setprio(1);  // the pixel passes are long: 3 only from the row pass (the pixel stores) on
         else __builtin_amdgcn_s_setprio(3);
@@ -331,42 +303,8 @@ __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
             } else {
                 // byte offset of bin k = 0 of the row (bin k lives 8 k bytes on; k = 0 is never stored)
                 char *base = reinterpret_cast<char *>(p.mags);
-#if defined(SGX_ABL_PITCH16K)
-                // A/B only (profiles/r03_k1_slow_box.txt): rows at a pitch of 16 384 bytes -- every 512-byte wave store then starts on a
-                // 128-byte line.  The caller's buffer must hold 16 384 bytes per row.
-                constexpr size_t kPitch = 16384;
-#else
                 constexpr size_t kPitch = (size_t)kM * 8;
-#endif
                 const long long row0 = (long long)(((size_t)(have_first ? f0 : 0) * p.pairs + p.pair) * kPitch) - 8;
-#if defined(SGX_ABL_ALIGNED_STAGE)
-                // A/B only: the two rows of a mono pair staged in LDS and written as 512-byte-ALIGNED wave stores whatever the rows'
-                // own alignment (a 16 376-byte row starts 8 bytes earlier inside its 128-byte line in every row)
-                if (MONO) {
-                    float *st = reinterpret_cast<float *>(buf);   // [2][2048]: bin k of row e at st[2048 e + k]
-                    lds_barrier();   // partner reads done
-#pragma unroll
-                    for (int q3 = 0; q3 < 8; ++q3) { st[col + 256 * q3] = ml[q3]; st[2048 + col + 256 * q3] = mr[q3]; }
-                    lds_barrier();
-                    const int wave = tid >> 6, lane = tid & 63;
-#pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        if (e == 0 ? !have_first : !have_second) continue;
-                        const long long rb = e == 0 ? row0 : (long long)((f1 * p.pairs + p.pair) * kPitch) - 8;   // byte of bin 0
-                        // first bin whose address is a multiple of 512
-                        const unsigned long long a1 = (unsigned long long)(base + rb + 8);
-                        const int head = (int)(((512 - (a1 & 511)) & 511) >> 3);     // bins 1 .. head lie in front of it
-                        const __amdgpu_buffer_rsrc_t r = row_rsrc(base, rb);
-                        for (int sgm = wave - 4; sgm * 64 + head < kM; sgm += 4) {
-                            const int k = 1 + head + 64 * sgm + lane;                // segment -1 (wave 3 first): the bins in front
-                            if (k >= 1 && k <= kM) {
-                                const float m = st[2048 * e + k];
-                                __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(m), __float_as_uint(m)}, r, 8 * k, 0, SGX_ABL_STAGE_AUX);
-                            }
-                        }
-                    }
-                } else
-#endif
                 if (MONO) {
                     if (have_first) store_row<true>(base, row0, col, ml, ml);
                     if (have_second) store_row<true>(base, (long long)((f1 * p.pairs + p.pair) * kPitch) - 8, col, mr, mr);

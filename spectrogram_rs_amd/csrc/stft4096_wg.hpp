@@ -1,9 +1,6 @@
 // stft4096_wg.hpp -- declarations shared by the two workgroup-per-transform kernels
 // (stft4096_wg.hip: scalar codelets; stft4096_wgp.hip: packed (re, im) codelets).
 #pragma once
-#ifndef SGX_ABL_NSTORE
-#define SGX_ABL_NSTORE 8  // ablation builds only: store this many of the 8 row segments
-#endif
 #include <hip/hip_fp16.h>
 
 #include "sgx_internal.hpp"
@@ -74,11 +71,7 @@ struct WgTables {
 __device__ __forceinline__ void lds_barrier()
 {
     // LDS-only workgroup barrier: outstanding global stores are NOT waited for
-#ifdef SGX_ABL_NOBARRIER
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#else
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#endif
 }
 
 // one row of [M][2] floats; rowm8 = row base - 8 bytes (bin k lives at byte 8 k of rowm8): a uniform
@@ -107,9 +100,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t pcm_rsrc(const float *base)
 // Cache policy of the magnitude stores (A/B on one device, 1e6 frames): an (l, r) stream re-reads 7/8 of every frame's
 // samples through L2, and marking the output non-temporal keeps them there: 6.00 -> 5.57 ms.  A mono stream slides its
 // window in registers and re-reads nothing: there the same bit costs 10-40 %, sc1 30 %.
-#ifndef SGX_OUT_AUX
-#define SGX_OUT_AUX (DUP ? 0 : 2 /* nt */)
-#endif
+constexpr int kAuxNt = 2;   // the `nt` bit of a buffer store
 template <bool DUP>  // DUP: mono, the row holds (m, m); else (va, vb) = (left, right)
 __device__ __forceinline__ void store_row(char *mags, long long row_byte, int col, const float (&va)[8], const float (&vb)[8])
 {
@@ -117,9 +108,9 @@ __device__ __forceinline__ void store_row(char *mags, long long row_byte, int co
     const int lane_off = col * 8;
 #pragma unroll
     for (int q3 = 0; q3 < 8; ++q3)
-        if ((q3 > 0 || col != 0) && q3 < SGX_ABL_NSTORE) {  // k = 0 (DC) is not part of the output (fft.rs:81)
+        if (q3 > 0 || col != 0) {  // k = 0 (DC) is not part of the output (fft.rs:81)
             const u32x2 d = {__float_as_uint(va[q3]), __float_as_uint(DUP ? va[q3] : vb[q3])};
-            __builtin_amdgcn_raw_buffer_store_b64(d, r, lane_off + 2048 * (q3 & 1), 4096 * (q3 >> 1), SGX_OUT_AUX);
+            __builtin_amdgcn_raw_buffer_store_b64(d, r, lane_off + 2048 * (q3 & 1), 4096 * (q3 >> 1), DUP ? 0 : kAuxNt);
         }
 }
 

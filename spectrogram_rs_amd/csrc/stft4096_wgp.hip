@@ -75,10 +75,8 @@ __global__ void __launch_bounds__(256, 4) stft4096_wgp_kernel(Params p)
     }
 
     // per-thread constants, kept in registers for the life of the (persistent) workgroup
-#ifndef SGX_WIN_RELOAD
     float win[8];
 #pragma unroll
-    for (int a = 0; a < 8; ++a) win[a] = p.window[tid + 256 * a];
 #endif
     f2v tw1[16];
 #pragma unroll

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Config-3 timing of the fused PCM -> RGBA kernel (development aid; bench.py is the contract): mono 1e6 frames, cosine and
-cubic, and an (l, r) stream; SGX_LIB=<other build> swaps the library for a same-device A/B (tools/ab_pixel.sh)."""
+cubic, and an (l, r) stream; SGX_LIB=<other build> swaps the library for a same-device A/B (BENCH=tools/pixel_bench.py tools/ab.sh)."""
 import os
 import sys
 
