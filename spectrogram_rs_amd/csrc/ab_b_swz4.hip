@@ -1,0 +1,583 @@
+// stft4096_wg.hip -- tuned STFT for W = 2048 (P = 4096): one 256-thread workgroup per transform,
+// 16 points per thread, three radix-16 passes.
+//
+// Why this shape (measured on MI355X, tools/microbench.hip): a single wave per SIMD issues one
+// VALU instruction every ~7 cycles, four waves per SIMD one every ~2.  64 points per lane (the
+// wave-per-transform kernel in stft4096.hip) needs > 128 VGPRs and so caps at 2 waves per SIMD;
+// 16 points per thread fits 4 waves per SIMD and keeps 16 waves per CU in flight to cover LDS,
+// barrier and memory latency.
+//
+// Replaces FastFourierTransform::process (fft.rs:43-99) + the hop loop (audio_transform.rs:34-42).
+//
+//   sample index  n = t + 256 a           (t = thread, a < 8 non-zero rows: padding never touched)
+//   pass 1  thread t        : 16-point DFT over a (8 non-zero inputs = two 8-point FFTs), -> q1
+//                             twiddle w_4096^{t q1}            (15 per-thread constants in VGPRs)
+//   pass 2  thread (q1, t0) : t = t0 + 16 t1; 16-point FFT over t1 -> q2; twiddle w_256^{t0 q2} (LDS)
+//   pass 3  thread q1+16 q2 : 16-point FFT over t0 -> q3;  bin k = q1 + 16 q2 + 256 q3
+//   split   F[k] and F[P-k] -> |L^[k]|, |R^[k]| (fft.rs:81-89): the partner of thread u is thread
+//           (256 - u) % 256, exchanged through LDS (upper 8 registers only; k = 1..2047 is kept)
+//
+// Mono streams (a mono sample is duplicated into (s, s): audio_input_list_model.rs:67-69) pack
+// TWO consecutive frames into one transform: frame 2j in the real part, frame 2j+1 in the
+// imaginary part; the same split that separates left from right separates the two frames.
+#include <cmath>
+
+#include "ab_b_swz4.hpp"
+
+namespace sgx {
+
+namespace wg {
+
+typedef float f2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float cl_fma(float a, float c, float u) { return fmaf(a, c, u); }
+__device__ __forceinline__ f2v cl_fma(f2v a, float c, f2v u) { return __builtin_elementwise_fma(a, f2v{c, c}, u); }
+
+#include "fft_codelets.inc"
+
+__device__ __forceinline__ float2 cmulf(float2 a, float2 b)
+{
+    return make_float2(fmaf(a.x, b.x, -(a.y * b.y)), fmaf(a.x, b.y, a.y * b.x));
+}
+
+template <bool MONO, int PAIRING, bool C2, bool RENDER>
+__global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2 *buf = reinterpret_cast<float2 *>(smem_raw);
+    float2 *tw2 = buf + kBufComplex;
+
+    uint2 *pal = reinterpret_cast<uint2 *>(tw2 + 256);          // RENDER only: [256] {threshold, RGBA} (pixel_for)
+
+    const int tid = threadIdx.x;
+    tw2[tid] = p.tw2[tid];
+    uint32_t row_words[4] = {0u, 0u, 0u, 0u};  // RENDER: the table words of this thread's rows tid + 256 i
+    if (RENDER) {
+        pal[tid] = make_uint2(__float_as_uint(tid < 255 ? p.lut_thr[tid] : __builtin_nanf("")), *reinterpret_cast<const uint32_t *>(&p.lut_rgba[tid]));
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if ((uint32_t)tid + 256u * i < p.R) row_words[i] = p.rows[tid + 256 * i];
+    }
+
+    // per-thread constants, kept in registers for the life of the (persistent) workgroup
+    // the output scale (hypot / 2) * (2 / W) = 2^-11 rides on the window: a power of two commutes with every
+    // rounding below (products, sums, the square root of a sum of squares), so the bits are the same and the
+    // 16 multiplies per thread after the square roots are gone
+    const float inv_w = 1.0f / (float)kW;
+    static_assert((kW & (kW - 1)) == 0, "the scale must be a power of two to move it");
+    float win[8];
+#pragma unroll
+    for (int a = 0; a < 8; ++a) win[a] = p.window[tid + 256 * a] * inv_w;
+    float2 tw1[16];
+#pragma unroll
+    for (int q = 1; q < 16; ++q) tw1[q] = p.tw1[q * 256 + tid];
+
+    const int q1_2 = tid >> 4, t0_2 = tid & 15;                 // pass-2 role
+    __syncthreads();
+
+    const unsigned long long job_begin = (unsigned long long)blockIdx.x * p.jobs_per_block;
+    unsigned long long job_end = job_begin + p.jobs_per_block;
+    if (job_end > p.n_jobs) job_end = p.n_jobs;
+
+    // Software pipeline: the samples of transform j+1 are requested while transform j is still in
+    // its FFT passes, i.e. BEFORE j's magnitude stores.  vmcnt retires in issue order, so a load
+    // issued after 16-32 stores would have to wait for all of them to reach memory first.
+    float sa[(MONO && PAIRING == kPairAdjacentRow) ? 9 : 8], sb[8];
+    float ld0 = 0.0f, ld1 = 0.0f;   // sliding window: the two rows requested for the next transform
+    bool pending = false;
+    uint32_t issued_since = 0;      // vector-memory instructions this wave issued after requesting ld0 / ld1
+    auto fetch = [&](unsigned long long job, bool sequential) {
+        if (MONO) {
+            // frames are paired by their GLOBAL index (2q, 2q+1), so the bytes do not depend on where a
+            // range starts: an odd first_frame computes frame first_frame-1 too and simply does not store it
+            const unsigned long long f = 2 * (p.pair_base + job);
+            const unsigned long long fb = f + 1;
+            const bool second = fb < p.total_frames;  // the partner is transformed whenever the stream holds it
+            const float *s0 = p.pcm + f * p.H;
+            if (PAIRING == kPairAdjacentRow) {
+                // H = 256 = one row: frame f+1 row a is frame f row a+1, and the next transform
+                // (two frames on) re-uses rows 2..8 of this one: slide the register window and
+                // load only the two new rows -- every sample is fetched once per workgroup
+                if (kSlideWindow && sequential) {
+                    // Only REQUEST the two new rows here.  They land in two pending registers and are rotated
+                    // into the window at the top of the next iteration, AFTER this transform's stores have been
+                    // issued: the wait for them is then `vmcnt(stores issued since)`, which the older loads
+                    // satisfy while the stores are still in flight.  The compiler cannot express that wait (at
+                    // the loop header it merges the entry path and falls back to vmcnt(0), i.e. it drains the
+                    // store stream once per transform), so the two loads and their wait are written by hand.
+                    const float *r7 = s0 + 256 * 7;
+                    const float *r8 = second ? r7 + 256 : r7;  // no partner frame: any valid address, the value is unused
+                    asm volatile("global_load_dword %0, %2, %3\n\tglobal_load_dword %1, %2, %4"
+                                 : "=&v"(ld0), "=&v"(ld1)
+                                 : "v"(tid * 4), "s"(r7), "s"(r8)
+                                 : "memory");
+                    pending = true;
+                } else {
+#pragma unroll
+                    for (int a = 0; a < 8; ++a) sa[a] = s0[tid + 256 * a];
+                    sa[8] = second ? s0[tid + 256 * 8] : 0.0f;
+                }
+            } else {
+                // (a uniform base in a buffer descriptor + one 32-bit lane offset: a per-lane 64-bit pointer kept across the loop is
+                // what the fused variants of this path spilled -- and its reload is a vector-memory load waited for with vmcnt(0))
+                const __amdgpu_buffer_rsrc_t r0 = pcm_rsrc(s0), r1 = pcm_rsrc(second ? p.pcm + fb * p.H : s0);
+#pragma unroll
+                for (int a = 0; a < 8; ++a) {
+                    sa[a] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r0, tid * 4, 1024 * a, 0));
+                    sb[a] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r1, tid * 4, 1024 * a, 0));
+                }
+            }
+        } else {
+            const float *s0 = p.pcm + (p.first_frame + job) * p.H * p.C;
+            if (C2) {
+                // (a sliding register window like the mono one was tried here: stereo input is not traffic-bound and
+                // the extra live registers cost more than the saved row loads)
+                const __amdgpu_buffer_rsrc_t r0 = pcm_rsrc(s0);
+#pragma unroll
+                for (int a = 0; a < 8; ++a) {
+                    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r0, tid * 8, 2048 * a, 0);
+                    sa[a] = __uint_as_float(v.x); sb[a] = __uint_as_float(v.y);
+                }
+            } else {
+                // one channel, every frame its own (s, s) transform (SGX_FLAG_INDEPENDENT_FRAMES; audio_input_list_model.rs:67-69).
+                // (More than two interleaved channels never come here: their pairs are split into planes first and each
+                // plane runs the C2 kernel -- launch_wg.)
+#pragma unroll
+                for (int a = 0; a < 8; ++a) sa[a] = s0[tid + 256 * a];
+            }
+        }
+    };
+    if (job_begin < job_end) fetch(job_begin, false);
+    if (MONO && PAIRING == kPairAdjacentRow && kSlideWindow) {
+        // the first window is waited for HERE, so that the loop header carries no pending load of the entry path
+        asm volatile("" ::"v"(sa[0]), "v"(sa[1]), "v"(sa[2]), "v"(sa[3]), "v"(sa[4]), "v"(sa[5]), "v"(sa[6]), "v"(sa[7]),
+                     "v"(sa[(MONO && PAIRING == kPairAdjacentRow) ? 8 : 7]));
+    }
+
+    // Wave priorities.  The four waves of a SIMD belong to four workgroups in four different phases; left to the
+    // default arbitration they share the VALU evenly, so every transform reaches its stores as late as possible.  The
+    // waves of a transform that has finished its third pass are raised to priority 3 and keep it through the split,
+    // the stores and the next transform's first pass (its row loads are already in flight); they drop to 0 once that
+    // pass is in LDS.  A transform that is nearly done is finished first, its stores are issued earlier and the store
+    // stream overlaps the other workgroups' arithmetic better: +6 % (mono), and with the intermediate steps 1 and 2 for
+    // the second pass +12 % for stereo input (same-device A/B; the steps cost mono 1 %).  The fused pixel path holds
+    // priority 1 through its sample pass and 3 from its row pass on: +12 % over no priorities.
+    for (unsigned long long job = job_begin; job < job_end; ++job) {
+        if (MONO && PAIRING == kPairAdjacentRow && kSlideWindow && pending) {
+            // this transform = the previous one moved on by two rows.  vmcnt counts in issue order: the two row
+            // loads are complete once no more than `issued_since` younger instructions are outstanding.
+            // ONE asm statement chooses among the three waits with a scalar branch of its own.  As three statements in
+            // three C++ branches (round 1) the compiler merged their results in a phi and placed the copies
+            // `v_mov v0, v97` in FRONT of the waits of the two short paths: a read of a register whose load was still
+            // pending (gfx9 has no interlock for it).  tools/isa_check_prefetch.py (run by the Makefile) fails the build
+            // if anything touches the two registers between request and wait again.
+            asm volatile("s_cmp_ge_u32 %2, 14\n\t"
+                         "s_cbranch_scc1 1f\n\t"
+                         "s_cmp_ge_u32 %2, 7\n\t"
+                         "s_cbranch_scc1 2f\n\t"
+                         "s_waitcnt vmcnt(0)\n\t"
+                         "s_branch 3f\n"
+                         "2:\n\t"
+                         "s_waitcnt vmcnt(7)\n\t"
+                         "s_branch 3f\n"
+                         "1:\n\t"
+                         "s_waitcnt vmcnt(14)\n"
+                         "3:"
+                         : "+v"(ld0), "+v"(ld1)
+                         : "s"(__builtin_amdgcn_readfirstlane(issued_since))
+                         : "scc");
+#pragma unroll
+            for (int a = 0; a < 7; ++a) sa[a] = sa[a + 2];
+            sa[7] = ld0;
+            sa[(MONO && PAIRING == kPairAdjacentRow) ? 8 : 7] = ld1;
+        }
+        // ---- Hann (fft.rs:53-63) on the prefetched samples
+        float er[8], ei[8];
+        int tx = tid;
+        asm volatile("" : "+v"(tx));
+        const int q1x = tx >> 4, t0x = tx & 15;
+        // local (output) frame indices; for mono f0 may be -1 (the pair's first frame precedes the range)
+        const long long f0 = MONO ? (long long)(2 * (p.pair_base + job)) - (long long)p.first_frame : (long long)job;
+        const long long f1 = f0 + 1;
+        const bool have_first = !MONO || f0 >= 0;
+        const bool data_second = !MONO || (unsigned long long)(f1 + (long long)p.first_frame) < p.total_frames;
+        const bool have_second = !MONO || f1 < (long long)p.n_frames;  // ... but stored only inside the requested range
+#pragma unroll
+        for (int a = 0; a < 8; ++a) {
+            er[a] = sa[a] * win[a];
+            if (MONO && PAIRING == kPairAdjacentRow) ei[a] = data_second ? sa[a + 1] * win[a] : 0.0f;
+            else if (!MONO && !C2) ei[a] = er[a];   // (s, s)
+            else ei[a] = data_second ? sb[a] * win[a] : 0.0f;
+        }
+        const int col = tid;                           // pass-3 / output column of this thread
+        const int pcol = col == 0 ? 256 : 256 - col;   // partner column (column 0 is its own partner, one row up)
+
+        // ---- pass 1: 16-point DFT over a, inputs a >= 8 are the zero padding:
+        //      even q1 = FFT8(z), odd q1 = FFT8(z * w_16^a)
+        float orr[8], oi[8];
+#pragma unroll
+        for (int a = 0; a < 8; ++a) { orr[a] = er[a]; oi[a] = ei[a]; }
+        pretwiddle8_w16(orr, oi);
+        fft8(er, ei);
+        fft8(orr, oi);
+
+        lds_barrier();  // the previous transform's partner reads are complete
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int pos = FFT8_OUT[j];
+            const float2 ve = make_float2(er[pos], ei[pos]);
+            const float2 vo = make_float2(orr[pos], oi[pos]);
+            buf[(2 * j) * kS1 + tx] = j == 0 ? ve : cmulf(ve, tw1[2 * j]);
+            buf[(2 * j + 1) * kS1 + (tx ^ 16)] = cmulf(vo, tw1[2 * j + 1]);
+        }
+        __builtin_amdgcn_s_setprio(0);  // (wave priorities: see the note at the head of the loop)
+        lds_barrier();
+
+        // ---- pass 2: thread (q1, t0): 16-point FFT over t1, then twiddle w_256^{t0 q2}
+        float xr[16], xi[16];
+#pragma unroll
+        for (int t1 = 0; t1 < 16; ++t1) {
+            const float2 v = buf[(q1x * kS1 + t0x) + 16 * (t1 ^ (q1x & 1))];
+            xr[t1] = v.x; xi[t1] = v.y;
+        }
+        fft16(xr, xi);
+        if (!MONO) __builtin_amdgcn_s_setprio(1);
+        lds_barrier();  // everyone has read image 1
+#pragma unroll
+        for (int q2 = 0; q2 < 16; ++q2) {
+            const int pos = FFT16_OUT[q2];
+            const float2 v = make_float2(xr[pos], xi[pos]);
+            buf[(t0x * kS2 + (q1x ^ t0x)) + 16 * q2] = q2 == 0 ? v : cmulf(v, tw2[q2 * 16 + t0_2]);
+        }
+        if (!MONO) __builtin_amdgcn_s_setprio(2);
+        lds_barrier();
+
+        // ---- pass 3: thread u = q1 + 16 q2: 16-point FFT over t0 -> bins k = u + 256 q3
+#pragma unroll
+        for (int t0 = 0; t0 < 16; ++t0) {
+            const float2 v = buf[t0 * kS2 + (tx ^ t0)];
+            xr[t0] = v.x; xi[t0] = v.y;
+        }
+        fft16(xr, xi);
+        if (job + 1 < job_end) fetch(job + 1, true);  // ahead of this transform's stores (see above)
+        if (RENDER) __builtin_amdgcn_s_setprio(1);  // the pixel passes are long: 3 only from the row pass (the pixel stores) on
+        else __builtin_amdgcn_s_setprio(3);
+        lds_barrier();  // everyone has read image 2
+        // partner exchange: publish q3 = 8..15 (the bins P-k of the kept half)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int pos = FFT16_OUT[8 + j];
+            buf[j * 256 + col] = make_float2(xr[pos], xi[pos]);
+        }
+        lds_barrier();
+
+        // ---- split + magnitude (fft.rs:81-98)
+        float ml[8], mr[8];
+#pragma unroll
+        for (int q3 = 0; q3 < 8; ++q3) {
+            const int pos = FFT16_OUT[q3];
+            // F[P-k]: thread 256-u holds it as q3' = 15 - q3 (row 7 - q3); thread 0 as q3' = 16 - q3
+            const float2 b = buf[(7 - q3) * 256 + pcol];
+            const float ar = xr[pos], ai = xi[pos];
+            const float pr = ar + b.x, pi = ai - b.y;   // a + conj(b) = 2 L^
+            const float qr = ar - b.x, qi = ai + b.y;   // a - conj(b) = 2i R^
+            ml[q3] = __builtin_amdgcn_sqrtf(fmaf(pr, pr, pi * pi));  // already scaled by 1 / W (see `win`)
+            mr[q3] = __builtin_amdgcn_sqrtf(fmaf(qr, qr, qi * qi));
+        }
+
+        // every stored row is 8 store instructions in every wave (the lane of bin 0 is masked, not skipped; the
+        // wait below assumes 7, one to spare); the fused pixel path issues table loads and pixel stores of its
+        // own: counted as "unknown" = 0
+        // (the fused pixel path: every wave issues at least n_samples / 256 table loads in the sample pass and R / 256 pixel stores per
+        // stored column in the row pass AFTER the two row loads were requested -- a lower bound is all the wait needs; with "unknown = 0"
+        // the head of the next transform waited for the pixel stores just issued to be acknowledged by memory)
+        issued_since = RENDER ? (p.n_samples >> 8) + (p.R >> 8) * ((have_first ? 1u : 0u) + ((MONO && have_second) ? 1u : 0u))
+                              : 7u * ((have_first ? 1u : 0u) + ((MONO && have_second) ? 1u : 0u));
+        if (!RENDER) {
+            // ---- store [F][pairs][M][2]: uniform row base (SGPR) + one 32-bit lane offset
+            if (p.out_f16) {
+                char *base = reinterpret_cast<char *>(p.mags);
+                const long long row0 = (long long)(((size_t)(have_first ? f0 : 0) * p.pairs + p.pair) * (size_t)kM * 4) - 4;
+                if (MONO) {
+                    if (have_first) store_row_f16<true>(base, row0, col, ml, ml);
+                    if (have_second) store_row_f16<true>(base, (long long)((f1 * p.pairs + p.pair) * (size_t)kM * 4) - 4, col, mr, mr);
+                } else {
+                    store_row_f16<false>(base, row0, col, ml, mr);
+                }
+            } else {
+                // byte offset of bin k = 0 of the row (bin k lives 8 k bytes on; k = 0 is never stored)
+                char *base = reinterpret_cast<char *>(p.mags);
+                constexpr size_t kPitch = (size_t)kM * 8;
+                const long long row0 = (long long)(((size_t)(have_first ? f0 : 0) * p.pairs + p.pair) * kPitch) - 8;
+                if (MONO) {
+                    if (have_first) store_row<true>(base, row0, col, ml, ml);
+                    if (have_second) store_row<true>(base, (long long)((f1 * p.pairs + p.pair) * kPitch) - 8, col, mr, mr);
+                } else {
+                    store_row<false>(base, row0, col, ml, mr);
+                }
+            }
+        } else {
+            // ---- fused pixel column(s): magnitude_in -> color_for -> put_pixel
+            //      (simple_spectrogram.rs:141-161), magnitudes staged in LDS only
+            float2 *m2 = reinterpret_cast<float2 *>(buf);  // [bin - 1]: (l, r), or for mono (frame f0, frame f0 + 1)
+            float2 *vbuf = m2 + 2048;                       // [sample]: the interpolated pair
+            lds_barrier();  // partner reads done: the buffer can be overwritten
+#pragma unroll
+            for (int q3 = 0; q3 < 8; ++q3) {
+                const int k = col + 256 * q3;
+                if (k >= 1) m2[k - 1] = make_float2(ml[q3], mr[q3]);
+            }
+            lds_barrier();
+            if (p.interp == SGX_INTERP_COSINE) sample_pass<true>(p, m2, vbuf, tid);
+            else sample_pass<false>(p, m2, vbuf, tid);
+            lds_barrier();
+            uchar4 *rgba = reinterpret_cast<uchar4 *>(p.rgba);
+            uchar4 *dst_a = rgba + ((size_t)(have_first ? f0 : 0) * p.pairs + p.pair) * (size_t)p.R;
+            uchar4 *dst_b = rgba + ((size_t)f1 * p.pairs + p.pair) * (size_t)p.R;
+            __builtin_amdgcn_s_setprio(3);
+            row_pass<MONO>(p, row_words, vbuf, dst_a, dst_b, have_first, have_second, pal, tid);
+        }
+    }
+}
+
+// Is the kernel's LUT-index seed floor(log2(power + 1e-7) a + b) (pixel_for) within one of the exact threshold count
+// for EVERY power?  u(p) = log2(p + 1e-7) a + b is monotone in p and the count steps from e to e + 1 at lut_thr[e]
+// (the exact switch point of the host's float32 evaluation, found by bisection over bit patterns), so it is enough
+// to look at the switch points: with u(lut_thr[e]) inside (e + 0.5, e + 1.5) for every e, a power between two
+// neighbouring switch points has u inside (count - 0.5, count + 1.5) and its floor is count - 1, count or count + 1.
+// The device's v_log_f32 (1 ulp), its float32 add and fma move u by less than 1e-3 -- far inside the half index kept
+// in hand.  Thresholds at +0 (levels every power reaches: dB ranges that start below the 1e-7 floor) are fine as long
+// as u(0) is not below their count; unreachable levels (NaN) or anything else unusual: walk instead.
+bool seed_within_one(const std::vector<float> &lut_thr, double guess_a, double guess_b)
+{
+    if (lut_thr.size() != 255) return false;
+    auto u = [&](double pw) { return log2(pw + 1e-7) * guess_a + guess_b; };
+    size_t zeros = 0;
+    for (size_t e = 0; e < lut_thr.size(); ++e) {
+        const float t = lut_thr[e];
+        if (!(t == t) || t < 0.0f || !std::isfinite(t)) return false;
+        if (e > 0 && t < lut_thr[e - 1]) return false;
+        if (t == 0.0f) { zeros = e + 1; continue; }
+        const double ue = u((double)t);
+        if (!(ue > (double)e + 0.51 && ue < (double)e + 1.49)) return false;   // (the device's log, add and fma move u by < 1e-3)
+    }
+    return u(0.0) > (double)zeros - 0.49;
+}
+
+}  // namespace wg
+
+hipError_t wg4096_init(sgx_ctx *c, void **out)
+{
+    using namespace wg;
+    auto *t = new WgTables();
+    std::vector<float2> tw1(16 * 256), tw2(256);
+    auto unit = [](int idx, int N) {
+        idx %= N;
+        const double ang = -2.0 * M_PI * (double)idx / (double)N;
+        double cs = cos(ang), sn = sin(ang);
+        if (idx == 0) { cs = 1.0; sn = 0.0; }
+        if (4 * idx == N) { cs = 0.0; sn = -1.0; }
+        if (2 * idx == N) { cs = -1.0; sn = 0.0; }
+        if (4 * idx == 3 * N) { cs = 0.0; sn = 1.0; }
+        return make_float2((float)cs, (float)sn);
+    };
+    for (int q = 0; q < 16; ++q)
+        for (int tt = 0; tt < 256; ++tt) tw1[q * 256 + tt] = unit(tt * q, kP);
+    for (int q = 0; q < 16; ++q)
+        for (int t0 = 0; t0 < 16; ++t0) tw2[q * 16 + t0] = unit(t0 * q, 256);
+
+    // packed tables of the fused pixel path: 4 B per row, 8 B per LDS slot (the kernel re-derives mu^2, mu^3 and 1 - o' with the
+    // same single-rounded operations the host table holds).  Slots = the rows' samples in lin_space order; after a row whose
+    // count is even and at least 4 comes one PAD slot -- a repeat of the row's last sample that no row reads -- so that the next
+    // row starts an odd number of slots on: the row pass reads slot first + i of 32 consecutive rows at once, and an even stride
+    // of 8-byte slots folds those 32 addresses onto a few bank pairs (stride 8: four of them).  Host table only: the kernel is
+    // the one of round 2.  SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 0.21 -> 0.13 (profiles/r03_pixel_ab.txt).
+    std::vector<uint32_t> rows(c->tab.rows.size());
+    std::vector<PackedSample> samples;
+    bool fusable = c->tab.rows.size() <= 1024;
+    const int32_t last = (int32_t)c->M - 1;
+    auto packed = [&](const SampleEntry &se) {
+        const int32_t x1 = se.i0;
+        // interior: no tap of this sample is clamped at either end of the spectrum
+        const bool interior = c->cfg.interp == SGX_INTERP_COSINE ? !(x1 + 1 > last) : !(x1 < 1 || x1 + 2 > last);
+        PackedSample ps;
+        ps.i0 = interior ? x1 : ~x1;
+        ps.w = c->cfg.interp == SGX_INTERP_COSINE ? se.w2 : se.w0;
+        return ps;
+    };
+    for (size_t i = 0; i < rows.size(); ++i) {
+        const auto &r = c->tab.rows[i];
+        if (r.count >= 65536 || samples.size() >= 65536) fusable = false;
+        rows[i] = ((uint32_t)samples.size() & 0xffffu) | ((r.count & 0xffffu) << 16);
+        for (uint32_t j = 0; j < r.count; ++j) samples.push_back(packed(c->tab.samples[r.first + j]));
+        if (r.count >= 4 && (r.count & 1u) == 0) samples.push_back(samples.back());   // the pad slot
+    }
+    // the interpolated samples of a column sit in LDS behind the column itself
+    fusable = fusable && samples.size() <= (size_t)kMaxFusedSamples;
+    if (samples.empty()) samples.push_back(PackedSample{0, 0.0f});
+    t->fusable = fusable;
+    t->n_samples = (uint32_t)samples.size();
+
+    auto up = [](auto **dst, const auto &v) {
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(dst), v.size() * sizeof(v[0]));
+        if (e == hipSuccess) e = hipMemcpy(*dst, v.data(), v.size() * sizeof(v[0]), hipMemcpyHostToDevice);
+        return e;
+    };
+    hipError_t e = up(&t->d_tw1, tw1);
+    if (e == hipSuccess) e = up(&t->d_tw2, tw2);
+    if (e == hipSuccess) e = up(&t->d_rows, rows);
+    if (e == hipSuccess) e = up(&t->d_samples, samples);
+    if (e != hipSuccess) {
+        wg4096_destroy(t);
+        return e;
+    }
+    *out = t;
+    return hipSuccess;
+}
+
+void wg4096_destroy(void *tables)
+{
+    auto *t = static_cast<wg::WgTables *>(tables);
+    if (!t) return;
+    if (t->d_tw1) (void)hipFree(t->d_tw1);
+    if (t->d_tw2) (void)hipFree(t->d_tw2);
+    if (t->d_rows) (void)hipFree(t->d_rows);
+    if (t->d_samples) (void)hipFree(t->d_samples);
+    if (t->d_planes) (void)hipFree(t->d_planes);
+    delete t;
+}
+
+bool wg4096_can_fuse_render(const sgx_ctx *c, const void *tables)
+{
+    const auto *t = static_cast<const wg::WgTables *>(tables);
+    // mono (sequential) colour schemes with a 256-entry ramp; diverging schemes take the two-kernel path
+    return t && t->fusable && c->pal.n == 256 && !c->pal.stereo && !c->pal.segments;
+}
+
+void lut_seed_coefficients(const sgx_ctx *c, float &a, float &b)
+{
+    // t * n = (10 log10(x) - min_db) * n / (max_db - min_db) = log2(x) * a + b   (seed only)
+    const double span = (double)c->cfg.max_db - (double)c->cfg.min_db;
+    const double n = c->cfg.lut_index_mode == SGX_LUT_ROUND_NM1 ? 255.0 : 256.0;
+    a = (float)(10.0 * log10(2.0) * n / span);
+    b = (float)(-(double)c->cfg.min_db * n / span + (c->cfg.lut_index_mode == SGX_LUT_ROUND_NM1 ? 0.5 : 0.0));
+}
+
+bool wg4096_seed_is_within_one(const sgx_ctx *c)
+{
+    float a, b;
+    lut_seed_coefficients(c, a, b);
+    return !(c->cfg.flags & SGX_FLAG_LUT_WALK) && wg::seed_within_one(c->pal.lut_thr, (double)a, (double)b);
+}
+
+namespace {
+
+template <bool RENDER>
+hipError_t launch_wg(const sgx_ctx *c, const void *tables, const float *d_pcm, uint32_t channels, uint32_t pairs,
+                     size_t first_frame, size_t n_frames, size_t total_frames, float *d_mags, uint8_t *d_rgba, bool out_f16 = false)
+{
+    using namespace wg;
+    if (n_frames == 0) return hipSuccess;
+    const auto *t = static_cast<const WgTables *>(tables);
+    int n_cu = 256;
+    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device);
+    // More than two channels: the (l, r) pairs are split into planes first and every pair runs the two-channel kernel on its
+    // own plane.  (Reading a pair at a stride of C floats kept the strided variant at the register cap with 60-68 bytes of
+    // scratch: 8 channels ran at 80 M transforms/s against 145-180 M for a stereo stream.)
+    size_t plane_floats = 0;
+    if (channels > 2) {
+        const size_t first_sample = first_frame * (size_t)c->H, n_samp = (n_frames - 1) * (size_t)c->H + kW;
+        plane_floats = (2 * n_samp + 63) & ~(size_t)63;
+        if (plane_floats * pairs > t->planes_floats) {
+            hipError_t e = hipStreamSynchronize(c->stream);  // a previous launch may still read the old planes
+            if (e != hipSuccess) return e;
+            if (t->d_planes) { (void)hipFree(t->d_planes); t->d_planes = nullptr; t->planes_floats = 0; }
+            e = hipMalloc(reinterpret_cast<void **>(&t->d_planes), plane_floats * pairs * sizeof(float));
+            if (e != hipSuccess) return e;
+            t->planes_floats = plane_floats * pairs;
+        }
+        const hipError_t e = launch_deinterleave_pairs(c, d_pcm, t->d_planes, plane_floats, first_sample, n_samp, channels, pairs);
+        if (e != hipSuccess) return e;
+    }
+    for (uint32_t pair = 0; pair < pairs; ++pair) {
+        Params p{};
+        p.pcm = d_pcm;
+        p.tw1 = t->d_tw1;
+        p.tw2 = t->d_tw2;
+        p.window = c->d_window;
+        p.mags = d_mags;
+        p.out_f16 = out_f16 ? 1u : 0u;
+        p.first_frame = first_frame;
+        p.n_frames = n_frames;
+        p.total_frames = total_frames;
+        p.H = c->H;
+        p.C = channels;
+        p.pairs = pairs;
+        p.pair = pair;
+        p.pair_l = channels == 1 ? 0 : 2 * pair;
+        p.pair_r = channels == 1 ? 0 : 2 * pair + 1;
+        if (channels > 2) {   // this pair's plane as a two-channel stream whose sample 0 is the call's first sample
+            p.pcm = t->d_planes + (size_t)pair * plane_floats - first_frame * (size_t)c->H * 2;
+            p.C = 2;
+            p.pair_l = 0;
+            p.pair_r = 1;
+        }
+        if (RENDER) {
+            p.rows = t->d_rows;
+            p.samples = t->d_samples;
+            p.n_samples = t->n_samples;
+            p.lut_thr = c->d_lut_thr;
+            p.lut_rgba = c->d_lut_rgba;
+            p.rgba = d_rgba;
+            p.R = c->R;
+            p.interp = c->cfg.interp;
+            lut_seed_coefficients(c, p.guess_a, p.guess_b);
+            p.seed_pm1 = wg4096_seed_is_within_one(c) ? 1u : 0u;
+        }
+        // mono normally rides two frames per transform; SGX_FLAG_INDEPENDENT_FRAMES runs it as (s, s) pairs
+        const bool mono = channels == 1 && !(c->cfg.flags & SGX_FLAG_INDEPENDENT_FRAMES);
+        p.pair_base = mono ? first_frame / 2 : 0;
+        p.n_jobs = mono ? (first_frame + n_frames + 1) / 2 - first_frame / 2 : n_frames;
+        // persistent workgroups, 4 per CU; each owns a contiguous run of transforms so that the
+        // overlapping audio of consecutive frames is re-read from L1/L2, not HBM
+        unsigned long long blocks = (unsigned long long)n_cu * 4;
+        unsigned long long per = (p.n_jobs + blocks - 1) / blocks;
+        if (per < 1) per = 1;
+        blocks = (p.n_jobs + per - 1) / per;
+        p.jobs_per_block = per;
+        const dim3 grid((unsigned)blocks), block(256);
+        const size_t lds = RENDER ? kLdsBytesRender : kLdsBytes;
+        if (mono) {
+            if (c->H == 256) hipLaunchKernelGGL((stft4096_wg_kernel<true, kPairAdjacentRow, false, RENDER>), grid, block, lds, c->stream, p);
+            else hipLaunchKernelGGL((stft4096_wg_kernel<true, kPairAdjacent, false, RENDER>), grid, block, lds, c->stream, p);
+        } else if (channels == 1) {   // SGX_FLAG_INDEPENDENT_FRAMES: every mono frame as its own (s, s) transform
+            hipLaunchKernelGGL((stft4096_wg_kernel<false, kPairAdjacent, false, RENDER>), grid, block, lds, c->stream, p);
+        } else {
+            hipLaunchKernelGGL((stft4096_wg_kernel<false, kPairAdjacent, true, RENDER>), grid, block, lds, c->stream, p);
+        }
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+}  // namespace
+
+hipError_t launch_stft_wg4096(const sgx_ctx *c, const void *tables, const float *d_pcm, uint32_t channels, uint32_t pairs,
+                              size_t first_frame, size_t n_frames, size_t total_frames, float *d_mags)
+{
+    return launch_wg<false>(c, tables, d_pcm, channels, pairs, first_frame, n_frames, total_frames, d_mags, nullptr);
+}
+
+hipError_t launch_stft_wg4096_f16(const sgx_ctx *c, const void *tables, const float *d_pcm, uint32_t channels, uint32_t pairs,
+                                  size_t first_frame, size_t n_frames, size_t total_frames, void *d_mags_f16)
+{
+    return launch_wg<false>(c, tables, d_pcm, channels, pairs, first_frame, n_frames, total_frames, static_cast<float *>(d_mags_f16), nullptr, true);
+}
+
+hipError_t launch_render_wg4096(const sgx_ctx *c, const void *tables, const float *d_pcm, uint32_t channels, uint32_t pairs,
+                                size_t first_frame, size_t n_frames, size_t total_frames, uint8_t *d_rgba)
+{
+    return launch_wg<true>(c, tables, d_pcm, channels, pairs, first_frame, n_frames, total_frames, nullptr, d_rgba);
+}
+
+}  // namespace sgx

@@ -1,0 +1,274 @@
+// stft4096_wg.hpp -- declarations shared by the two workgroup-per-transform kernels
+// (stft4096_wg.hip: scalar codelets; stft4096_wgp.hip: packed (re, im) codelets).
+#pragma once
+#include <hip/hip_fp16.h>
+
+#include "sgx_internal.hpp"
+
+namespace sgx {
+namespace wg {
+
+constexpr int kW = 2048, kP = 4096, kM = 2047;
+// Sliding the sample window in registers (2 new rows per mono transform instead of 9 loads): every
+// sample is fetched once per workgroup.  It pins 7 VGPRs across the FFT passes (the scalar kernel
+// then spills 3 registers) but the launch is bound by total HBM traffic, and dropping the overlap
+// re-reads (3.3 -> 1.0 KB per frame) was worth +5 % (same-device A/B, 1e6 frames).
+constexpr bool kSlideWindow = true;
+constexpr int kS1 = 256;            // row stride (complex) of the pass-1 -> pass-2 image [q1][t]
+constexpr int kS2 = 256;            // row stride (complex) of the pass-2 -> pass-3 image [t0][q1 + 16 q2]
+constexpr int kBufComplex = 16 * kS1;  // 4352 complex = 34 816 B (also holds 16*257 and 9*256)
+constexpr size_t kLdsBytes = (size_t)(kBufComplex + 256) * sizeof(float2);
+constexpr size_t kLdsBytesRender = kLdsBytes + 256 * sizeof(uint2);   // + the palette table of pixel_for: {threshold to leave index i, RGBA of index i}
+
+struct PackedSample {
+    int32_t i0;   // cubic: floor(index); cosine: low
+    float w;      // cubic: mu;           cosine: o' (the cosine-eased offset)
+};
+
+struct Params {
+    const float *pcm;
+    const float2 *tw1;   // [16][256]  w_4096^{t q1}
+    const float2 *tw2;   // [16][16]   w_256^{t0 q2} at [q2][t0]
+    const float *window; // [2048]
+    float *mags;
+    unsigned long long first_frame, n_frames, n_jobs, jobs_per_block;
+    unsigned long long pair_base;  // mono: global index of the first frame PAIR (first_frame / 2)
+    unsigned long long total_frames;  // frames the stream holds (a pair's second frame is transformed whenever it exists)
+    uint32_t H, C, pair_l, pair_r, pairs, pair;
+    uint32_t out_f16;          // magnitudes are stored as (l, r) half pairs, 4 B per bin (the F16F16 ring of gpu_spectrogram.rs:218-226)
+    // fused pixel path (RENDER): magnitudes never leave LDS
+    const uint32_t *rows;      // [R]  first slot | count << 16
+    const PackedSample *samples;   // one entry per LDS slot: the rows' samples in lin_space order, plus pad slots (see wg4096_init)
+    uint32_t n_samples;        // slots per column (sum of the rows' counts + pads)
+    const float *lut_thr;      // [255]
+    const uchar4 *lut_rgba;    // [256]
+    uint8_t *rgba;             // [F][pairs][R][4]
+    uint32_t R, interp;
+    float guess_a, guess_b;    // LUT index ~ floor(log2(power + 1e-7) * a + b), then exact fix-up
+    uint32_t seed_pm1;         // the host has shown that this seed is never off by more than one (seed_within_one): one compare pair fixes it
+};
+
+// Which two mono frames share a transform: always (2j, 2j+1).
+//   kPairAdjacentRow : H = 256: frame 2j+1's rows are frame 2j's rows shifted by one (9 rows feed both)
+//   kPairAdjacent    : any other hop (16 row loads)
+// (Tried and rejected, same-device A/B on 1e6 frames: pairing (f, f+16) plus a per-row lane rotation
+// so that both rows' stores are 128-byte aligned: -10 %, the extra row loads cost more than the
+// alignment buys; 16-byte stores via a DPP lane-pair exchange: -8 %.  The launch is bound by total
+// HBM traffic, not by store alignment or store instruction count.)
+constexpr int kPairAdjacentRow = 0, kPairAdjacent = 1;
+
+struct WgTables {
+    float2 *d_tw1 = nullptr;
+    float2 *d_tw2 = nullptr;
+    uint32_t *d_rows = nullptr;        // packed row table for the fused pixel path
+    PackedSample *d_samples = nullptr;
+    uint32_t n_samples = 0;
+    bool fusable = false;
+    mutable float *d_planes = nullptr;   // more than two channels: (l, r) pair planes of the sample range of a call, grown on demand
+    mutable size_t planes_floats = 0;
+};
+
+__device__ __forceinline__ void lds_barrier()
+{
+    // LDS-only workgroup barrier: outstanding global stores are NOT waited for
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// one row of [M][2] floats; rowm8 = row base - 8 bytes (bin k lives at byte 8 k of rowm8): a uniform
+// (SGPR) row base plus one 32-bit lane offset, immediate offsets per segment
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+// A raw buffer descriptor over one output row: base = the row's bin-0 address (uniform), no stride, no bounds
+// in the way (2 GB window).  Stores through it take an SGPR descriptor + one 32-bit lane offset + a scalar
+// segment offset + an immediate: no per-lane 64-bit address arithmetic at all.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t row_rsrc(char *mags, long long row_byte)
+{
+    const uint32_t olo = __builtin_amdgcn_readfirstlane((uint32_t)row_byte);
+    const uint32_t ohi = __builtin_amdgcn_readfirstlane((uint32_t)((unsigned long long)row_byte >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc(mags + (long long)(((unsigned long long)ohi << 32) | olo), 0, 0x7fffffff, 0x00020000);
+}
+
+// the same kind of descriptor over the sample stream from a wave-uniform address on (a frame's first sample)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t pcm_rsrc(const float *base)
+{
+    const unsigned long long a = (unsigned long long)base;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((unsigned long long)hi << 32) | lo), 0, 0x7fffffff, 0x00020000);
+}
+
+// one row of [M][2] floats; row_byte = byte offset of the row's (absent) bin 0, bin k lives 8 k bytes on
+// Cache policy of the magnitude stores (A/B on one device, 1e6 frames): an (l, r) stream re-reads 7/8 of every frame's
+// samples through L2, and marking the output non-temporal keeps them there: 6.00 -> 5.57 ms.  A mono stream slides its
+// window in registers and re-reads nothing: there the same bit costs 10-40 %, sc1 30 %.
+constexpr int kAuxNt = 2;   // the `nt` bit of a buffer store
+template <bool DUP>  // DUP: mono, the row holds (m, m); else (va, vb) = (left, right)
+__device__ __forceinline__ void store_row(char *mags, long long row_byte, int col, const float (&va)[8], const float (&vb)[8])
+{
+    const __amdgpu_buffer_rsrc_t r = row_rsrc(mags, row_byte);
+    const int lane_off = col * 8;
+#pragma unroll
+    for (int q3 = 0; q3 < 8; ++q3)
+        if (q3 > 0 || col != 0) {  // k = 0 (DC) is not part of the output (fft.rs:81)
+            const u32x2 d = {__float_as_uint(va[q3]), __float_as_uint(DUP ? va[q3] : vb[q3])};
+            __builtin_amdgcn_raw_buffer_store_b64(d, r, lane_off + 2048 * (q3 & 1), 4096 * (q3 >> 1), DUP ? 0 : kAuxNt);
+        }
+}
+
+// ---- fused pixel column: magnitude_in -> color_for -> put_pixel (simple_spectrogram.rs:141-161) ---------------
+// Two passes over LDS, both balanced whatever the rows' sample counts (a row of the log axis averages 1 sample
+// at the bottom and 11 at the top: one thread per ROW leaves the wave that owns the top rows with twice the work
+// of the others, and walks the sample table in a dependent loop of L1 loads):
+//   sample pass  one thread per magnitude_in SAMPLE (2 173 per column at 48 kHz / 1024 rows): coalesced table
+//                read, interpolation of BOTH channels (stereo) or BOTH mono columns of the transform -- the
+//                column lives in LDS as float2 per bin either way -- result to LDS
+//   row pass     one thread per row: sum of its samples in lin_space order (Complex::sum), the divide, dB
+//                thresholds, LUT, pixel store (coalesced: consecutive lanes, consecutive image rows).  A row's slots
+//                start at an odd distance from the previous row's where the count is even (pad slots, host table
+//                only): 32 consecutive rows of 8 samples then touch 32 different bank pairs instead of 4
+// Sample word: i0 >= 0: no tap touches the ends of the spectrum (taps are contiguous bins, the saturating index
+// arithmetic of interpolated_frequency_sample.rs:89-105 is skipped); i0 < 0: ~i0 is the index, taps are clamped.
+constexpr int kMaxFusedSamples = (kBufComplex - 2048);  // float2 per sample behind the 2048-bin column (2304)
+
+template <bool COSINE, bool INTERIOR>
+__device__ __forceinline__ float2 interp_sample2(const float2 *m2, int i0, float w, int last)
+{
+    float2 v;
+    if (COSINE) {
+        // :79-86  data[low] * (1 - o') + data[high] * o'
+        const int lo = i0, hi = INTERIOR ? lo + 1 : (lo + 1 < last ? lo + 1 : last);
+        const float w1 = 1.0f - w;
+        const float2 a = m2[lo], b = m2[hi];
+        v.x = a.x * w1 + b.x * w;
+        v.y = a.y * w1 + b.y * w;
+    } else {
+        // :89-105
+        const int x1 = i0;
+        const int x0 = INTERIOR ? x1 - 1 : (x1 > 0 ? x1 - 1 : 0);
+        const int x2 = INTERIOR ? x1 + 1 : (x1 + 1 < last ? x1 + 1 : last);
+        const int x3 = INTERIOR ? x1 + 2 : (x1 + 2 < last ? x1 + 2 : last);
+        const float mu = w, mu2 = mu * mu, mu3 = mu * mu2;
+        const float2 y0 = m2[x0], y1 = m2[x1], y2 = m2[x2], y3 = m2[x3];
+        {
+            const float a0 = ((y3.x - y2.x) - y0.x) + y1.x;
+            const float a1 = (y0.x - y1.x) - a0;
+            const float a2 = y2.x - y0.x;
+            v.x = ((a0 * mu3) + (a1 * mu2)) + ((a2 * mu) + y1.x);
+        }
+        {
+            const float a0 = ((y3.y - y2.y) - y0.y) + y1.y;
+            const float a1 = (y0.y - y1.y) - a0;
+            const float a2 = y2.y - y0.y;
+            v.y = ((a0 * mu3) + (a1 * mu2)) + ((a2 * mu) + y1.y);
+        }
+    }
+    return v;
+}
+
+template <bool COSINE>
+__device__ __forceinline__ void sample_pass(const Params &p, const float2 *m2, float2 *vbuf, int tid)
+{
+    const int last = kM - 1;
+    // the table word of the next step is requested before this step's gathers: one L1 latency per step is
+    // overlapped instead of exposed (two registers; deeper unrolling costs more registers than these kernels have)
+    // (the table through a buffer descriptor: a uniform base + a 32-bit lane offset, no per-lane 64-bit pointer to keep)
+    const __amdgpu_buffer_rsrc_t rt = pcm_rsrc(reinterpret_cast<const float *>(p.samples));
+    auto item = [&](uint32_t i) {
+        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rt, (int)((i < p.n_samples ? i : 0u) * 8u), 0, 0);
+        return PackedSample{(int32_t)v.x, __uint_as_float(v.y)};
+    };
+    uint32_t s = tid;
+    PackedSample se = item(s);
+    while (s < p.n_samples) {
+        const uint32_t s_next = s + 256;
+        const PackedSample se_next = item(s_next);
+        vbuf[s] = se.i0 >= 0 ? interp_sample2<COSINE, true>(m2, se.i0, se.w, last)
+                             : interp_sample2<COSINE, false>(m2, ~se.i0, se.w, last);
+        se = se_next;
+        s = s_next;
+    }
+}
+
+// colorscheme.rs:59-61 as a threshold count: the LUT index is the number of thresholds the power has reached, the
+// thresholds being the exact switch points of the host's float32 evaluation (sgx_tables.cpp).  v_log_f32 only SEEDS the
+// count.  pal[i] = {the smallest power whose index is i + 1 (NaN for i = 255: no power leaves the last index), RGBA of i}.
+//   seed_pm1 (the usual case): the host has checked, threshold by threshold, that the exact value u the seed approximates
+//     lies within half an index of the count at every switch point (seed_within_one), so floor(u - 1/2) is the count or
+//     one below it: ONE 16-byte LDS access brings that entry's threshold and both candidate colours, one compare picks.
+//     No loop, no second (dependent) LDS access for the colour.  (A NaN power: the seed is 0 and the compare fails ->
+//     index 0, as the walk below gives.)
+//   otherwise (unreachable levels, SGX_FLAG_LUT_WALK): walk from the seed, as the first version of this kernel did.
+__device__ __forceinline__ uchar4 pixel_for(const Params &p, float l, float r, const uint2 *pal)
+{
+    const float power = (l * l) + (r * r);
+    const float u = fmaf(__builtin_amdgcn_logf(power + 1e-7f), p.guess_a, p.guess_b);
+    uint32_t rgba;
+    if (p.seed_pm1) {
+        int idx = (int)floorf(u - 0.5f);
+        idx = idx < 0 ? 0 : (idx > 254 ? 254 : idx);
+        const uint2 e0 = pal[idx], e1 = pal[idx + 1];
+        rgba = power >= __uint_as_float(e0.x) ? e1.y : e0.y;
+    } else {
+        int idx = (int)floorf(u);
+        idx = idx < 0 ? 0 : (idx > 255 ? 255 : idx);
+        while (idx < 255 && power >= __uint_as_float(pal[idx].x)) ++idx;
+        while (idx > 0 && !(power >= __uint_as_float(pal[idx - 1].x))) --idx;
+        rgba = pal[idx].y;
+    }
+    uchar4 c;
+    c.x = rgba & 0xff; c.y = (rgba >> 8) & 0xff; c.z = (rgba >> 16) & 0xff; c.w = rgba >> 24;   // alpha = 1.0 -> 255
+    return c;
+}
+
+bool seed_within_one(const std::vector<float> &lut_thr, double guess_a, double guess_b);
+
+// MONO: .x / .y of a sample are the two columns (frames) of the transform, each a (s, s) pixel; else one (l, r) pixel.
+// (Tried, same-device A/B: the thread's sample-table words and row words requested before the two barriers and the
+// loops unrolled (9 samples, 4 rows side by side, thresholds read four at a time): 182 -> 131 M frames/s -- these
+// kernels sit at the 128-VGPR cap of four waves per SIMD and every extra live value becomes scratch traffic.)
+template <bool MONO>
+__device__ __forceinline__ void row_pass(const Params &p, const uint32_t (&row_words)[4], const float2 *vbuf, uchar4 *dst_a, uchar4 *dst_b,
+                                         bool have_a, bool have_b, const uint2 *pal, int tid)
+{
+    int i_row = 0;
+    for (uint32_t py = tid; py < p.R; py += 256, ++i_row) {
+        // a thread renders the same rows (tid + 256 i) of every column: their table words stay in registers (R <= 1024)
+        const uint32_t re = i_row == 0 ? row_words[0] : i_row == 1 ? row_words[1] : i_row == 2 ? row_words[2] : row_words[3];
+        const uint32_t first = re & 0xffffu, cnt = re >> 16;
+        float sl = 0.0f, sr = 0.0f;  // Complex::sum starts at zero
+        for (uint32_t i = 0; i < cnt; ++i) {
+            const float2 v = vbuf[first + i];
+            sl = sl + v.x;
+            sr = sr + v.y;
+        }
+        float l = sl, r = sr;
+        if (cnt > 1) {  // x / 1.0 == x: only rows that average several samples divide (:72)
+            const float nf = (float)cnt;
+            l = sl / nf;
+            r = sr / nf;
+        }
+        const uint32_t y = p.R - 1 - py;  // simple_spectrogram.rs:150
+        if (MONO) {  // mono -> (s, s): both channels carry the same magnitude
+            if (have_a) dst_a[y] = pixel_for(p, l, l, pal);
+            if (have_b) dst_b[y] = pixel_for(p, r, r, pal);
+        } else {
+            dst_a[y] = pixel_for(p, l, r, pal);
+        }
+    }
+}
+
+// the same row as IEEE half pairs (round to nearest even): bin k at byte 4 k of rowm4
+template <bool DUP>
+__device__ __forceinline__ void store_row_f16(char *mags, long long row_byte, int col, const float (&va)[8], const float (&vb)[8])
+{
+    const __amdgpu_buffer_rsrc_t r = row_rsrc(mags, row_byte);
+    const int lane_off = col * 4;
+#pragma unroll
+    for (int q3 = 0; q3 < 8; ++q3)
+        if (q3 > 0 || col != 0) {
+            const __half2 h = __floats2half2_rn(va[q3], DUP ? va[q3] : vb[q3]);
+            __builtin_amdgcn_raw_buffer_store_b32(*reinterpret_cast<const uint32_t *>(&h), r, lane_off + 1024 * (q3 & 3), 4096 * (q3 >> 2), 0);
+        }
+}
+
+}  // namespace wg
+}  // namespace sgx
