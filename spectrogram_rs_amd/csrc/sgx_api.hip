@@ -235,6 +235,9 @@ hipError_t run_stft(const sgx_ctx *c, const float *d_pcm, uint32_t channels, uin
     if (c->stft_kernel == 4 && c->d_chz) return sgx::launch_stft_chirpz(c, c->d_chz, d_pcm, channels, pairs, first, n, total, d_mags);
     if (c->stft_kernel == 4) return sgx::launch_stft_bluestein(c, c->d_blu, d_pcm, channels, pairs, first, n, total, d_mags);
     if (c->stft_kernel == 3) return sgx::launch_stft_wgp4096(c, c->d_fast_wg, d_pcm, channels, pairs, first, n, total, d_mags);
+    if (c->stft_kernel == 2 && c->d_real && (c->cfg.flags & SGX_FLAG_INDEPENDENT_FRAMES) && !(c->cfg.flags & SGX_FLAG_COMPLEX_MONO)
+        && sgx::real4096_serves(c, d_pcm, channels))
+        return sgx::launch_stft_real4096(c, c->d_real, d_pcm, first, n, total, d_mags, false);
     if (c->stft_kernel == 2) return sgx::launch_stft_wg4096(c, c->d_fast_wg, d_pcm, channels, pairs, first, n, total, d_mags);
     if (c->stft_kernel == 1) return sgx::launch_stft_fast4096(c, d_pcm, channels, pairs, first, n, total, d_mags);
     return sgx::launch_stft_generic(c, d_pcm, channels, pairs, first, n, total, d_mags);
@@ -383,6 +386,10 @@ int sgx_create(const sgx_config *cfg, sgx_ctx **out_ctx)
         if (e != hipSuccess) return bail(SGX_ERR_HIP, std::string("sgx_create: tuned kernel tables: ") + hipGetErrorString(e));
         e = sgx::wg4096_init(c, &c->d_fast_wg);
         if (e != hipSuccess) return bail(SGX_ERR_HIP, std::string("sgx_create: tuned kernel tables: ") + hipGetErrorString(e));
+        if (c->C == 1 && c->H == 256) {
+            e = sgx::real4096_init(c, &c->d_real);
+            if (e != hipSuccess) return bail(SGX_ERR_HIP, std::string("sgx_create: real-input kernel tables: ") + hipGetErrorString(e));
+        }
         c->stft_kernel = (cfg->flags & SGX_FLAG_WAVE_KERNEL) ? 1 : ((cfg->flags & SGX_FLAG_PACKED_KERNEL) ? 3 : 2);
     } else if (!(cfg->flags & SGX_FLAG_FORCE_GENERIC) && (cfg->flags & SGX_FLAG_LEGACY_16K) && sgx::wg16384_supported(c)) {
         e = sgx::wg16384_init(c, &c->d_fast_16k);
@@ -410,6 +417,8 @@ void sgx_destroy(sgx_ctx *c)
     sgx::fast4096_destroy(c);
     sgx::wg4096_destroy(c->d_fast_wg);
     c->d_fast_wg = nullptr;
+    sgx::real4096_destroy(c->d_real);
+    c->d_real = nullptr;
     sgx::bluestein_destroy(c->d_blu);
     c->d_blu = nullptr;
     sgx::mixed_destroy(c->d_mix);
@@ -451,6 +460,7 @@ int sgx_query(const sgx_ctx *c, sgx_info *out)
     if ((c->stft_kernel == 2 || c->stft_kernel == 3) && !(c->cfg.flags & SGX_FLAG_NO_FUSED_RENDER) && sgx::wg4096_can_fuse_render(c, c->d_fast_wg))
         out->render_path = 1u | (sgx::wg4096_seed_is_within_one(c) ? 2u : 0u);
     if ((c->stft_kernel == 6 || c->stft_kernel == 9) && sgx::mixed_fixed_plan(c->d_mix)) out->render_path |= 4u;
+    if (c->stft_kernel == 2 && c->d_real && (c->cfg.flags & SGX_FLAG_INDEPENDENT_FRAMES) && !(c->cfg.flags & SGX_FLAG_COMPLEX_MONO)) out->render_path |= 8u;
     if (c->stft_kernel == 4 && c->d_chz) out->render_path |= 4u;
     if ((c->stft_kernel == 6 || c->stft_kernel == 9) && !(c->cfg.flags & SGX_FLAG_NO_FUSED_RENDER) && sgx::mixed_can_fuse_render(c, c->d_mix)) out->render_path |= 3u;
     out->mags_bytes_per_frame = (uint64_t)c->pairs * c->M * 2 * sizeof(float);
@@ -507,7 +517,11 @@ int sgx_stft_batch_f16(sgx_ctx *c, const float *d_pcm, size_t n_samples, size_t 
     if (n > max_frames) n = max_frames;
     if (!d_pcm || !d_mags_f16) return fail(c, SGX_ERR_INVALID_ARG, "sgx_stft_batch_f16: null buffer");
     SGX_HIP(c, hipSetDevice(c->device));
-    if (c->stft_kernel == 2) {
+    if (c->stft_kernel == 2 && c->d_real && (c->cfg.flags & SGX_FLAG_INDEPENDENT_FRAMES) && !(c->cfg.flags & SGX_FLAG_COMPLEX_MONO)
+        && sgx::real4096_serves(c, d_pcm, c->C)) {
+        hipError_t e = sgx::launch_stft_real4096(c, c->d_real, d_pcm, first_frame, n, total, d_mags_f16, true);
+        if (e != hipSuccess) return fail_hip(c, e, "sgx_stft_batch_f16: kernel launch");
+    } else if (c->stft_kernel == 2) {
         hipError_t e = sgx::launch_stft_wg4096_f16(c, c->d_fast_wg, d_pcm, c->C, c->pairs, first_frame, n, total, d_mags_f16);
         if (e != hipSuccess) return fail_hip(c, e, "sgx_stft_batch_f16: kernel launch");
     } else if (c->stft_kernel == 9 && c->C <= 2) {

@@ -104,6 +104,7 @@ struct sgx_ctx {
     void *d_blu = nullptr;         // tables of the Bluestein (non-power-of-two) kernel
     void *d_mix = nullptr;         // tables of the mixed-radix (2, 3, 5, 7-smooth lengths) kernel
     void *d_w4800 = nullptr;       // tables of the tuned 4800-point kernel (W = 2400: the application's window at 48 kHz)
+    void *d_real = nullptr;        // tables of the real-input 4096-point kernel (independent mono frames at W 2048 / H 256)
     void *d_chz = nullptr;         // chirp-z through the mixed-radix kernel's stages (or null: the radix-4 ladder of stft_bluestein.hip)
     void *d_fast_16k = nullptr;    // tables of the 16384-point kernel, first design (one 1024-thread workgroup per transform)
     void *d_q16k = nullptr;        // tables of the 16384-point kernel, four 4096-point residues of the output (SGX_FLAG_RESIDUE_16K)
@@ -192,6 +193,12 @@ hipError_t launch_stft_q16384(const sgx_ctx *c, void *tables, const float *d_pcm
                               size_t first_frame, size_t n_frames, size_t total_frames, float *d_mags);
 // W = 2400 (48 kHz x 0.05 s): persistent 320-thread workgroups, 16 x 20 x 15 (stft4800_wg.hip); rows and half rows of one or two channels -- more
 // channels and the fused PCM-to-pixel path go to the composite-radix kernel, whose tables such a context carries too
+// stft4096_real.hip: independent mono frames at W 2048 / H 256 as 2048-point complex transforms of the real frame
+hipError_t real4096_init(sgx_ctx *c, void **out);
+void real4096_destroy(void *tables);
+bool real4096_serves(const sgx_ctx *c, const float *d_pcm, uint32_t channels);
+hipError_t launch_stft_real4096(const sgx_ctx *c, const void *tables, const float *d_pcm, size_t first_frame, size_t n_frames,
+                                size_t total_frames, void *d_mags, bool out_f16);
 bool w4800_supported(const sgx_ctx *c);
 hipError_t w4800_init(sgx_ctx *c, void **out);
 void w4800_destroy(void *tables);

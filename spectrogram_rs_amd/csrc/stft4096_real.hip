@@ -1,0 +1,384 @@
+// stft4096_real.hip -- K1R: a mono stream at W = 2048 / H = 256 with EVERY frame its own transform, at the price of half a transform.
+//
+// The reference duplicates a mono sample into (s, s) and runs one 4096-point complex transform per frame
+// (audio_input_list_model.rs:67-69, fft.rs:47-99): F = (1 + i) S with S the spectrum of the real windowed frame, and both output
+// columns are |S[k]| 2 / W (fft.rs:81-98).  The headline kernel (stft4096_wg.hip) halves that work by packing frames 2j and 2j+1
+// into the real and imaginary part of ONE transform -- and pays with a shared rounding floor: the quieter frame of a pair carries
+// the louder one's float32 noise (tests/test_gpu_parity.py::test_onsets_*).  This kernel halves the work the other way: the
+// 4096-point spectrum of a REAL sequence is a 2048-point complex transform of z[m] = x[2m] + i x[2m+1] plus one butterfly per bin,
+//
+//     S[k]        = E[k] + w_4096^k O[k],          E[k] = (Z[k] + conj Z[2048-k]) / 2,   O[k] = (Z[k] - conj Z[2048-k]) / 2i
+//     S[2048 - k] = conj(E[k] - w_4096^k O[k]),    k = 0 .. 1023   (+ the self-paired k = 1024)
+//
+// so every frame is transformed on its own -- the reference's dataflow, north_star's tolerance against the frame's OWN peak on any
+// input -- for the arithmetic of half a 4096-point transform.  Two frames share a workgroup only as two independent problems.
+//
+// Shape: K1's, so that K1's measured choices carry over (256 threads, three in-register passes, two LDS exchanges of one padded
+// 34 816-byte image, partner exchange, persistent workgroups, four per CU, the same wave priorities).  A workgroup iteration does
+// frames fa = first + 2 job (A) and fa + 1 (B), 2048 points each (zero padding: only m < 1024 is non-zero, never materialised):
+//
+//   sample index  m = t + 256 a            (a < 4 non-zero rows; x[2m], x[2m+1] arrive as ONE 8-byte load per lane)
+//   pass 1  thread t, BOTH frames : 8-point DFT over a with 4 non-zero inputs = two 4-point FFTs -> q1; twiddle w_2048^{t q1}
+//   pass 2  thread (F, q1, t0)    : t = t0 + 16 t1; 16-point FFT over t1 -> q2; twiddle w_256^{t0 q2} (K1's LDS table)
+//   pass 3  thread (F, u = q1 + 8 q2): 16-point FFT over t0 -> q3;  Z_F[k], k = u + 128 q3
+//   untangle  Z[k] with Z[2048-k] (thread 128 - u, register 15 - q3, through LDS as K1's split) -> |S[k]|, |S[2048-k]|:
+//           every thread stores 16 bins of its frame's row, 8 ascending and 8 descending runs of 512 contiguous bytes per wave
+//
+// H = 256 = HALF a row of z.  With c[i] = (x[2i], x[2i+1]) the stream as 8-byte columns, frame f reads c[128 f + t + 256 a]: a thread's
+// eight rows of a frame pair are R[j] = c[128 fa + t + 128 j], j = 0 .. 7 (even j: frame A, odd j: frame B), and the next pair's are
+// R[j + 2]: the window slides in registers.  Of the two new values R[9] = c[128 fa + 1152 + t] is the thread's own load (ONE 8-byte
+// load per thread and iteration, requested a whole iteration ahead, in front of the stores); R[8] = c[128 fa + 1024 + t] is what
+// thread t - 128 loads in this iteration (t >= 128) or what thread t + 128 loaded in the previous one (t < 128): it crosses the
+// workgroup through 2 KB of LDS beside the partner exchange (same barrier).  Every sample is fetched from memory exactly once.
+// (The first version let both frames slide on their own and fetched every sample twice; the output stream keeps evicting the
+// input from L2, the second fetch went to HBM, and the launch took exactly the 5.9 % longer that 18 424 B / frame are more than
+// 17 400: 3.72 ms per 1e6 frames against the paired kernel's 3.50.)
+#include <cmath>
+
+#include "stft4096_wg.hpp"
+
+namespace sgx {
+
+namespace wgr {
+
+using wg::kBufComplex;
+using wg::kLdsBytes;
+using wg::kM;
+using wg::kS1;
+using wg::kS2;
+using wg::kW;
+using wg::lds_barrier;
+using wg::pcm_rsrc;
+using wg::u32x2;
+
+typedef float f2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float cl_fma(float a, float c, float u) { return fmaf(a, c, u); }
+__device__ __forceinline__ f2v cl_fma(f2v a, float c, f2v u) { return __builtin_elementwise_fma(a, f2v{c, c}, u); }
+
+#include "fft_codelets.inc"
+
+struct Params {
+    const float *pcm;
+    const float2 *tw1;    // [8][256]   w_2048^{t q1}
+    const float2 *tw2;    // [16][16]   w_256^{t0 q2} at [q2][t0]   (K1's table)
+    const float2 *twu;    // [8][128]   w_4096^{u + 128 q3} at [q3][u]; [0][0] holds w_4096^{1024} = -i (thread 0 does bin 1024 in its q3 = 0 slot)
+    const float *window;  // [2048]
+    void *mags;           // [F][1][M][2] float, or the same as half pairs
+    unsigned long long first_frame, n_frames, n_samples, n_jobs, jobs_per_block;
+};
+
+__device__ __forceinline__ float2 cmulf(float2 a, float2 b)
+{
+    return make_float2(fmaf(a.x, b.x, -(a.y * b.y)), fmaf(a.x, b.y, a.y * b.x));
+}
+
+// a raw buffer descriptor over one output row (uniform base); `present` false: zero records, every store through it is dropped by
+// the range check -- a frame outside the requested range costs no branch in the store section
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t out_rsrc(char *base, long long byte, bool present)
+{
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)byte);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)((unsigned long long)byte >> 32));
+    const int records = __builtin_amdgcn_readfirstlane(present ? 0x7fffffff : 0);
+    return __builtin_amdgcn_make_buffer_rsrc(base + (long long)(((unsigned long long)hi << 32) | lo), 0, records, 0x00020000);
+}
+
+// 8-point forward DFT of (z0, z1, z2, z3, 0, 0, 0, 0): even bins = FFT4(z), odd bins = FFT4(z_a w_8^a); bin q1 in (yr, yi)[q1]
+__device__ __forceinline__ void fft8_half_zero(const float (&zr)[4], const float (&zi)[4], float (&yr)[8], float (&yi)[8])
+{
+    constexpr float kH = 0.70710678118654752440f;
+    auto fft4 = [](float a0r, float a0i, float a1r, float a1i, float a2r, float a2i, float a3r, float a3i, float *outr, float *outi) {
+        const float s0r = a0r + a2r, s0i = a0i + a2i, s1r = a0r - a2r, s1i = a0i - a2i;
+        const float s2r = a1r + a3r, s2i = a1i + a3i, s3r = a1r - a3r, s3i = a1i - a3i;
+        outr[0] = s0r + s2r; outi[0] = s0i + s2i;          // bin 0
+        outr[4] = s0r - s2r; outi[4] = s0i - s2i;          // bin 2
+        outr[2] = s1r + s3i; outi[2] = s1i - s3r;          // bin 1: s1 - i s3
+        outr[6] = s1r - s3i; outi[6] = s1i + s3r;          // bin 3: s1 + i s3
+    };
+    fft4(zr[0], zi[0], zr[1], zi[1], zr[2], zi[2], zr[3], zi[3], yr, yi);                       // even q1 at [0], [2], [4], [6]
+    const float y1r = (zr[1] + zi[1]) * kH, y1i = (zi[1] - zr[1]) * kH;                          // z1 (1 - i) / sqrt 2
+    const float y3r = (zi[3] - zr[3]) * kH, y3i = -(zr[3] + zi[3]) * kH;                         // z3 (-1 - i) / sqrt 2
+    fft4(zr[0], zi[0], y1r, y1i, zi[2], -zr[2], y3r, y3i, yr + 1, yi + 1);                       // odd q1 at [1], [3], [5], [7]
+}
+
+template <bool F16>
+__global__ void __launch_bounds__(256, 4) stft4096_real_kernel(Params p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2 *buf = reinterpret_cast<float2 *>(smem_raw);
+    float2 *tw2 = buf + kBufComplex;
+
+    const int tid = threadIdx.x;
+    tw2[tid] = p.tw2[tid];
+
+    // per-thread constants, resident for the life of the (persistent) workgroup
+    // the output scale |S| 2 / W rides on the window as 1 / 2048 (the untangle's two halves and 2 / W = 1 / 1024): a power of two
+    // commutes with every rounding below
+    float win[8];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        win[2 * a] = p.window[2 * tid + 512 * a] * (1.0f / 2048.0f);
+        win[2 * a + 1] = p.window[2 * tid + 512 * a + 1] * (1.0f / 2048.0f);
+    }
+    float2 tw1[8];
+#pragma unroll
+    for (int q = 1; q < 8; ++q) tw1[q] = p.tw1[q * 256 + tid];
+    const int F = tid >> 7, u = tid & 127;        // pass-3 / output role: frame of the pair, bins u + 128 q3
+    float2 twu[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) twu[q] = p.twu[q * 128 + u];
+    const int g2 = tid >> 4, t0_2 = tid & 15;      // pass-2 role: g2 = 8 F + q1
+    const int cbase2 = (g2 >> 3) * 128 + (g2 & 7); // its image-2 column is cbase2 + 8 q2
+    __syncthreads();
+
+    const unsigned long long job_begin = (unsigned long long)blockIdx.x * p.jobs_per_block;
+    unsigned long long job_end = job_begin + p.jobs_per_block;
+    if (job_end > p.n_jobs) job_end = p.n_jobs;
+    if (job_begin >= job_end) return;
+
+    // Columns from `col0` of the stream on, as a raw buffer (uniform base + one 32-bit lane offset); its record count is what the
+    // stream still holds from there, so a column past the end reads as zero: a pair's second frame that the stream does not hold, or
+    // the rows requested ahead at the end of a run, need no branch (their results are never stored).
+    auto columns_from = [&](unsigned long long col0) {
+        const unsigned long long first = 2 * col0;                           // sample index
+        const unsigned long long left = first < p.n_samples ? (p.n_samples - first) * 4 : 0;
+        const unsigned long long addr = (unsigned long long)(p.pcm + (first < p.n_samples ? first : 0));
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)addr), hi = __builtin_amdgcn_readfirstlane((uint32_t)(addr >> 32));
+        const int records = __builtin_amdgcn_readfirstlane((int)(left < 0x7fffffffull ? left : 0x7fffffffull));
+        return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((unsigned long long)hi << 32) | lo), 0, records, 0x00020000);
+    };
+    auto column = [&](__amdgpu_buffer_rsrc_t r, int byte_offset) {
+        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, tid * 8, byte_offset, 0);
+        return make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
+    };
+    float2 R[8];        // R[j] = c[128 fa + tid + 128 j]: rows a = j / 2 of frame A (even j) and frame B (odd j)
+    float2 carry, L;    // carry (tid < 128): the next R[6], read from LDS one iteration early; L: the next R[7], in flight
+    {
+        const __amdgpu_buffer_rsrc_t r0 = columns_from(128 * (p.first_frame + 2 * job_begin));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) R[j] = column(r0, 1024 * j);
+        carry = column(r0, 8192);     // c[128 fa + 1024 + tid]
+        L = column(r0, 9216);         // c[128 fa + 1152 + tid]
+    }
+    float2 *xch = buf + 2304;         // [256] the iteration's loads, beside the partner rows (image 2 is dead by then)
+
+    char *out = reinterpret_cast<char *>(p.mags);
+    constexpr int kBin = F16 ? 4 : 8;             // bytes per output bin
+    for (unsigned long long job = job_begin; job < job_end; ++job) {
+        const unsigned long long fa = p.first_frame + 2 * job;             // frame A; B = fa + 1
+        const unsigned long long la = 2 * job, lb = la + 1;                // their rows in the output
+        const bool have_b = lb < p.n_frames;                                // (a B outside the range is computed and dropped)
+
+        // ---- Hann (fft.rs:53-63) and pass 1 for both frames
+        float yr[8], yi[8];
+        {
+            float zr[4], zi[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) { zr[a] = R[2 * a].x * win[2 * a]; zi[a] = R[2 * a].y * win[2 * a + 1]; }
+            fft8_half_zero(zr, zi, yr, yi);
+        }
+        float vr[8], vi[8];
+        {
+            float zr[4], zi[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) { zr[a] = R[2 * a + 1].x * win[2 * a]; zi[a] = R[2 * a + 1].y * win[2 * a + 1]; }
+            fft8_half_zero(zr, zi, vr, vi);
+        }
+        lds_barrier();  // the previous iteration's partner reads are complete
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float2 ya = make_float2(yr[q], yi[q]), yb = make_float2(vr[q], vi[q]);
+            buf[q * kS1 + tid] = q == 0 ? ya : cmulf(ya, tw1[q]);
+            buf[(8 + q) * kS1 + tid] = q == 0 ? yb : cmulf(yb, tw1[q]);
+        }
+        __builtin_amdgcn_s_setprio(0);  // (wave priorities: stft4096_wg.hip)
+        lds_barrier();
+
+        // ---- pass 2: thread (g2 = 8 F + q1, t0): 16-point FFT over t1, then twiddle w_256^{t0 q2}
+        float xr[16], xi[16];
+#pragma unroll
+        for (int t1 = 0; t1 < 16; ++t1) {
+            const float2 v = buf[g2 * kS1 + t0_2 + 16 * t1];
+            xr[t1] = v.x; xi[t1] = v.y;
+        }
+        fft16(xr, xi);
+        lds_barrier();  // everyone has read image 1
+#pragma unroll
+        for (int q2 = 0; q2 < 16; ++q2) {
+            const int pos = FFT16_OUT[q2];
+            const float2 v = make_float2(xr[pos], xi[pos]);
+            buf[t0_2 * kS2 + cbase2 + 8 * q2] = q2 == 0 ? v : cmulf(v, tw2[q2 * 16 + t0_2]);
+        }
+        lds_barrier();
+
+        // ---- pass 3: thread (F, u): 16-point FFT over t0 -> Z[u + 128 q3]
+#pragma unroll
+        for (int t0 = 0; t0 < 16; ++t0) {
+            const float2 v = buf[t0 * kS2 + tid];
+            xr[t0] = v.x; xi[t0] = v.y;
+        }
+        fft16(xr, xi);
+
+        // the load of the NEXT iteration (its R[9]), ahead of this iteration's stores (vmcnt retires in issue order) and a whole
+        // iteration ahead of its use.  Unconditional (a conditional request keeps the old value alive around the loop); past the end
+        // of the stream it reads zeros.
+        const float2 Ln = column(columns_from(128 * (fa + 2) + 1152), 0);
+
+        __builtin_amdgcn_s_setprio(3);
+        lds_barrier();  // everyone has read image 2
+        // partner exchange: publish q3 = 8..15
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int pos = FFT16_OUT[8 + j];
+            buf[j * 256 + tid] = make_float2(xr[pos], xi[pos]);
+        }
+        xch[tid] = L;   // this iteration's load (requested one iteration ago) for the threads half a row away
+        lds_barrier();
+        const float2 Y = xch[(tid + 128) & 255];   // tid >= 128: the next R[6]; tid < 128: the R[6] after that
+
+        // ---- untangle + magnitude: bins k = u + 128 q3 and 2048 - k.  Z[2048 - k] is register 15 - q3 of thread 128 - u (row 7 - q3);
+        // thread 0 holds its own partners one row up (register 16 - q3), and spends its q3 = 0 slot -- DC and Nyquist are not outputs
+        // (fft.rs:81) -- on the self-paired bin 1024: Z = P = its register 8, twiddle -i (twu[0][0])
+        const int pcol = F * 128 + (u == 0 ? 256 : 128 - u);
+        float m1[8], m2[8];
+#pragma unroll
+        for (int q3 = 0; q3 < 8; ++q3) {
+            const int pos = FFT16_OUT[q3];
+            float zr_ = xr[pos], zi_ = xi[pos];
+            float2 pv = buf[(7 - q3) * 256 + pcol];
+            if (q3 == 0) {
+                const float2 own = buf[F * 128];              // thread 0 of the frame: its register 8 as published
+                const int p8 = FFT16_OUT[8];
+                zr_ = u == 0 ? xr[p8] : zr_; zi_ = u == 0 ? xi[p8] : zi_;
+                pv.x = u == 0 ? own.x : pv.x; pv.y = u == 0 ? own.y : pv.y;
+            }
+            const float er = zr_ + pv.x, ei = zi_ - pv.y;    // Z + conj P   = 2 E
+            const float orr = zi_ + pv.y, oi = pv.x - zr_;    // -i (Z - conj P) = 2 O
+            const float wr = fmaf(twu[q3].x, orr, -(twu[q3].y * oi)), wi = fmaf(twu[q3].x, oi, twu[q3].y * orr);
+            const float ar = er + wr, ai = ei + wi, br = er - wr, bi = ei - wi;
+            m1[q3] = __builtin_amdgcn_sqrtf(fmaf(ar, ar, ai * ai));   // |S[k]| 2 / W      (the scale rides on the window)
+            m2[q3] = __builtin_amdgcn_sqrtf(fmaf(br, br, bi * bi));   // |S[2048 - k]| 2 / W
+        }
+
+        // ---- store row [M][2] (or half pairs): bin k at byte kBin (k - 1).  Straight-line code: the wait for the prefetched rows below
+        // is then vmcnt(stores issued since).  Thread 0's q3 = 0 slot: bin 1024 from m1, and a second copy of it where its m2 would go.
+        {
+            const long long row = (long long)(F == 0 ? la : lb) * (long long)kM * kBin - kBin;      // byte of the (absent) bin 0
+            const __amdgpu_buffer_rsrc_t r = out_rsrc(out, row, F == 0 || have_b);
+            const int l1 = kBin * u, l2 = kBin * (1152 - u);                                        // bins u + 128 q3 ; 2048 - u - 128 q3 = (1152 - u) + 128 (7 - q3)
+#pragma unroll
+            for (int q3 = 0; q3 < 8; ++q3) {
+                const float a = m1[q3], b = (q3 == 0 && u == 0) ? m1[0] : m2[q3];
+                const int o1 = (q3 == 0 && u == 0) ? kBin * 1024 : l1;
+                const int o2 = (q3 == 0 && u == 0) ? kBin * 128 : l2;                               // 128 + 128 * 7 = 1024
+                const int s1 = kBin * 128 * q3, s2 = kBin * 128 * (7 - q3);
+                if (F16) {
+                    const __half2 ha = __floats2half2_rn(a, a), hb = __floats2half2_rn(b, b);
+                    __builtin_amdgcn_raw_buffer_store_b32(*reinterpret_cast<const uint32_t *>(&ha), r, o1 + (s1 & 2047), s1 & ~2047, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(*reinterpret_cast<const uint32_t *>(&hb), r, o2 + (s2 & 2047), s2 & ~2047, 0);
+                } else {
+                    __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(a), __float_as_uint(a)}, r, o1 + (s1 & 2047), s1 & ~2047, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(b), __float_as_uint(b)}, r, o2 + (s2 & 2047), s2 & ~2047, 0);
+                }
+            }
+        }
+        // ---- slide the window by two half rows
+#pragma unroll
+        for (int j = 0; j < 6; ++j) R[j] = R[j + 2];
+        R[6].x = tid >= 128 ? Y.x : carry.x;
+        R[6].y = tid >= 128 ? Y.y : carry.y;
+        carry = Y;
+        R[7] = L;
+        L = Ln;
+    }
+}
+
+struct RealTables {
+    float2 *d_tw1 = nullptr, *d_tw2 = nullptr, *d_twu = nullptr;
+};
+
+}  // namespace wgr
+
+hipError_t real4096_init(sgx_ctx *c, void **out)
+{
+    using namespace wgr;
+    (void)c;
+    auto *t = new RealTables();
+    auto unit = [](unsigned long long e, unsigned long long n) {   // e^{-2 pi i e / n}, exact on the axes
+        e %= n;
+        if (e == 0) return make_float2(1.0f, 0.0f);
+        if (4 * e == n) return make_float2(0.0f, -1.0f);
+        if (2 * e == n) return make_float2(-1.0f, 0.0f);
+        if (4 * e == 3 * n) return make_float2(0.0f, 1.0f);
+        const double ang = -2.0 * M_PI * (double)e / (double)n;
+        return make_float2((float)cos(ang), (float)sin(ang));
+    };
+    std::vector<float2> tw1(8 * 256), tw2(256), twu(8 * 128);
+    for (int q = 0; q < 8; ++q)
+        for (int tt = 0; tt < 256; ++tt) tw1[q * 256 + tt] = unit((unsigned long long)tt * q, 2048);
+    for (int q = 0; q < 16; ++q)
+        for (int t0 = 0; t0 < 16; ++t0) tw2[q * 16 + t0] = unit((unsigned long long)t0 * q, 256);
+    for (int q3 = 0; q3 < 8; ++q3)
+        for (int uu = 0; uu < 128; ++uu) twu[q3 * 128 + uu] = unit((unsigned long long)(uu + 128 * q3), 4096);
+    twu[0] = unit(1024, 4096);   // thread 0, q3 = 0: the self-paired bin 1024
+    auto up = [](float2 **dst, const std::vector<float2> &v) {
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(dst), v.size() * sizeof(float2));
+        if (e == hipSuccess) e = hipMemcpy(*dst, v.data(), v.size() * sizeof(float2), hipMemcpyHostToDevice);
+        return e;
+    };
+    hipError_t e = up(&t->d_tw1, tw1);
+    if (e == hipSuccess) e = up(&t->d_tw2, tw2);
+    if (e == hipSuccess) e = up(&t->d_twu, twu);
+    if (e != hipSuccess) {
+        real4096_destroy(t);
+        return e;
+    }
+    *out = t;
+    return hipSuccess;
+}
+
+void real4096_destroy(void *tables)
+{
+    auto *t = static_cast<wgr::RealTables *>(tables);
+    if (!t) return;
+    if (t->d_tw1) (void)hipFree(t->d_tw1);
+    if (t->d_tw2) (void)hipFree(t->d_tw2);
+    if (t->d_twu) (void)hipFree(t->d_twu);
+    delete t;
+}
+
+// the streams this kernel serves: one channel, W = 2048, H = 256, every frame start 8-byte aligned (rows arrive as float2)
+bool real4096_serves(const sgx_ctx *c, const float *d_pcm, uint32_t channels)
+{
+    return channels == 1 && c->W == (uint32_t)wgr::kW && c->H == 256 && (reinterpret_cast<uintptr_t>(d_pcm) & 7u) == 0;
+}
+
+hipError_t launch_stft_real4096(const sgx_ctx *c, const void *tables, const float *d_pcm, size_t first_frame, size_t n_frames,
+                                size_t total_frames, void *d_mags, bool out_f16)
+{
+    using namespace wgr;
+    if (n_frames == 0) return hipSuccess;
+    const auto *t = static_cast<const RealTables *>(tables);
+    Params p{};
+    p.pcm = d_pcm;
+    p.tw1 = t->d_tw1;
+    p.tw2 = t->d_tw2;
+    p.twu = t->d_twu;
+    p.window = c->d_window;
+    // rows are written relative to the call's first frame
+    p.mags = d_mags;
+    p.first_frame = first_frame;
+    p.n_frames = n_frames;
+    p.n_samples = total_frames ? (total_frames - 1) * 256ull + (unsigned long long)kW : 0;   // what the frames of the stream cover (the caller may hold a few more)
+    p.n_jobs = (n_frames + 1) / 2;
+    unsigned long long blocks = (unsigned long long)c->n_cu * 4;   // persistent workgroups, four per CU, each a contiguous run of frame pairs
+    unsigned long long per = (p.n_jobs + blocks - 1) / blocks;
+    if (per < 1) per = 1;
+    blocks = (p.n_jobs + per - 1) / per;
+    p.jobs_per_block = per;
+    const dim3 grid((unsigned)blocks), block(256);
+    if (out_f16) hipLaunchKernelGGL((stft4096_real_kernel<true>), grid, block, kLdsBytes, c->stream, p);
+    else hipLaunchKernelGGL((stft4096_real_kernel<false>), grid, block, kLdsBytes, c->stream, p);
+    return hipGetLastError();
+}
+
+}  // namespace sgx

@@ -900,6 +900,49 @@ def test_frame_pairing_dynamic_range_and_independent_frames(torch_cuda, mags_err
     assert np.abs(paired[1] - ref[1]).max() <= 1e-6 * pair_peak
 
 
+@pytest.mark.parametrize("n_frames", [1, 2, 3, 64, 131, 2051])
+def test_real_input_kernel_for_independent_mono_frames(torch_cuda, mags_err, n_frames):
+    # SGX_FLAG_INDEPENDENT_FRAMES at W 2048 / H 256 (the headline's stream shape): every mono frame is its own transform -- the
+    # reference's (s, s) dataflow, audio_input_list_model.rs:67-69 + fft.rs:47-99 -- computed as a 2048-point complex transform of
+    # the real frame + one butterfly per bin (csrc/stft4096_real.hip).  Against the float64 truth (1 x), the float32 oracle (2 x),
+    # the literal (s, s) transform (SGX_FLAG_COMPLEX_MONO) and itself over sub-ranges, odd counts and a misaligned stream.
+    torch = torch_cuda
+    n = W + (n_frames - 1) * H + 77
+    pcm = oracle.white_noise(n, seed=1000 + n_frames)
+    pcm[: min(n, 5000)] *= np.float32(0.01)                 # a level step inside the stream: frames of very different peaks
+    dev = to_dev(torch, pcm)
+    real = engine(window_samples=W, hop_samples=H, channels=1, independent_frames=True)
+    cplx = engine(window_samples=W, hop_samples=H, channels=1, independent_frames=True, complex_mono=True)
+    assert real.info.stft_kernel == 2 and real.info.render_path & 8 and not (cplx.info.render_path & 8)
+    got = real.stft_batch(dev).cpu().numpy()
+    assert got.shape == (n_frames, 1, M, 2)
+    pick = sorted(set(list(range(min(n_frames, 24))) + [n_frames - 1, n_frames // 2] + list(range(0, n_frames, 97))))
+    truth = np.stack([oracle.np_truth_frame(np.stack([pcm[t * H:t * H + W]] * 2, 1), W) for t in pick])
+    assert mags_err(got[pick, 0], truth) <= 1.0              # own-peak tolerance, every checked frame
+    assert np.array_equal(got[..., 0], got[..., 1])          # (m, m): one spectrum, written twice
+    ref32 = oracle.stream_process(pcm, 1, W, H, threads=8)
+    assert mags_err(got, ref32) <= 2.0
+    assert mags_err(got, cplx.stft_batch(dev).cpu().numpy().astype(np.float64)) <= 2.0
+    # frames are independent problems: any sub-range, from an odd first frame too, writes the bytes of the full run
+    for first, cnt in ((0, 1), (1, 1), (1, 2), (2, 5), (n_frames - 1, 1), (n_frames // 2, n_frames)):
+        if first >= n_frames:
+            continue
+        part = real.stft_batch(dev, first_frame=first, max_frames=cnt).cpu().numpy()
+        assert np.array_equal(part, got[first:first + cnt]), (first, cnt)
+    # half rows straight from the kernel = the float rows rounded to nearest even
+    h = real.stft_batch_f16(dev)
+    assert torch.equal(h, torch.from_numpy(got).cuda().to(torch.float16))
+    assert torch.equal(real.stft_batch_f16(dev, first_frame=1, max_frames=3), h[1:4])
+    # a stream that is 4- but not 8-byte aligned cannot be read as float2 rows: the (s, s) kernel takes it, same tolerance
+    shifted = torch.empty(dev.numel() + 1, dtype=dev.dtype, device=dev.device)
+    shifted[1:] = dev
+    assert shifted[1:].data_ptr() % 8 == 4
+    alt = real.stft_batch(shifted[1:]).cpu().numpy()
+    assert mags_err(alt[pick, 0], truth) <= 1.0
+    # determinism
+    assert np.array_equal(real.stft_batch(dev).cpu().numpy(), got)
+
+
 def _pair_error(x, ref, first_frame=0):
     """mags_error with the PAIR's peak (frames 2j, 2j+1 by global index) in place of the frame's own: the tolerance a mono
     frame meets when it shares its transform with its neighbour, as left and right do in the reference (fft.rs:57,87-88)"""
