@@ -32,9 +32,11 @@ Extra objects on the same line:
   config3      -- (N = 1) BASELINE config 3: the same stream -> RGBA pixel columns, with its own roofline
   config4      -- (N = 1) BASELINE config 4 at its own size: 16384-point, hop 512, 8 interleaved channels, 1e5 hop positions
                   (26 GB of output), with its own roofline
-  mono_independent_frames -- (N = 1) the headline stream with every mono frame as its own (s, s) transform
-                  (SGX_FLAG_INDEPENDENT_FRAMES): the reference's dataflow (audio_input_list_model.rs:67-69), what conformance
-                  to north_star's tolerance on EVERY input costs next to the headline's two-frames-per-transform mode
+  mono_paired_frames -- (N = 1) the headline stream with two frames per transform (SGX_FLAG_PAIRED_FRAMES), the headline mode of
+                  rounds 1-3.  The headline itself now runs the reference's dataflow -- every mono frame its own transform
+                  (audio_input_list_model.rs:67-69), as a real-input 2048-point transform (csrc/stft4096_real.hip) -- so that
+                  north_star's tolerance holds against every frame's OWN peak on any input; this leg says what that costs
+  mono_complex_frames -- (N = 1) the same stream with every frame as the literal (s, s) 4096-point transform (SGX_FLAG_COMPLEX_MONO)
   config5      -- (N > 1) BASELINE config 5: 1e8 frames frame-sharded over the ranks, PCM generated on device chunk by
                   chunk, pixel columns gathered to rank 0 over RCCL / xGMI, every piece consumed (checksummed) by the root
 """
@@ -65,6 +67,8 @@ KERNEL_NAMES = {
     1: ("stft4096 wave-per-transform", "sgx::stft4096_kernel<6, true>"),
     2: ("stft4096 workgroup-per-transform (256 threads x 16 points, radix-16 x3, mono frame pairs), scalar codelets",
         "sgx::wg::stft4096_wg_kernel<true, 0, false, false>"),
+    "real": ("stft4096 real-input: every mono frame its own transform, a 2048-point complex transform of the real frame + one butterfly per bin "
+             "(256 threads x 2 frames x 8 points, radix 8 x 16 x 16, sliding half-row window)", "sgx::wgr::stft4096_real_kernel<0, false>"),
     3: ("stft4096 workgroup-per-transform (256 threads x 16 points, radix-16 x3, mono frame pairs), packed (re, im) codelets",
         "sgx::wgp::stft4096_wgp_kernel<true, 0, false, false>"),
     5: ("stft16384 as four 4096-point residues (512 threads = 256 lane pairs, DPP decimation)", "sgx::q16k::stft16384_q_kernel<false, true>"),
@@ -85,7 +89,8 @@ def parse(argv=None):
     ap.add_argument("--placements", type=int, default=4, help="candidate allocations of the output buffer, timed hot and interleaved; another than the first is kept "
                                                               "only if it is faster by > 2 %% in BOTH passes (1 = take the first, no study)")
     ap.add_argument("--leg-sustain-s", type=float, default=1.0, help="seconds of back-to-back launches behind the burst of every side leg")
-    ap.add_argument("--independent-frames", type=int, default=1_000_000, help="N = 1: frames of the independent-mono-frames leg (0 = skip)")
+    ap.add_argument("--paired-frames", type=int, default=1_000_000, help="N = 1: frames of the two-frames-per-transform leg (0 = skip)")
+    ap.add_argument("--complex-frames", type=int, default=1_000_000, help="N = 1: frames of the (s, s)-transform-per-frame leg (0 = skip)")
     ap.add_argument("--sustain-s", type=float, default=3.0, help="seconds of back-to-back steps before the timed region (0 = skip)")
     ap.add_argument("--pixel-frames", type=int, default=1_000_000, help="N = 1: frames of the config-3 leg (0 = skip)")
     ap.add_argument("--config4-hops", type=int, default=100_000, help="N = 1: hop positions of the config-4 leg (BASELINE: 1e5 = 26 GB of output; 0 = skip)")
@@ -191,6 +196,13 @@ def load_profile_json(name):
         return d
     except Exception:
         return None
+
+
+def kernel_name(eng):
+    """(description, profiler name) of the transform kernel an engine's float rows come from"""
+    if eng.info.stft_kernel == 2 and eng.channels == 1 and eng.info.render_path & 8:
+        return KERNEL_NAMES["real"]
+    return KERNEL_NAMES.get(eng.info.stft_kernel, ("?", "?"))
 
 
 def stats_ms(v):
@@ -378,9 +390,9 @@ def main_rank(args):
             "config": {
                 "workload": f"configs[1]: batched 4096-pt Hann STFT, hop 256, {F} frames/GPU of counter-based white-noise mono PCM resident in HBM",
                 "window": W, "fft_length": 2 * W, "hop": H, "channels": 1, "frames_per_gpu": F,
-                "kernel": KERNEL_NAMES[eng.info.stft_kernel][0],
-                "mono_mode": "two frames per transform: frame 2j in the real part, 2j+1 in the imaginary part (the quieter frame of a pair inherits "
-                             "the louder one's rounding floor; `mono_independent_frames` is the reference's (s, s) dataflow)",
+                "kernel": kernel_name(eng)[0],
+                "mono_mode": "every frame its own transform (the reference's (s, s) dataflow, audio_input_list_model.rs:67-69; default flags)"
+                             if eng.info.render_path & 8 else "two frames per transform (frame 2j in the real part, 2j+1 in the imaginary part)",
                 "sharding": "contiguous frame ranges per rank, no data-path collective" if world > 1 else "single GPU",
                 "timed_region": f"{args.steps} steps after {args.warmup} warm-up steps, {args.steps} burst steps and {sustain_wall:.1f} s of back-to-back steps",
             },
@@ -391,7 +403,7 @@ def main_rank(args):
                 "frac_burst": frac_of(burst_ms), "frac_sustained": frac_of(sustained_ms),
                 "traffic": ((traffic or {}).get("stft_bytes_per_frame") or 0) * F or None,
                 "traffic_source": (traffic or {}).get("source"),
-                "kernel": KERNEL_NAMES[eng.info.stft_kernel][1],
+                "kernel": kernel_name(eng)[1],
                 "launch_ms": kernel_ms, "bytes_per_frame": ALGO_BYTES_STFT, "frames_per_launch": F,
                 "launch_ms_burst": stats_ms(burst), "launch_ms_sustained": stats_ms(steady),
                 "first_allocation": {"launch_ms": first_ms, "frac": frac_of(first_ms), "frames_per_s": F / (first_ms * 1e-3),
@@ -436,8 +448,14 @@ def main_rank(args):
             pcm = None
             if args.stereo_frames > 0:
                 extra["stereo4096"] = stereo_leg(args, torch, local_rank)
-            if args.independent_frames > 0:
-                extra["mono_independent_frames"] = independent_frames_leg(args, torch, local_rank)
+            if args.paired_frames > 0:
+                extra["mono_paired_frames"] = mono_mode_leg(args, torch, local_rank, args.paired_frames, dict(paired_frames=True),
+                                                            "two frames per transform (SGX_FLAG_PAIRED_FRAMES: the headline mode of rounds 1-3)",
+                                                            "sgx::wg::stft4096_wg_kernel<true, 0, false, false>")
+            if args.complex_frames > 0:
+                extra["mono_complex_frames"] = mono_mode_leg(args, torch, local_rank, args.complex_frames, dict(complex_mono=True),
+                                                             "every frame the literal (s, s) 4096-point transform (SGX_FLAG_COMPLEX_MONO; fft.rs:47-57)",
+                                                             "sgx::wg::stft4096_wg_kernel<false, 1, false, false>")
             if args.app_frames > 0:
                 extra["app_point"] = app_point_leg(args, torch, local_rank)
         elif args.config5_frames > 0:
@@ -598,8 +616,18 @@ def config3_leg(args, torch, eng, pcm, F):
         eng3.close()
     except Exception as e:  # noqa: BLE001 -- an extra, never fatal
         cubic = {"error": f"{type(e).__name__}: {e}"}
+    paired = None
+    try:
+        engp = SpectrogramEngine(48000.0, window_samples=W, hop_samples=H, channels=1, device=eng.device.index, interp=1, gradient="viridis", paired_frames=True)
+        mpf = measure_leg(torch, lambda: engp.render_batch(pcm, max_frames=Fp, out=rgba), args.leg_sustain_s)
+        paired = dict({"frames_per_s": Fp / (mpf["mean_ms"] * 1e-3), "what": "the same leg (cosine) with two frames per transform (SGX_FLAG_PAIRED_FRAMES)"},
+                      **leg_times(mpf))
+        engp.close()
+    except Exception as e:  # noqa: BLE001 -- an extra, never fatal
+        paired = {"error": f"{type(e).__name__}: {e}"}
     return {
         "workload": f"configs[2]: {Fp} frames of the same stream -> 1024 log rows (cosine interpolation), Viridis RGBA, fused PCM-to-pixel kernel",
+        "paired_frames": paired,
         "frames_per_s": Fp / (mean * 1e-3),
         **leg_times(m),
         "cubic": cubic,
@@ -609,7 +637,8 @@ def config3_leg(args, torch, eng, pcm, F):
             "bytes_per_frame": ALGO_BYTES_PIXEL, "frames_per_launch": Fp,
             "traffic": ((traffic or {}).get("pixel_bytes_per_frame") or 0) * Fp or None,
             "traffic_source": (traffic or {}).get("source"),
-            "kernel": "sgx::wg::stft4096_wg_kernel<true, 0, false, true>",
+            "kernel": "sgx::wgr::stft4096_real_kernel<2, true>" if eng.info.render_path & 8 else "sgx::wg::stft4096_wg_kernel<true, 0, false, true>",
+            "mono_mode": "every frame its own transform" if eng.info.render_path & 8 else "two frames per transform",
             "binding_pipe": pipes,
             "note": "48 flop per algorithmic byte: above the FP32 ridge (19.7), so the HBM fraction is low by construction; "
                     "the binding pipes (VALU issue, LDS) are in binding_pipe, from this round's SQ counter pass",
@@ -680,15 +709,12 @@ def first_allocation_of(torch, first, m_chosen, launch, bytes_per_launch, args):
     return {"launch_ms": m["mean_ms"], "frac": bytes_per_launch / (m["mean_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "is_value": first is None}
 
 
-def independent_frames_leg(args, torch, device):
-    """The headline stream in the reference's own dataflow: a mono sample is duplicated into (s, s) and EVERY frame is one transform
-    (audio_input_list_model.rs:67-69 + fft.rs:81-98; SGX_FLAG_INDEPENDENT_FRAMES).  Same 17 400 algorithmic bytes per frame as the
-    headline; twice the transforms.  This is the mode that meets north_star's tolerance against the frame's OWN peak on every
-    input (tests/test_gpu_parity.py::test_onsets_*); the headline packs two frames per transform."""
+def mono_mode_leg(args, torch, device, Fi, flags, what, kernel):
+    """The headline stream (configs[1]) in another mono mode of the library (include/sgx.h, "Mono streams"): same 17 400 algorithmic
+    bytes per frame, same protocol as every side leg."""
     from spectrogram_rs_amd import SpectrogramEngine
 
-    Fi = args.independent_frames
-    eng = SpectrogramEngine(48000.0, window_samples=W, hop_samples=H, channels=1, device=device, independent_frames=True)
+    eng = SpectrogramEngine(48000.0, window_samples=W, hop_samples=H, channels=1, device=device, **flags)
     pcm = eng.white_noise((Fi - 1) * H + W)
     out, first, placement = place_output(torch, args.placements, lambda: torch.empty((Fi, 1, M, 2), dtype=torch.float32, device=eng.device),
                                          lambda buf: eng.stft_batch(pcm, out=buf), Fi * ALGO_BYTES_STFT)
@@ -696,15 +722,12 @@ def independent_frames_leg(args, torch, device):
     mean = m["mean_ms"]
     achieved = Fi * ALGO_BYTES_STFT / (mean * 1e-3) / 1e9
     res = {
-        "workload": f"configs[1] in the reference's dataflow: {Fi} frames of the same mono stream, every frame its own (s, s) transform "
-                    "(SGX_FLAG_INDEPENDENT_FRAMES; audio_input_list_model.rs:67-69)",
+        "workload": f"configs[1], {Fi} frames of the same mono stream: {what}",
         "frames_per_s": Fi / (mean * 1e-3), **leg_times(m),
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "bytes_per_frame": ALGO_BYTES_STFT, "frames_per_launch": Fi,
-                     "kernel": "sgx::wg::stft4096_wg_kernel<false, 1, false, false>",
+                     "bytes_per_frame": ALGO_BYTES_STFT, "frames_per_launch": Fi, "kernel": kernel,
                      "first_allocation": first_allocation_of(torch, first, m, lambda buf: eng.stft_batch(pcm, out=buf), Fi * ALGO_BYTES_STFT, args),
-                     "placement": placement,
-                     "note": "one transform per frame: bound by the kernel's transform rate, as the (l, r) leg"},
+                     "placement": placement},
     }
     del out, first
     eng.close()

@@ -235,9 +235,6 @@ hipError_t run_stft(const sgx_ctx *c, const float *d_pcm, uint32_t channels, uin
     if (c->stft_kernel == 4 && c->d_chz) return sgx::launch_stft_chirpz(c, c->d_chz, d_pcm, channels, pairs, first, n, total, d_mags);
     if (c->stft_kernel == 4) return sgx::launch_stft_bluestein(c, c->d_blu, d_pcm, channels, pairs, first, n, total, d_mags);
     if (c->stft_kernel == 3) return sgx::launch_stft_wgp4096(c, c->d_fast_wg, d_pcm, channels, pairs, first, n, total, d_mags);
-    if (c->stft_kernel == 2 && c->d_real && (c->cfg.flags & SGX_FLAG_INDEPENDENT_FRAMES) && !(c->cfg.flags & SGX_FLAG_COMPLEX_MONO)
-        && sgx::real4096_serves(c, d_pcm, channels))
-        return sgx::launch_stft_real4096(c, c->d_real, d_pcm, first, n, total, d_mags, false);
     if (c->stft_kernel == 2) return sgx::launch_stft_wg4096(c, c->d_fast_wg, d_pcm, channels, pairs, first, n, total, d_mags);
     if (c->stft_kernel == 1) return sgx::launch_stft_fast4096(c, d_pcm, channels, pairs, first, n, total, d_mags);
     return sgx::launch_stft_generic(c, d_pcm, channels, pairs, first, n, total, d_mags);
@@ -460,7 +457,8 @@ int sgx_query(const sgx_ctx *c, sgx_info *out)
     if ((c->stft_kernel == 2 || c->stft_kernel == 3) && !(c->cfg.flags & SGX_FLAG_NO_FUSED_RENDER) && sgx::wg4096_can_fuse_render(c, c->d_fast_wg))
         out->render_path = 1u | (sgx::wg4096_seed_is_within_one(c) ? 2u : 0u);
     if ((c->stft_kernel == 6 || c->stft_kernel == 9) && sgx::mixed_fixed_plan(c->d_mix)) out->render_path |= 4u;
-    if (c->stft_kernel == 2 && c->d_real && (c->cfg.flags & SGX_FLAG_INDEPENDENT_FRAMES) && !(c->cfg.flags & SGX_FLAG_COMPLEX_MONO)) out->render_path |= 8u;
+    if (c->stft_kernel == 2 && c->d_real && !(c->cfg.flags & SGX_FLAG_COMPLEX_MONO)
+        && ((c->cfg.flags & SGX_FLAG_INDEPENDENT_FRAMES) || !(c->cfg.flags & SGX_FLAG_PAIRED_FRAMES))) out->render_path |= 8u;
     if (c->stft_kernel == 4 && c->d_chz) out->render_path |= 4u;
     if ((c->stft_kernel == 6 || c->stft_kernel == 9) && !(c->cfg.flags & SGX_FLAG_NO_FUSED_RENDER) && sgx::mixed_can_fuse_render(c, c->d_mix)) out->render_path |= 3u;
     out->mags_bytes_per_frame = (uint64_t)c->pairs * c->M * 2 * sizeof(float);
@@ -517,11 +515,7 @@ int sgx_stft_batch_f16(sgx_ctx *c, const float *d_pcm, size_t n_samples, size_t 
     if (n > max_frames) n = max_frames;
     if (!d_pcm || !d_mags_f16) return fail(c, SGX_ERR_INVALID_ARG, "sgx_stft_batch_f16: null buffer");
     SGX_HIP(c, hipSetDevice(c->device));
-    if (c->stft_kernel == 2 && c->d_real && (c->cfg.flags & SGX_FLAG_INDEPENDENT_FRAMES) && !(c->cfg.flags & SGX_FLAG_COMPLEX_MONO)
-        && sgx::real4096_serves(c, d_pcm, c->C)) {
-        hipError_t e = sgx::launch_stft_real4096(c, c->d_real, d_pcm, first_frame, n, total, d_mags_f16, true);
-        if (e != hipSuccess) return fail_hip(c, e, "sgx_stft_batch_f16: kernel launch");
-    } else if (c->stft_kernel == 2) {
+    if (c->stft_kernel == 2) {
         hipError_t e = sgx::launch_stft_wg4096_f16(c, c->d_fast_wg, d_pcm, c->C, c->pairs, first_frame, n, total, d_mags_f16);
         if (e != hipSuccess) return fail_hip(c, e, "sgx_stft_batch_f16: kernel launch");
     } else if (c->stft_kernel == 9 && c->C <= 2) {

@@ -196,9 +196,7 @@ hipError_t launch_stft_q16384(const sgx_ctx *c, void *tables, const float *d_pcm
 // stft4096_real.hip: independent mono frames at W 2048 / H 256 as 2048-point complex transforms of the real frame
 hipError_t real4096_init(sgx_ctx *c, void **out);
 void real4096_destroy(void *tables);
-bool real4096_serves(const sgx_ctx *c, const float *d_pcm, uint32_t channels);
-hipError_t launch_stft_real4096(const sgx_ctx *c, const void *tables, const float *d_pcm, size_t first_frame, size_t n_frames,
-                                size_t total_frames, void *d_mags, bool out_f16);
+bool real4096_serves(const sgx_ctx *c, const float *d_pcm, uint32_t channels);   // (launched from stft4096_wg.hip: launch_wg)
 bool w4800_supported(const sgx_ctx *c);
 hipError_t w4800_init(sgx_ctx *c, void **out);
 void w4800_destroy(void *tables);

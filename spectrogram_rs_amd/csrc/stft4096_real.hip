@@ -43,6 +43,7 @@ namespace wgr {
 
 using wg::kBufComplex;
 using wg::kLdsBytes;
+using wg::kLdsBytesRender;
 using wg::kM;
 using wg::kS1;
 using wg::kS2;
@@ -57,15 +58,7 @@ __device__ __forceinline__ f2v cl_fma(f2v a, float c, f2v u) { return __builtin_
 
 #include "fft_codelets.inc"
 
-struct Params {
-    const float *pcm;
-    const float2 *tw1;    // [8][256]   w_2048^{t q1}
-    const float2 *tw2;    // [16][16]   w_256^{t0 q2} at [q2][t0]   (K1's table)
-    const float2 *twu;    // [8][128]   w_4096^{u + 128 q3} at [q3][u]; [0][0] holds w_4096^{1024} = -i (thread 0 does bin 1024 in its q3 = 0 slot)
-    const float *window;  // [2048]
-    void *mags;           // [F][1][M][2] float, or the same as half pairs
-    unsigned long long first_frame, n_frames, n_samples, n_jobs, jobs_per_block;
-};
+using wg::Params;   // the 4096-point kernels' parameter block: tw1 = [8][256] w_2048^{t q1}, + twu, stream_samples (stft4096_wg.hpp)
 
 __device__ __forceinline__ float2 cmulf(float2 a, float2 b)
 {
@@ -100,15 +93,26 @@ __device__ __forceinline__ void fft8_half_zero(const float (&zr)[4], const float
     fft4(zr[0], zi[0], y1r, y1i, zi[2], -zr[2], y3r, y3i, yr + 1, yi + 1);                       // odd q1 at [1], [3], [5], [7]
 }
 
-template <bool F16>
+constexpr int kRowsF32 = 0, kRowsF16 = 1, kPixels = 2;   // what a launch writes: float rows, half-pair rows, RGBA columns (fused pixel path)
+
+template <int MODE, bool COSINE>
 __global__ void __launch_bounds__(256, 4) stft4096_real_kernel(Params p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float2 *buf = reinterpret_cast<float2 *>(smem_raw);
     float2 *tw2 = buf + kBufComplex;
+    uint2 *pal = reinterpret_cast<uint2 *>(tw2 + 256);          // kPixels only: [256] {threshold, RGBA} (wg::pixel_for)
+    constexpr bool F16 = MODE == kRowsF16;
 
     const int tid = threadIdx.x;
     tw2[tid] = p.tw2[tid];
+    uint32_t row_words[4] = {0u, 0u, 0u, 0u};  // kPixels: the table words of this thread's rows tid + 256 i
+    if (MODE == kPixels) {
+        pal[tid] = make_uint2(__float_as_uint(tid < 255 ? p.lut_thr[tid] : __builtin_nanf("")), *reinterpret_cast<const uint32_t *>(&p.lut_rgba[tid]));
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if ((uint32_t)tid + 256u * i < p.R) row_words[i] = p.rows[tid + 256 * i];
+    }
 
     // per-thread constants, resident for the life of the (persistent) workgroup
     // the output scale |S| 2 / W rides on the window as 1 / 2048 (the untangle's two halves and 2 / W = 1 / 1024): a power of two
@@ -140,8 +144,8 @@ __global__ void __launch_bounds__(256, 4) stft4096_real_kernel(Params p)
     // the rows requested ahead at the end of a run, need no branch (their results are never stored).
     auto columns_from = [&](unsigned long long col0) {
         const unsigned long long first = 2 * col0;                           // sample index
-        const unsigned long long left = first < p.n_samples ? (p.n_samples - first) * 4 : 0;
-        const unsigned long long addr = (unsigned long long)(p.pcm + (first < p.n_samples ? first : 0));
+        const unsigned long long left = first < p.stream_samples ? (p.stream_samples - first) * 4 : 0;
+        const unsigned long long addr = (unsigned long long)(p.pcm + (first < p.stream_samples ? first : 0));
         const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)addr), hi = __builtin_amdgcn_readfirstlane((uint32_t)(addr >> 32));
         const int records = __builtin_amdgcn_readfirstlane((int)(left < 0x7fffffffull ? left : 0x7fffffffull));
         return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((unsigned long long)hi << 32) | lo), 0, records, 0x00020000);
@@ -223,7 +227,8 @@ __global__ void __launch_bounds__(256, 4) stft4096_real_kernel(Params p)
         // of the stream it reads zeros.
         const float2 Ln = column(columns_from(128 * (fa + 2) + 1152), 0);
 
-        __builtin_amdgcn_s_setprio(3);
+        if (MODE == kPixels) __builtin_amdgcn_s_setprio(1);   // the pixel passes are long: 3 only from the row pass (the pixel stores) on
+        else __builtin_amdgcn_s_setprio(3);
         lds_barrier();  // everyone has read image 2
         // partner exchange: publish q3 = 8..15
 #pragma unroll
@@ -261,7 +266,7 @@ __global__ void __launch_bounds__(256, 4) stft4096_real_kernel(Params p)
 
         // ---- store row [M][2] (or half pairs): bin k at byte kBin (k - 1).  Straight-line code: the wait for the prefetched rows below
         // is then vmcnt(stores issued since).  Thread 0's q3 = 0 slot: bin 1024 from m1, and a second copy of it where its m2 would go.
-        {
+        if (MODE != kPixels) {
             const long long row = (long long)(F == 0 ? la : lb) * (long long)kM * kBin - kBin;      // byte of the (absent) bin 0
             const __amdgpu_buffer_rsrc_t r = out_rsrc(out, row, F == 0 || have_b);
             const int l1 = kBin * u, l2 = kBin * (1152 - u);                                        // bins u + 128 q3 ; 2048 - u - 128 q3 = (1152 - u) + 128 (7 - q3)
@@ -280,6 +285,26 @@ __global__ void __launch_bounds__(256, 4) stft4096_real_kernel(Params p)
                     __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(b), __float_as_uint(b)}, r, o2 + (s2 & 2047), s2 & ~2047, 0);
                 }
             }
+        } else {
+            // ---- fused pixel columns (simple_spectrogram.rs:141-161): the pair's magnitudes go to LDS as float2 per bin -- (frame A,
+            // frame B), each half written by its own frame's threads -- and K1's two pixel passes render both columns
+            float2 *mpair = buf;                           // [bin - 1]
+            float2 *vbuf = mpair + 2048;                   // [sample slot]
+            float *mcol = reinterpret_cast<float *>(buf) + F;
+            lds_barrier();  // partner and exchange reads done: the image can be overwritten
+#pragma unroll
+            for (int q3 = 0; q3 < 8; ++q3) {
+                const bool self = q3 == 0 && u == 0;       // thread 0's bin-1024 slot: m1 twice
+                const int k1 = self ? 1024 : u + 128 * q3, k2 = self ? 1024 : 2048 - u - 128 * q3;
+                mcol[2 * (k1 - 1)] = m1[q3];
+                mcol[2 * (k2 - 1)] = self ? m1[0] : m2[q3];
+            }
+            lds_barrier();
+            wg::sample_pass<COSINE>(p, mpair, vbuf, tid);
+            lds_barrier();
+            uchar4 *rgba = reinterpret_cast<uchar4 *>(p.rgba);
+            __builtin_amdgcn_s_setprio(3);
+            wg::row_pass<true>(p, row_words, vbuf, rgba + la * (size_t)p.R, rgba + lb * (size_t)p.R, true, have_b, pal, tid);
         }
         // ---- slide the window by two half rows
 #pragma unroll
@@ -349,36 +374,40 @@ void real4096_destroy(void *tables)
 // the streams this kernel serves: one channel, W = 2048, H = 256, every frame start 8-byte aligned (rows arrive as float2)
 bool real4096_serves(const sgx_ctx *c, const float *d_pcm, uint32_t channels)
 {
-    return channels == 1 && c->W == (uint32_t)wgr::kW && c->H == 256 && (reinterpret_cast<uintptr_t>(d_pcm) & 7u) == 0;
+    return channels == 1 && c->d_real && c->W == (uint32_t)wgr::kW && c->H == 256 && (reinterpret_cast<uintptr_t>(d_pcm) & 7u) == 0;
 }
 
-hipError_t launch_stft_real4096(const sgx_ctx *c, const void *tables, const float *d_pcm, size_t first_frame, size_t n_frames,
-                                size_t total_frames, void *d_mags, bool out_f16)
+namespace wg {
+
+// p: as launch_wg (stft4096_wg.hip) fills it for a one-channel stream -- stream, window, tw2, output, the pixel tables; the
+// transform's own tables and the job split are set here
+hipError_t launch_real4096(const sgx_ctx *c, const void *real_tables, Params p, bool out_f16, bool render)
 {
     using namespace wgr;
-    if (n_frames == 0) return hipSuccess;
-    const auto *t = static_cast<const RealTables *>(tables);
-    Params p{};
-    p.pcm = d_pcm;
+    if (p.n_frames == 0) return hipSuccess;
+    const auto *t = static_cast<const RealTables *>(real_tables);
     p.tw1 = t->d_tw1;
     p.tw2 = t->d_tw2;
     p.twu = t->d_twu;
-    p.window = c->d_window;
-    // rows are written relative to the call's first frame
-    p.mags = d_mags;
-    p.first_frame = first_frame;
-    p.n_frames = n_frames;
-    p.n_samples = total_frames ? (total_frames - 1) * 256ull + (unsigned long long)kW : 0;   // what the frames of the stream cover (the caller may hold a few more)
-    p.n_jobs = (n_frames + 1) / 2;
+    p.stream_samples = p.total_frames ? (p.total_frames - 1) * 256ull + (unsigned long long)kW : 0;   // what the stream's frames cover (the caller may hold more)
+    p.n_jobs = (p.n_frames + 1) / 2;
     unsigned long long blocks = (unsigned long long)c->n_cu * 4;   // persistent workgroups, four per CU, each a contiguous run of frame pairs
     unsigned long long per = (p.n_jobs + blocks - 1) / blocks;
     if (per < 1) per = 1;
     blocks = (p.n_jobs + per - 1) / per;
     p.jobs_per_block = per;
     const dim3 grid((unsigned)blocks), block(256);
-    if (out_f16) hipLaunchKernelGGL((stft4096_real_kernel<true>), grid, block, kLdsBytes, c->stream, p);
-    else hipLaunchKernelGGL((stft4096_real_kernel<false>), grid, block, kLdsBytes, c->stream, p);
+    if (render) {
+        if (p.interp == SGX_INTERP_COSINE) hipLaunchKernelGGL((stft4096_real_kernel<kPixels, true>), grid, block, kLdsBytesRender, c->stream, p);
+        else hipLaunchKernelGGL((stft4096_real_kernel<kPixels, false>), grid, block, kLdsBytesRender, c->stream, p);
+    } else if (out_f16) {
+        hipLaunchKernelGGL((stft4096_real_kernel<kRowsF16, false>), grid, block, kLdsBytes, c->stream, p);
+    } else {
+        hipLaunchKernelGGL((stft4096_real_kernel<kRowsF32, false>), grid, block, kLdsBytes, c->stream, p);
+    }
     return hipGetLastError();
 }
+
+}  // namespace wg
 
 }  // namespace sgx

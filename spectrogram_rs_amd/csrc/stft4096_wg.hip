@@ -530,8 +530,14 @@ hipError_t launch_wg(const sgx_ctx *c, const void *tables, const float *d_pcm, u
             lut_seed_coefficients(c, p.guess_a, p.guess_b);
             p.seed_pm1 = wg4096_seed_is_within_one(c) ? 1u : 0u;
         }
-        // mono normally rides two frames per transform; SGX_FLAG_INDEPENDENT_FRAMES runs it as (s, s) pairs
-        const bool mono = channels == 1 && !(c->cfg.flags & SGX_FLAG_INDEPENDENT_FRAMES);
+        // A one-channel stream (include/sgx.h, "Mono streams"): by default at H = 256 every frame its own real-input transform
+        // (stft4096_real.hip); SGX_FLAG_PAIRED_FRAMES, other hops and streams that are not 8-byte aligned: two frames per
+        // transform; SGX_FLAG_INDEPENDENT_FRAMES elsewhere and SGX_FLAG_COMPLEX_MONO: every frame as its own (s, s) transform
+        const uint32_t fl = c->cfg.flags;
+        const bool own_transform = (fl & (SGX_FLAG_INDEPENDENT_FRAMES | SGX_FLAG_COMPLEX_MONO)) || !(fl & SGX_FLAG_PAIRED_FRAMES);
+        if (channels == 1 && own_transform && !(fl & SGX_FLAG_COMPLEX_MONO) && real4096_serves(c, d_pcm, channels))
+            return launch_real4096(c, c->d_real, p, out_f16, RENDER);
+        const bool mono = channels == 1 && !(fl & (SGX_FLAG_INDEPENDENT_FRAMES | SGX_FLAG_COMPLEX_MONO));
         p.pair_base = mono ? first_frame / 2 : 0;
         p.n_jobs = mono ? (first_frame + n_frames + 1) / 2 - first_frame / 2 : n_frames;
         // persistent workgroups, 4 per CU; each owns a contiguous run of transforms so that the

@@ -46,7 +46,13 @@ struct Params {
     uint32_t R, interp;
     float guess_a, guess_b;    // LUT index ~ floor(log2(power + 1e-7) * a + b), then exact fix-up
     uint32_t seed_pm1;         // the host has shown that this seed is never off by more than one (seed_within_one): one compare pair fixes it
+    // the real-input kernel (stft4096_real.hip: every mono frame its own transform; tw1 is then [8][256] w_2048^{t q1})
+    const float2 *twu;         // [8][128] w_4096^{u + 128 q3} at [q3][u]; [0][0] holds w_4096^{1024} = -i
+    unsigned long long stream_samples;   // samples the frames of the stream cover: columns past them read as zero
 };
+
+// stft4096_real.hip
+hipError_t launch_real4096(const sgx_ctx *c, const void *real_tables, Params p, bool out_f16, bool render);
 
 // Which two mono frames share a transform: always (2j, 2j+1).
 //   kPairAdjacentRow : H = 256: frame 2j+1's rows are frame 2j's rows shifted by one (9 rows feed both)

@@ -48,20 +48,23 @@ def has_variants():
 
 # ---- the transform -----------------------------------------------------------------------------
 
-@pytest.mark.parametrize("variant", ["default", "packed", "wave", "generic"])
+@pytest.mark.parametrize("variant", ["default", "paired", "complex", "packed", "wave", "generic"])
 @pytest.mark.parametrize("channels", [1, 2])
 def test_stft_batch_matches_oracle(torch_cuda, mags_err, variant, channels):
-    # every kernel that can serve W = 2048: workgroup-per-transform (default), its packed-arithmetic
-    # twin, the wave-per-transform kernel, and the generic power-of-two kernel
+    # every kernel that can serve W = 2048: workgroup-per-transform (default; a mono stream: the real-input kernel, "paired": two
+    # frames per transform, "complex": every frame its (s, s) transform), its packed-arithmetic twin, the wave-per-transform
+    # kernel, and the generic power-of-two kernel
     torch = torch_cuda
-    kw = {"default": {}, "packed": {"packed_kernel": True}, "wave": {"wave_kernel": True}, "generic": {"force_generic": True}}[variant]
+    kw = {"default": {}, "paired": {"paired_frames": True}, "complex": {"complex_mono": True}, "packed": {"packed_kernel": True},
+          "wave": {"wave_kernel": True}, "generic": {"force_generic": True}}[variant]
     if variant in ("packed", "wave") and not has_variants():
         from spectrogram_rs_amd import SgxError
         with pytest.raises(SgxError, match="VARIANTS=1"):   # the default build leaves the superseded kernels out and says so
             engine(window_samples=W, hop_samples=H, channels=channels, **kw)
         pytest.skip("superseded A/B kernel: not in the default build (make VARIANTS=1)")
     eng = engine(window_samples=W, hop_samples=H, channels=channels, **kw)
-    assert eng.info.stft_kernel == {"default": 2, "packed": 3, "wave": 1, "generic": 0}[variant]
+    assert eng.info.stft_kernel == {"default": 2, "paired": 2, "complex": 2, "packed": 3, "wave": 1, "generic": 0}[variant]
+    assert bool(eng.info.render_path & 8) == (variant == "default" and channels == 1)
     n = W + H * 130 + 77
     pcm = oracle.white_noise(n * channels, seed=11 + channels)
     got = eng.stft_batch(to_dev(torch, pcm)).cpu().numpy()
@@ -268,7 +271,7 @@ def test_short_ragged_and_empty_inputs(torch_cuda):
     assert np.array_equal(part, full[3:5])
     assert eng.stft_batch(to_dev(torch, pcm), first_frame=99).shape[0] == 0
     # mono: two frames share a transform, paired by GLOBAL index -- any sub-range gives the same bytes
-    for kw in (dict(), dict(wave_kernel=True), dict(packed_kernel=True)) if has_variants() else (dict(),):
+    for kw in (dict(), dict(paired_frames=True), dict(wave_kernel=True), dict(packed_kernel=True)) if has_variants() else (dict(), dict(paired_frames=True)):
         mono = engine(window_samples=W, hop_samples=H, channels=1, **kw)
         m = to_dev(torch, oracle.white_noise(W + 12 * H, seed=6))
         full = mono.stft_batch(m)
@@ -382,7 +385,8 @@ def _error_bands(got, truth):
     return rows
 
 
-@pytest.mark.parametrize("name,Wt,Ht,ch,kw", [("4096 mono pairs", 2048, 256, 1, {}), ("4096 stereo", 2048, 256, 2, {}),
+@pytest.mark.parametrize("name,Wt,Ht,ch,kw", [("4096 mono, real-input", 2048, 256, 1, {}), ("4096 mono pairs", 2048, 256, 1, {"paired_frames": True}),
+                                              ("4096 stereo", 2048, 256, 2, {}),
                                               ("16384 stereo", 8192, 512, 2, {}), ("4800 mixed radix", 2400, 93, 2, {}),
                                               ("2204 chirp-z", 1102, 100, 2, {}), ("3704 chirp-z", 1852, 100, 2, {}),
                                               ("2048 generic", 1024, 128, 2, {})])
@@ -777,12 +781,13 @@ def test_threshold_tables_reproduce_log10_everywhere(torch_cuda, gradients):
     assert np.array_equal(got, ref)
 
 
-def test_fused_pcm_to_rgba_end_to_end(torch_cuda, gradients):
+@pytest.mark.parametrize("paired", [False, True])
+def test_fused_pcm_to_rgba_end_to_end(torch_cuda, gradients, paired):
     # end to end the magnitudes differ from the oracle's by float32 rounding, so a pixel that sits
     # on a LUT boundary may move by one step: report the rate, bound it, and bound the step.
     torch = torch_cuda
     for interp in (0, 1):
-        eng = engine(window_samples=W, hop_samples=H, channels=1, interp=interp, gradient="viridis")
+        eng = engine(window_samples=W, hop_samples=H, channels=1, interp=interp, gradient="viridis", paired_frames=paired)
         pcm = oracle.white_noise(W + 63 * H, seed=33) * np.float32(0.05)
         got = eng.render_batch(to_dev(torch, pcm)).cpu().numpy()[:, 0]
         mags = oracle.stream_process(pcm, 1, W, H)[:, 0]
@@ -798,15 +803,17 @@ def test_fused_pcm_to_rgba_end_to_end(torch_cuda, gradients):
         assert np.array_equal(got, own)
 
 
-@pytest.mark.parametrize("channels,frames", [(1, 37), (1, 64), (2, 21)])
+@pytest.mark.parametrize("channels,frames,mode", [(1, 37, {}), (1, 64, {}), (1, 37, {"paired_frames": True}), (1, 64, {"paired_frames": True}),
+                                                  (1, 21, {"complex_mono": True}), (2, 21, {})])
 @pytest.mark.parametrize("interp", [0, 1])
-def test_fused_kernel_equals_two_kernel_path(torch_cuda, channels, frames, interp):
-    # the fused PCM -> RGBA kernel (magnitudes stay in LDS) must write the bytes of STFT + pixel stage
+def test_fused_kernel_equals_two_kernel_path(torch_cuda, channels, frames, mode, interp):
+    # the fused PCM -> RGBA kernel (magnitudes stay in LDS) must write the bytes of STFT + pixel stage -- in every mono mode (the
+    # real-input kernel, frame pairs, (s, s) transforms) and for an (l, r) stream
     torch = torch_cuda
     n = W + (frames - 1) * H
     pcm = to_dev(torch, oracle.white_noise(n * channels, seed=77) * np.float32(0.1))
-    fused = engine(window_samples=W, hop_samples=H, channels=channels, interp=interp, gradient="magma")
-    split = engine(window_samples=W, hop_samples=H, channels=channels, interp=interp, gradient="magma", fused_render=False)
+    fused = engine(window_samples=W, hop_samples=H, channels=channels, interp=interp, gradient="magma", **mode)
+    split = engine(window_samples=W, hop_samples=H, channels=channels, interp=interp, gradient="magma", fused_render=False, **mode)
     a = fused.render_batch(pcm).cpu().numpy()
     b = split.render_batch(pcm).cpu().numpy()
     assert a.shape == (frames, 1, R, 4) and np.array_equal(a, b)
@@ -817,12 +824,12 @@ def test_fused_kernel_equals_two_kernel_path(torch_cuda, channels, frames, inter
     # more than one -- also where the dB range starts below the 1e-7 power floor, min_db < -70); SGX_FLAG_LUT_WALK
     # makes it walk the thresholds from the seed instead, as it does where that proof fails -- the same bytes either
     # way, over the whole level range
-    assert fused.info.render_path == 3 and split.info.render_path == 0
-    kw = dict(window_samples=W, hop_samples=H, channels=channels, interp=interp, gradient="magma")
+    assert fused.info.render_path & 7 == 3 and split.info.render_path & 7 == 0
+    kw = dict(window_samples=W, hop_samples=H, channels=channels, interp=interp, gradient="magma", **mode)
     walk = engine(lut_walk=True, **kw)
     low = engine(min_db=-110.0, max_db=-20.0, **kw)
     low_split = engine(min_db=-110.0, max_db=-20.0, fused_render=False, **kw)
-    assert walk.info.render_path == 1 and low.info.render_path == 3
+    assert walk.info.render_path & 7 == 1 and low.info.render_path & 7 == 3
     for amp in (1.0, 1e-2, 1e-4, 0.0):       # every LUT index from the top of the ramp down to silence
         x = pcm * amp
         want = split.render_batch(x)
@@ -885,15 +892,17 @@ def test_non_finite_and_extreme_samples(torch_cuda, gradients):
 def test_frame_pairing_dynamic_range_and_independent_frames(torch_cuda, mags_err):
     # A mono transform carries two frames; float32 rounding of the louder one is the noise floor of the
     # quieter one (as left / right share one transform in the reference).  Frames that share 7/8 of their
-    # samples are never far apart in level -- except across an isolated transient.  With
-    # independent_frames=True every frame gets its own transform, exactly the reference's dataflow.
+    # samples are never far apart in level -- except across an isolated transient.  By default (W 2048 / H 256: the real-input
+    # kernel) and with independent_frames=True every frame gets its own transform, exactly the reference's dataflow;
+    # paired_frames=True is the two-frames-per-transform mode.
     torch = torch_cuda
     x = oracle.white_noise(W + 3 * H, seed=9) * np.float32(1e-3)
     x[10] = 1.0                                  # a click inside frame 0 only (sample 10 < H)
     ref = np.stack([oracle.np_truth_frame(np.stack([x[t * H:t * H + W]] * 2, 1), W) for t in range(4)])
-    paired = engine(window_samples=W, hop_samples=H, channels=1).stft_batch(to_dev(torch, x)).cpu().numpy()[:, 0]
-    indep = engine(window_samples=W, hop_samples=H, channels=1, independent_frames=True).stft_batch(to_dev(torch, x)).cpu().numpy()[:, 0]
-    assert mags_err(indep, ref) <= 1.0                       # every frame within tolerance of the truth
+    paired = engine(window_samples=W, hop_samples=H, channels=1, paired_frames=True).stft_batch(to_dev(torch, x)).cpu().numpy()[:, 0]
+    indep = engine(window_samples=W, hop_samples=H, channels=1).stft_batch(to_dev(torch, x)).cpu().numpy()[:, 0]   # the default at this window / hop
+    cplx = engine(window_samples=W, hop_samples=H, channels=1, independent_frames=True, complex_mono=True).stft_batch(to_dev(torch, x)).cpu().numpy()[:, 0]
+    assert mags_err(indep, ref) <= 1.0 and mags_err(cplx, ref) <= 1.0   # every frame within tolerance of the truth
     assert mags_err(paired[[0, 2, 3]], ref[[0, 2, 3]]) <= 1.0
     # frame 1 rides with the click: its error is bounded relative to the PAIR's peak, not its own
     pair_peak = np.abs(ref[:2]).max()
@@ -902,18 +911,21 @@ def test_frame_pairing_dynamic_range_and_independent_frames(torch_cuda, mags_err
 
 @pytest.mark.parametrize("n_frames", [1, 2, 3, 64, 131, 2051])
 def test_real_input_kernel_for_independent_mono_frames(torch_cuda, mags_err, n_frames):
-    # SGX_FLAG_INDEPENDENT_FRAMES at W 2048 / H 256 (the headline's stream shape): every mono frame is its own transform -- the
+    # A mono stream at W 2048 / H 256 (the headline's stream shape), DEFAULT flags: every frame is its own transform -- the
     # reference's (s, s) dataflow, audio_input_list_model.rs:67-69 + fft.rs:47-99 -- computed as a 2048-point complex transform of
     # the real frame + one butterfly per bin (csrc/stft4096_real.hip).  Against the float64 truth (1 x), the float32 oracle (2 x),
-    # the literal (s, s) transform (SGX_FLAG_COMPLEX_MONO) and itself over sub-ranges, odd counts and a misaligned stream.
+    # the literal (s, s) transform (SGX_FLAG_COMPLEX_MONO), the paired mode (pair-peak tolerance) and itself over sub-ranges,
+    # odd counts and a misaligned stream.
     torch = torch_cuda
     n = W + (n_frames - 1) * H + 77
     pcm = oracle.white_noise(n, seed=1000 + n_frames)
     pcm[: min(n, 5000)] *= np.float32(0.01)                 # a level step inside the stream: frames of very different peaks
     dev = to_dev(torch, pcm)
-    real = engine(window_samples=W, hop_samples=H, channels=1, independent_frames=True)
-    cplx = engine(window_samples=W, hop_samples=H, channels=1, independent_frames=True, complex_mono=True)
-    assert real.info.stft_kernel == 2 and real.info.render_path & 8 and not (cplx.info.render_path & 8)
+    real = engine(window_samples=W, hop_samples=H, channels=1)
+    cplx = engine(window_samples=W, hop_samples=H, channels=1, complex_mono=True)
+    pair = engine(window_samples=W, hop_samples=H, channels=1, paired_frames=True)
+    assert real.info.stft_kernel == 2 and real.info.render_path & 8 and not (cplx.info.render_path & 8) and not (pair.info.render_path & 8)
+    assert engine(window_samples=W, hop_samples=H, channels=1, independent_frames=True, paired_frames=True).info.render_path & 8   # "never pair" wins
     got = real.stft_batch(dev).cpu().numpy()
     assert got.shape == (n_frames, 1, M, 2)
     pick = sorted(set(list(range(min(n_frames, 24))) + [n_frames - 1, n_frames // 2] + list(range(0, n_frames, 97))))
@@ -923,6 +935,8 @@ def test_real_input_kernel_for_independent_mono_frames(torch_cuda, mags_err, n_f
     ref32 = oracle.stream_process(pcm, 1, W, H, threads=8)
     assert mags_err(got, ref32) <= 2.0
     assert mags_err(got, cplx.stft_batch(dev).cpu().numpy().astype(np.float64)) <= 2.0
+    assert np.array_equal(engine(window_samples=W, hop_samples=H, channels=1, independent_frames=True).stft_batch(dev).cpu().numpy(), got)
+    assert _pair_error(pair.stft_batch(dev).cpu().numpy()[pick, 0], truth) <= 1.0 if pick == list(range(n_frames)) else True
     # frames are independent problems: any sub-range, from an odd first frame too, writes the bytes of the full run
     for first, cnt in ((0, 1), (1, 1), (1, 2), (2, 5), (n_frames - 1, 1), (n_frames // 2, n_frames)):
         if first >= n_frames:
@@ -933,12 +947,15 @@ def test_real_input_kernel_for_independent_mono_frames(torch_cuda, mags_err, n_f
     h = real.stft_batch_f16(dev)
     assert torch.equal(h, torch.from_numpy(got).cuda().to(torch.float16))
     assert torch.equal(real.stft_batch_f16(dev, first_frame=1, max_frames=3), h[1:4])
-    # a stream that is 4- but not 8-byte aligned cannot be read as float2 rows: the (s, s) kernel takes it, same tolerance
+    # a stream that is 4- but not 8-byte aligned cannot be read as float2 rows: "never pair" sends it to the (s, s) kernel (own-peak
+    # tolerance), the default to the paired kernel (pair-peak tolerance; on this stream of one level step: the own-peak one too
+    # except around the step)
     shifted = torch.empty(dev.numel() + 1, dtype=dev.dtype, device=dev.device)
     shifted[1:] = dev
     assert shifted[1:].data_ptr() % 8 == 4
-    alt = real.stft_batch(shifted[1:]).cpu().numpy()
+    alt = engine(window_samples=W, hop_samples=H, channels=1, independent_frames=True).stft_batch(shifted[1:]).cpu().numpy()
     assert mags_err(alt[pick, 0], truth) <= 1.0
+    assert mags_err(real.stft_batch(shifted[1:]).cpu().numpy(), ref32) <= 4.0
     # determinism
     assert np.array_equal(real.stft_batch(dev).cpu().numpy(), got)
 
@@ -961,14 +978,15 @@ def _pair_error(x, ref, first_frame=0):
 @pytest.mark.parametrize("step_db", [20, 40, 60, None])
 @pytest.mark.parametrize("kind", ["onset", "offset"])
 def test_onsets_inside_one_hop_own_peak_tolerance_and_the_paired_bound(torch_cuda, mags_err, step_db, kind):
-    # What the headline's mono mode costs in conformance, measured and bounded.  A level step of
+    # What two frames per transform cost in conformance, measured and bounded -- the mode of rounds 1-3's
+    # headline, now SGX_FLAG_PAIRED_FRAMES at this window / hop and still the default at every other one.  A level step of
     # 20 / 40 / 60 dB -- or from digital silence (None) -- to full scale INSIDE ONE HOP, placed so that it falls between the two
     # frames of a pair: onset in [6H + W, 7H + W) is inside frame 7's last hop and outside frame 6; offset (loud -> quiet) at a
     # sample in [6H, 7H) leaves its last loud samples in frame 6's first hop and none in frame 7.  Also one step that does NOT
     # split a pair (between frames 9 and 10), where paired and independent modes must both hold the own-peak tolerance.
-    #   independent frames (the reference's (s, s) dataflow, audio_input_list_model.rs:67-69 + fft.rs:81-98):
+    #   every frame its own transform (the default here; the reference's (s, s) dataflow, audio_input_list_model.rs:67-69 + fft.rs:81-98):
     #       every frame within 1 x north_star's tolerance of the float64 truth against ITS OWN peak -- asserted;
-    #   paired (default): every frame within 1 x the same tolerance against the PAIR's peak -- asserted; against its own peak
+    #   paired: every frame within 1 x the same tolerance against the PAIR's peak -- asserted; against its own peak
     #       the quiet frame of a split pair is off by up to the level ratio of the pair -- measured, printed, and bounded by
     #       that ratio (the statement "1e-7 of the pair's peak" of DESIGN section 4 as an assertion).
     torch = torch_cuda
@@ -981,12 +999,12 @@ def test_onsets_inside_one_hop_own_peak_tolerance_and_the_paired_bound(torch_cud
         x = noise * gain
         ref = np.stack([oracle.np_truth_frame(np.stack([x[t * H:t * H + W]] * 2, 1), W) for t in range(16)])
         own_peak = np.abs(ref).max(axis=(1, 2))
-        indep = engine(window_samples=W, hop_samples=H, channels=1, independent_frames=True).stft_batch(to_dev(torch, x)).cpu().numpy()[:, 0]
-        paired = engine(window_samples=W, hop_samples=H, channels=1).stft_batch(to_dev(torch, x)).cpu().numpy()[:, 0]
+        indep = engine(window_samples=W, hop_samples=H, channels=1).stft_batch(to_dev(torch, x)).cpu().numpy()[:, 0]          # the default: every frame its own transform
+        paired = engine(window_samples=W, hop_samples=H, channels=1, paired_frames=True).stft_batch(to_dev(torch, x)).cpu().numpy()[:, 0]
         assert mags_err(indep, ref) <= 1.0
         assert _pair_error(paired, ref) <= 1.0
         # sub-ranges pair by GLOBAL index: the same bound from an odd first frame
-        part = engine(window_samples=W, hop_samples=H, channels=1).stft_batch(to_dev(torch, x), first_frame=5, max_frames=6).cpu().numpy()[:, 0]
+        part = engine(window_samples=W, hop_samples=H, channels=1, paired_frames=True).stft_batch(to_dev(torch, x), first_frame=5, max_frames=6).cpu().numpy()[:, 0]
         assert np.array_equal(part, paired[5:11])
         per_frame = np.array([mags_err(paired[t], ref[t]) for t in range(16)])
         worst = int(per_frame.argmax())
@@ -999,7 +1017,7 @@ def test_onsets_inside_one_hop_own_peak_tolerance_and_the_paired_bound(torch_cud
         assert mags_err(paired[frames_far], ref[frames_far]) <= 1.5   # frames whose partner is at their own level: (about) the own-peak tolerance
 
 
-@pytest.mark.parametrize("kw", [dict(channels=1), dict(channels=2), dict(channels=1, force_generic=True),
+@pytest.mark.parametrize("kw", [dict(channels=1), dict(channels=1, paired_frames=True), dict(channels=2), dict(channels=1, force_generic=True),
                                 dict(channels=2, window_samples=2400, hop_samples=93), dict(channels=1, window_samples=2400, hop_samples=93),
                                 dict(channels=2, window_samples=2205, hop_samples=86), dict(channels=4, window_samples=1600, hop_samples=50),
                                 dict(channels=2, window_samples=1102, hop_samples=100)])
