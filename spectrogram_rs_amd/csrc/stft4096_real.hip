@@ -162,6 +162,21 @@ __global__ void __launch_bounds__(256, 4) stft4096_real_kernel(Params p)
         for (int j = 0; j < 8; ++j) R[j] = column(r0, 1024 * j);
         carry = column(r0, 8192);     // c[128 fa + 1024 + tid]
         L = column(r0, 9216);         // c[128 fa + 1152 + tid]
+        // the window is waited for HERE (an empty asm that reads it), so that the loop header carries no pending load of the entry path:
+        // merged with the back edge -- where the same registers are long complete -- it made the compiler wait at the top of EVERY
+        // iteration with vmcnt(2), i.e. for the sixteen row stores just issued to be acknowledged by memory
+#pragma unroll
+        for (int j = 0; j < 8; ++j) asm volatile("" ::"v"(R[j].x), "v"(R[j].y));
+        asm volatile("" ::"v"(carry.x), "v"(carry.y), "v"(L.x), "v"(L.y));
+        // (the resident constants too: the compiler schedules their loads BEHIND the window's, and a constant still pending at the
+        // loop entry became a vmcnt(10) .. vmcnt(5) at its first use inside the loop -- in every iteration)
+#pragma unroll
+        for (int q = 1; q < 8; ++q) asm volatile("" ::"v"(tw1[q].x), "v"(tw1[q].y));
+#pragma unroll
+        for (int q = 0; q < 8; ++q) asm volatile("" ::"v"(twu[q].x), "v"(twu[q].y), "v"(win[q]));
+        // (L as well: in flight at the loop entry it made the wait at its first use -- the exchange write, two thirds into the
+        // iteration -- a vmcnt(1): all sixteen row stores of the PREVIOUS iteration acknowledged.  Every later L is complete before the
+        // back edge: the copy from Ln behind the stores waits for it with vmcnt(16), the stores still in flight.)
     }
     float2 *xch = buf + 2304;         // [256] the iteration's loads, beside the partner rows (image 2 is dead by then)
 
@@ -225,7 +240,7 @@ __global__ void __launch_bounds__(256, 4) stft4096_real_kernel(Params p)
         // the load of the NEXT iteration (its R[9]), ahead of this iteration's stores (vmcnt retires in issue order) and a whole
         // iteration ahead of its use.  Unconditional (a conditional request keeps the old value alive around the loop); past the end
         // of the stream it reads zeros.
-        const float2 Ln = column(columns_from(128 * (fa + 2) + 1152), 0);
+        float2 Ln = column(columns_from(128 * (fa + 2) + 1152), 0);
 
         if (MODE == kPixels) __builtin_amdgcn_s_setprio(1);   // the pixel passes are long: 3 only from the row pass (the pixel stores) on
         else __builtin_amdgcn_s_setprio(3);
@@ -306,7 +321,9 @@ __global__ void __launch_bounds__(256, 4) stft4096_real_kernel(Params p)
             __builtin_amdgcn_s_setprio(3);
             wg::row_pass<true>(p, row_words, vbuf, rgba + la * (size_t)p.R, rgba + lb * (size_t)p.R, true, have_b, pal, tid);
         }
-        // ---- slide the window by two half rows
+        // ---- slide the window by two half rows.  `Ln` is pinned behind the stores: its copy into L needs the load complete, and
+        // scheduled in front of the stores (where the compiler had put it) that is a vmcnt(0) in the middle of the iteration
+        asm volatile("" : "+v"(Ln.x), "+v"(Ln.y));
 #pragma unroll
         for (int j = 0; j < 6; ++j) R[j] = R[j + 2];
         R[6].x = tid >= 128 ? Y.x : carry.x;
