@@ -28,8 +28,9 @@
 // eight rows of a frame pair are R[j] = c[128 fa + t + 128 j], j = 0 .. 7 (even j: frame A, odd j: frame B), and the next pair's are
 // R[j + 2]: the window slides in registers.  Of the two new values R[9] = c[128 fa + 1152 + t] is the thread's own load (ONE 8-byte
 // load per thread and iteration, requested a whole iteration ahead, in front of the stores); R[8] = c[128 fa + 1024 + t] is what
-// thread t - 128 loads in this iteration (t >= 128) or what thread t + 128 loaded in the previous one (t < 128): it crosses the
-// workgroup through 2 KB of LDS beside the partner exchange (same barrier).  Every sample is fetched from memory exactly once.
+// thread t - 128 loaded for this iteration (t >= 128) or what thread t + 128 holds as its R[7] (t < 128): every thread publishes
+// the one its opposite number needs in 2 KB of LDS beside the partner exchange (same barrier) and reads the other's.  Every sample
+// is fetched from memory exactly once.
 // (The first version let both frames slide on their own and fetched every sample twice; the output stream keeps evicting the
 // input from L2, the second fetch went to HBM, and the launch took exactly the 5.9 % longer that 18 424 B / frame are more than
 // 17 400: 3.72 ms per 1e6 frames against the paired kernel's 3.50.)
@@ -95,7 +96,8 @@ __device__ __forceinline__ void fft8_half_zero(const float (&zr)[4], const float
 
 constexpr int kRowsF32 = 0, kRowsF16 = 1, kPixels = 2;   // what a launch writes: float rows, half-pair rows, RGBA columns (fused pixel path)
 
-template <int MODE, bool COSINE>
+// PIX (kPixels only): the pixel code of the instantiation, wg::kPixCubic / kPixCosine / kPixGeneric (stft4096_wg.hpp)
+template <int MODE, int PIX>
 __global__ void __launch_bounds__(256, 4) stft4096_real_kernel(Params p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -155,19 +157,18 @@ __global__ void __launch_bounds__(256, 4) stft4096_real_kernel(Params p)
         return make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
     };
     float2 R[8];        // R[j] = c[128 fa + tid + 128 j]: rows a = j / 2 of frame A (even j) and frame B (odd j)
-    float2 carry, L;    // carry (tid < 128): the next R[6], read from LDS one iteration early; L: the next R[7], in flight
+    float2 L;           // the next R[7] = c[128 fa + 1152 + tid]
     {
         const __amdgpu_buffer_rsrc_t r0 = columns_from(128 * (p.first_frame + 2 * job_begin));
 #pragma unroll
         for (int j = 0; j < 8; ++j) R[j] = column(r0, 1024 * j);
-        carry = column(r0, 8192);     // c[128 fa + 1024 + tid]
         L = column(r0, 9216);         // c[128 fa + 1152 + tid]
         // the window is waited for HERE (an empty asm that reads it), so that the loop header carries no pending load of the entry path:
         // merged with the back edge -- where the same registers are long complete -- it made the compiler wait at the top of EVERY
         // iteration with vmcnt(2), i.e. for the sixteen row stores just issued to be acknowledged by memory
 #pragma unroll
         for (int j = 0; j < 8; ++j) asm volatile("" ::"v"(R[j].x), "v"(R[j].y));
-        asm volatile("" ::"v"(carry.x), "v"(carry.y), "v"(L.x), "v"(L.y));
+        asm volatile("" ::"v"(L.x), "v"(L.y));
         // (the resident constants too: the compiler schedules their loads BEHIND the window's, and a constant still pending at the
         // loop entry became a vmcnt(10) .. vmcnt(5) at its first use inside the loop -- in every iteration)
 #pragma unroll
@@ -240,7 +241,10 @@ __global__ void __launch_bounds__(256, 4) stft4096_real_kernel(Params p)
         // the load of the NEXT iteration (its R[9]), ahead of this iteration's stores (vmcnt retires in issue order) and a whole
         // iteration ahead of its use.  Unconditional (a conditional request keeps the old value alive around the loop); past the end
         // of the stream it reads zeros.
-        float2 Ln = column(columns_from(128 * (fa + 2) + 1152), 0);
+        // (The fused pixel path requests it at the END of the iteration instead: its few pixel stores are no queue to wait behind, and
+        // two registers fewer are live through the pixel passes -- with them the kernel spilled.)
+        float2 Ln = make_float2(0.0f, 0.0f);
+        if (MODE != kPixels) Ln = column(columns_from(128 * (fa + 2) + 1152), 0);
 
         if (MODE == kPixels) __builtin_amdgcn_s_setprio(1);   // the pixel passes are long: 3 only from the row pass (the pixel stores) on
         else __builtin_amdgcn_s_setprio(3);
@@ -251,9 +255,16 @@ __global__ void __launch_bounds__(256, 4) stft4096_real_kernel(Params p)
             const int pos = FFT16_OUT[8 + j];
             buf[j * 256 + tid] = make_float2(xr[pos], xi[pos]);
         }
-        xch[tid] = L;   // this iteration's load (requested one iteration ago) for the threads half a row away
+        // the next R[6] = c[128 fa + 1024 + tid] of the thread half a row away: its L (lower half publishes) or its R[7] (upper half)
+        xch[tid].x = tid < 128 ? L.x : R[7].x;
+        xch[tid].y = tid < 128 ? L.y : R[7].y;
         lds_barrier();
-        const float2 Y = xch[(tid + 128) & 255];   // tid >= 128: the next R[6]; tid < 128: the R[6] after that
+        const float2 Y = xch[(tid + 128) & 255];
+        // ---- slide the window by two half rows, here: L is dead from now on (the Hann products of this iteration were taken at its top)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) R[j] = R[j + 2];
+        R[6] = Y;
+        R[7] = L;
 
         // ---- untangle + magnitude: bins k = u + 128 q3 and 2048 - k.  Z[2048 - k] is register 15 - q3 of thread 128 - u (row 7 - q3);
         // thread 0 holds its own partners one row up (register 16 - q3), and spends its q3 = 0 slot -- DC and Nyquist are not outputs
@@ -303,34 +314,36 @@ __global__ void __launch_bounds__(256, 4) stft4096_real_kernel(Params p)
         } else {
             // ---- fused pixel columns (simple_spectrogram.rs:141-161): the pair's magnitudes go to LDS as float2 per bin -- (frame A,
             // frame B), each half written by its own frame's threads -- and K1's two pixel passes render both columns
-            float2 *mpair = buf;                           // [bin - 1]
-            float2 *vbuf = mpair + 2048;                   // [sample slot]
+            float2 *mpair = buf;                           // the padded column [bin] (wg::kColSlots)
+            float2 *vbuf = mpair + wg::kColSlots;          // [sample slot]
             float *mcol = reinterpret_cast<float *>(buf) + F;
             lds_barrier();  // partner and exchange reads done: the image can be overwritten
 #pragma unroll
             for (int q3 = 0; q3 < 8; ++q3) {
                 const bool self = q3 == 0 && u == 0;       // thread 0's bin-1024 slot: m1 twice
                 const int k1 = self ? 1024 : u + 128 * q3, k2 = self ? 1024 : 2048 - u - 128 * q3;
-                mcol[2 * (k1 - 1)] = m1[q3];
-                mcol[2 * (k2 - 1)] = self ? m1[0] : m2[q3];
+                mcol[2 * k1] = m1[q3];
+                mcol[2 * k2] = self ? m1[0] : m2[q3];
+                if (q3 == 0 && u == 1) {                   // this thread holds bin 1 (m1[0]) and bin 2047 (m2[0]): the repeats around the column
+                    mcol[0] = m1[0];
+                    mcol[2 * (kM + 1)] = mcol[2 * (kM + 2)] = m2[0];
+                }
             }
             lds_barrier();
-            wg::sample_pass<COSINE>(p, mpair, vbuf, tid);
+            wg::sample_pass<PIX>(p, mpair, vbuf, tid);
             lds_barrier();
             uchar4 *rgba = reinterpret_cast<uchar4 *>(p.rgba);
             __builtin_amdgcn_s_setprio(3);
-            wg::row_pass<true>(p, row_words, vbuf, rgba + la * (size_t)p.R, rgba + lb * (size_t)p.R, true, have_b, pal, tid);
+            wg::row_pass<true, PIX>(p, row_words, vbuf, rgba + la * (size_t)p.R, rgba + lb * (size_t)p.R, true, have_b, pal, tid);
         }
-        // ---- slide the window by two half rows.  `Ln` is pinned behind the stores: its copy into L needs the load complete, and
+        // ---- the next iteration's own load.  Rows: `Ln` is pinned behind the stores -- its copy into L needs the load complete, and
         // scheduled in front of the stores (where the compiler had put it) that is a vmcnt(0) in the middle of the iteration
-        asm volatile("" : "+v"(Ln.x), "+v"(Ln.y));
-#pragma unroll
-        for (int j = 0; j < 6; ++j) R[j] = R[j + 2];
-        R[6].x = tid >= 128 ? Y.x : carry.x;
-        R[6].y = tid >= 128 ? Y.y : carry.y;
-        carry = Y;
-        R[7] = L;
-        L = Ln;
+        if (MODE != kPixels) {
+            asm volatile("" : "+v"(Ln.x), "+v"(Ln.y));
+            L = Ln;
+        } else {
+            L = column(columns_from(128 * (fa + 2) + 1152), 0);
+        }
     }
 }
 
@@ -415,12 +428,13 @@ hipError_t launch_real4096(const sgx_ctx *c, const void *real_tables, Params p, 
     p.jobs_per_block = per;
     const dim3 grid((unsigned)blocks), block(256);
     if (render) {
-        if (p.interp == SGX_INTERP_COSINE) hipLaunchKernelGGL((stft4096_real_kernel<kPixels, true>), grid, block, kLdsBytesRender, c->stream, p);
-        else hipLaunchKernelGGL((stft4096_real_kernel<kPixels, false>), grid, block, kLdsBytesRender, c->stream, p);
+        if (!p.seed_pm1) hipLaunchKernelGGL((stft4096_real_kernel<kPixels, kPixGeneric>), grid, block, kLdsBytesRender, c->stream, p);
+        else if (p.interp == SGX_INTERP_COSINE) hipLaunchKernelGGL((stft4096_real_kernel<kPixels, kPixCosine>), grid, block, kLdsBytesRender, c->stream, p);
+        else hipLaunchKernelGGL((stft4096_real_kernel<kPixels, kPixCubic>), grid, block, kLdsBytesRender, c->stream, p);
     } else if (out_f16) {
-        hipLaunchKernelGGL((stft4096_real_kernel<kRowsF16, false>), grid, block, kLdsBytes, c->stream, p);
+        hipLaunchKernelGGL((stft4096_real_kernel<kRowsF16, kPixNone>), grid, block, kLdsBytes, c->stream, p);
     } else {
-        hipLaunchKernelGGL((stft4096_real_kernel<kRowsF32, false>), grid, block, kLdsBytes, c->stream, p);
+        hipLaunchKernelGGL((stft4096_real_kernel<kRowsF32, kPixNone>), grid, block, kLdsBytes, c->stream, p);
     }
     return hipGetLastError();
 }

@@ -21,6 +21,7 @@
 // TWO consecutive frames into one transform: frame 2j in the real part, frame 2j+1 in the
 // imaginary part; the same split that separates left from right separates the two frames.
 #include <cmath>
+#include <type_traits>
 
 #include "stft4096_wg.hpp"
 
@@ -39,9 +40,11 @@ __device__ __forceinline__ float2 cmulf(float2 a, float2 b)
     return make_float2(fmaf(a.x, b.x, -(a.y * b.y)), fmaf(a.x, b.y, a.y * b.x));
 }
 
-template <bool MONO, int PAIRING, bool C2, bool RENDER>
+// PIX: kPixNone = rows (float or half pairs); else the fused pixel path with that pixel code (stft4096_wg.hpp)
+template <bool MONO, int PAIRING, bool C2, int PIX>
 __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
 {
+    constexpr bool RENDER = PIX != kPixNone;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float2 *buf = reinterpret_cast<float2 *>(smem_raw);
     float2 *tw2 = buf + kBufComplex;
@@ -315,23 +318,24 @@ __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
         } else {
             // ---- fused pixel column(s): magnitude_in -> color_for -> put_pixel
             //      (simple_spectrogram.rs:141-161), magnitudes staged in LDS only
-            float2 *m2 = reinterpret_cast<float2 *>(buf);  // [bin - 1]: (l, r), or for mono (frame f0, frame f0 + 1)
-            float2 *vbuf = m2 + 2048;                       // [sample]: the interpolated pair
+            float2 *m2 = reinterpret_cast<float2 *>(buf);  // the padded column [bin]: (l, r), or for mono (frame f0, frame f0 + 1)
+            float2 *vbuf = m2 + kColSlots;                  // [sample]: the interpolated pair
             lds_barrier();  // partner reads done: the buffer can be overwritten
 #pragma unroll
             for (int q3 = 0; q3 < 8; ++q3) {
                 const int k = col + 256 * q3;
-                if (k >= 1) m2[k - 1] = make_float2(ml[q3], mr[q3]);
+                if (k >= 1) m2[k] = make_float2(ml[q3], mr[q3]);
+                if (q3 == 0 && col == 1) m2[0] = make_float2(ml[0], mr[0]);                            // bin 1 again in front
+                if (q3 == 7 && col == 255) m2[kM + 1] = m2[kM + 2] = make_float2(ml[7], mr[7]);      // bin 2047 twice behind
             }
             lds_barrier();
-            if (p.interp == SGX_INTERP_COSINE) sample_pass<true>(p, m2, vbuf, tid);
-            else sample_pass<false>(p, m2, vbuf, tid);
+            sample_pass<PIX>(p, m2, vbuf, tid);
             lds_barrier();
             uchar4 *rgba = reinterpret_cast<uchar4 *>(p.rgba);
             uchar4 *dst_a = rgba + ((size_t)(have_first ? f0 : 0) * p.pairs + p.pair) * (size_t)p.R;
             uchar4 *dst_b = rgba + ((size_t)f1 * p.pairs + p.pair) * (size_t)p.R;
             __builtin_amdgcn_s_setprio(3);
-            row_pass<MONO>(p, row_words, vbuf, dst_a, dst_b, have_first, have_second, pal, tid);
+            row_pass<MONO, PIX>(p, row_words, vbuf, dst_a, dst_b, have_first, have_second, pal, tid);
         }
     }
 }
@@ -391,14 +395,11 @@ hipError_t wg4096_init(sgx_ctx *c, void **out)
     std::vector<uint32_t> rows(c->tab.rows.size());
     std::vector<PackedSample> samples;
     bool fusable = c->tab.rows.size() <= 1024;
-    const int32_t last = (int32_t)c->M - 1;
     auto packed = [&](const SampleEntry &se) {
-        const int32_t x1 = se.i0;
-        // interior: no tap of this sample is clamped at either end of the spectrum
-        const bool interior = c->cfg.interp == SGX_INTERP_COSINE ? !(x1 + 1 > last) : !(x1 < 1 || x1 + 2 > last);
         PackedSample ps;
-        ps.i0 = interior ? x1 : ~x1;
+        ps.i0 = se.i0;   // the taps are slots i0 .. i0 + 3 of the padded column: the clamps at both ends of the spectrum are its repeated end bins
         ps.w = c->cfg.interp == SGX_INTERP_COSINE ? se.w2 : se.w0;
+        if (se.i0 < 0 || se.i0 > (int32_t)c->M - 1) fusable = false;   // (index_of clamps to [0, M - 1]: cannot happen)
         return ps;
     };
     for (size_t i = 0; i < rows.size(); ++i) {
@@ -413,6 +414,11 @@ hipError_t wg4096_init(sgx_ctx *c, void **out)
     if (samples.empty()) samples.push_back(PackedSample{0, 0.0f});
     t->fusable = fusable;
     t->n_samples = (uint32_t)samples.size();
+    for (uint32_t blk = 0; blk < 4; ++blk) {          // blocks of 256 rows whose every row is ONE sample: no loop, no divide in the row pass
+        bool single = true;
+        for (size_t i = 256 * blk; i < 256 * (blk + 1) && i < rows.size(); ++i) single = single && c->tab.rows[i].count == 1;
+        if (single && 256 * blk < rows.size()) t->single_rows |= 1u << blk;
+    }
 
     auto up = [](auto **dst, const auto &v) {
         hipError_t e = hipMalloc(reinterpret_cast<void **>(dst), v.size() * sizeof(v[0]));
@@ -529,6 +535,7 @@ hipError_t launch_wg(const sgx_ctx *c, const void *tables, const float *d_pcm, u
             p.interp = c->cfg.interp;
             lut_seed_coefficients(c, p.guess_a, p.guess_b);
             p.seed_pm1 = wg4096_seed_is_within_one(c) ? 1u : 0u;
+            p.single_rows = t->single_rows;
         }
         // A one-channel stream (include/sgx.h, "Mono streams"): by default at H = 256 every frame its own real-input transform
         // (stft4096_real.hip); SGX_FLAG_PAIRED_FRAMES, other hops and streams that are not 8-byte aligned: two frames per
@@ -549,13 +556,26 @@ hipError_t launch_wg(const sgx_ctx *c, const void *tables, const float *d_pcm, u
         p.jobs_per_block = per;
         const dim3 grid((unsigned)blocks), block(256);
         const size_t lds = RENDER ? kLdsBytesRender : kLdsBytes;
+        // the pixel code of the instantiation: the interpolator and the seed-only LUT search are compile-time (kPixCubic / kPixCosine);
+        // SGX_FLAG_LUT_WALK and palettes whose seed proof fails run kPixGeneric
+        const int pix = !RENDER ? kPixNone : (!p.seed_pm1 ? kPixGeneric : (p.interp == SGX_INTERP_COSINE ? kPixCosine : kPixCubic));
+        auto launch = [&](auto mono_c, auto pairing_c, auto c2_c) {
+            constexpr bool M_ = decltype(mono_c)::value, C2_ = decltype(c2_c)::value;
+            constexpr int P_ = decltype(pairing_c)::value;
+            if (!RENDER) hipLaunchKernelGGL((stft4096_wg_kernel<M_, P_, C2_, kPixNone>), grid, block, lds, c->stream, p);
+            else if (pix == kPixCubic) hipLaunchKernelGGL((stft4096_wg_kernel<M_, P_, C2_, RENDER ? kPixCubic : kPixNone>), grid, block, lds, c->stream, p);
+            else if (pix == kPixCosine) hipLaunchKernelGGL((stft4096_wg_kernel<M_, P_, C2_, RENDER ? kPixCosine : kPixNone>), grid, block, lds, c->stream, p);
+            else hipLaunchKernelGGL((stft4096_wg_kernel<M_, P_, C2_, RENDER ? kPixGeneric : kPixNone>), grid, block, lds, c->stream, p);
+        };
+        using T = std::true_type;
+        using F = std::false_type;
         if (mono) {
-            if (c->H == 256) hipLaunchKernelGGL((stft4096_wg_kernel<true, kPairAdjacentRow, false, RENDER>), grid, block, lds, c->stream, p);
-            else hipLaunchKernelGGL((stft4096_wg_kernel<true, kPairAdjacent, false, RENDER>), grid, block, lds, c->stream, p);
-        } else if (channels == 1) {   // SGX_FLAG_INDEPENDENT_FRAMES: every mono frame as its own (s, s) transform
-            hipLaunchKernelGGL((stft4096_wg_kernel<false, kPairAdjacent, false, RENDER>), grid, block, lds, c->stream, p);
+            if (c->H == 256) launch(T{}, std::integral_constant<int, kPairAdjacentRow>{}, F{});
+            else launch(T{}, std::integral_constant<int, kPairAdjacent>{}, F{});
+        } else if (channels == 1) {   // every mono frame as its own (s, s) transform
+            launch(F{}, std::integral_constant<int, kPairAdjacent>{}, F{});
         } else {
-            hipLaunchKernelGGL((stft4096_wg_kernel<false, kPairAdjacent, true, RENDER>), grid, block, lds, c->stream, p);
+            launch(F{}, std::integral_constant<int, kPairAdjacent>{}, T{});
         }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;

@@ -21,7 +21,7 @@ constexpr size_t kLdsBytes = (size_t)(kBufComplex + 256) * sizeof(float2);
 constexpr size_t kLdsBytesRender = kLdsBytes + 256 * sizeof(uint2);   // + the palette table of pixel_for: {threshold to leave index i, RGBA of index i}
 
 struct PackedSample {
-    int32_t i0;   // cubic: floor(index); cosine: low
+    int32_t i0;   // cubic: floor(index) = x1; cosine: low.  The taps are the slots i0 .. i0 + 3 (cubic) / i0 + 1, i0 + 2 (cosine) of the padded column
     float w;      // cubic: mu;           cosine: o' (the cosine-eased offset)
 };
 
@@ -46,6 +46,7 @@ struct Params {
     uint32_t R, interp;
     float guess_a, guess_b;    // LUT index ~ floor(log2(power + 1e-7) * a + b), then exact fix-up
     uint32_t seed_pm1;         // the host has shown that this seed is never off by more than one (seed_within_one): one compare pair fixes it
+    uint32_t single_rows;      // bit i: every row of block i (rows 256 i .. 256 i + 255) averages exactly one sample
     // the real-input kernel (stft4096_real.hip: every mono frame its own transform; tw1 is then [8][256] w_2048^{t q1})
     const float2 *twu;         // [8][128] w_4096^{u + 128 q3} at [q3][u]; [0][0] holds w_4096^{1024} = -i
     unsigned long long stream_samples;   // samples the frames of the stream cover: columns past them read as zero
@@ -69,6 +70,7 @@ struct WgTables {
     uint32_t *d_rows = nullptr;        // packed row table for the fused pixel path
     PackedSample *d_samples = nullptr;
     uint32_t n_samples = 0;
+    uint32_t single_rows = 0;          // Params::single_rows
     bool fusable = false;
     mutable float *d_planes = nullptr;   // more than two channels: (l, r) pair planes of the sample range of a call, grown on demand
     mutable size_t planes_floats = 0;
@@ -131,29 +133,33 @@ __device__ __forceinline__ void store_row(char *mags, long long row_byte, int co
 //                thresholds, LUT, pixel store (coalesced: consecutive lanes, consecutive image rows).  A row's slots
 //                start at an odd distance from the previous row's where the count is even (pad slots, host table
 //                only): 32 consecutive rows of 8 samples then touch 32 different bank pairs instead of 4
-// Sample word: i0 >= 0: no tap touches the ends of the spectrum (taps are contiguous bins, the saturating index
-// arithmetic of interpolated_frequency_sample.rs:89-105 is skipped); i0 < 0: ~i0 is the index, taps are clamped.
-constexpr int kMaxFusedSamples = (kBufComplex - 2048);  // float2 per sample behind the 2048-bin column (2304)
+// The column in LDS (round 4): P[k] = bin k (k = 1 .. 2047, i.e. data[k - 1] of interpolated_frequency_sample.rs), with the end bins
+// REPEATED around it -- P[0] = bin 1, P[2048] = P[2049] = bin 2047 -- so that the saturating index arithmetic of :89-105
+// (x0 = max(x1 - 1, 0), x2 / x3 = min(x1 + 1 / 2, M - 1)) is a plain read of four CONTIGUOUS slots P[x1 .. x1 + 3] for every sample:
+// no clamped variant, no branch per sample, two ds_read2_b64 per cubic sample (one per cosine sample: P[lo + 1], P[lo + 2]).
+constexpr int kColSlots = 2050;                                 // slots of the padded column
+constexpr int kMaxFusedSamples = kBufComplex - kColSlots;       // float2 per sample behind it (2302)
+// which pixel code an instantiation carries: the launch-uniform switches -- the interpolator, the LUT search -- are compile-time,
+// each instantiation holds one path's code and live ranges
+constexpr int kPixNone = 0, kPixCubic = 1, kPixCosine = 2, kPixGeneric = 3;   // kPixGeneric: interpolator at run time, LUT seed + walk (SGX_FLAG_LUT_WALK / proof failed)
 
-template <bool COSINE, bool INTERIOR>
-__device__ __forceinline__ float2 interp_sample2(const float2 *m2, int i0, float w, int last)
+// (The repeats are written by the ONE thread that holds bin 1 / bin 2047, in the one unrolled step where it does -- a test of the
+// bin index in every step of every thread kept sixteen compares' worth of values alive and spilled 14 registers.)
+
+template <bool COSINE>
+__device__ __forceinline__ float2 interp_sample2(const float2 *P, int i0, float w)
 {
     float2 v;
     if (COSINE) {
-        // :79-86  data[low] * (1 - o') + data[high] * o'
-        const int lo = i0, hi = INTERIOR ? lo + 1 : (lo + 1 < last ? lo + 1 : last);
+        // :79-86  data[low] * (1 - o') + data[high] * o',  high = min(low + 1, M - 1)
         const float w1 = 1.0f - w;
-        const float2 a = m2[lo], b = m2[hi];
+        const float2 a = P[i0 + 1], b = P[i0 + 2];
         v.x = a.x * w1 + b.x * w;
         v.y = a.y * w1 + b.y * w;
     } else {
         // :89-105
-        const int x1 = i0;
-        const int x0 = INTERIOR ? x1 - 1 : (x1 > 0 ? x1 - 1 : 0);
-        const int x2 = INTERIOR ? x1 + 1 : (x1 + 1 < last ? x1 + 1 : last);
-        const int x3 = INTERIOR ? x1 + 2 : (x1 + 2 < last ? x1 + 2 : last);
         const float mu = w, mu2 = mu * mu, mu3 = mu * mu2;
-        const float2 y0 = m2[x0], y1 = m2[x1], y2 = m2[x2], y3 = m2[x3];
+        const float2 y0 = P[i0], y1 = P[i0 + 1], y2 = P[i0 + 2], y3 = P[i0 + 3];
         {
             const float a0 = ((y3.x - y2.x) - y0.x) + y1.x;
             const float a1 = (y0.x - y1.x) - a0;
@@ -171,9 +177,8 @@ __device__ __forceinline__ float2 interp_sample2(const float2 *m2, int i0, float
 }
 
 template <bool COSINE>
-__device__ __forceinline__ void sample_pass(const Params &p, const float2 *m2, float2 *vbuf, int tid)
+__device__ __forceinline__ void sample_pass_for(const Params &p, const float2 *P, float2 *vbuf, int tid)
 {
-    const int last = kM - 1;
     // the table word of the next step is requested before this step's gathers: one L1 latency per step is
     // overlapped instead of exposed (two registers; deeper unrolling costs more registers than these kernels have)
     // (the table through a buffer descriptor: a uniform base + a 32-bit lane offset, no per-lane 64-bit pointer to keep)
@@ -187,78 +192,96 @@ __device__ __forceinline__ void sample_pass(const Params &p, const float2 *m2, f
     while (s < p.n_samples) {
         const uint32_t s_next = s + 256;
         const PackedSample se_next = item(s_next);
-        vbuf[s] = se.i0 >= 0 ? interp_sample2<COSINE, true>(m2, se.i0, se.w, last)
-                             : interp_sample2<COSINE, false>(m2, ~se.i0, se.w, last);
+        vbuf[s] = interp_sample2<COSINE>(P, se.i0, se.w);
         se = se_next;
         s = s_next;
     }
 }
 
+template <int PIX>
+__device__ __forceinline__ void sample_pass(const Params &p, const float2 *P, float2 *vbuf, int tid)
+{
+    if (PIX == kPixCosine || (PIX == kPixGeneric && p.interp == SGX_INTERP_COSINE)) sample_pass_for<true>(p, P, vbuf, tid);
+    else sample_pass_for<false>(p, P, vbuf, tid);
+}
+
 // colorscheme.rs:59-61 as a threshold count: the LUT index is the number of thresholds the power has reached, the
 // thresholds being the exact switch points of the host's float32 evaluation (sgx_tables.cpp).  v_log_f32 only SEEDS the
 // count.  pal[i] = {the smallest power whose index is i + 1 (NaN for i = 255: no power leaves the last index), RGBA of i}.
-//   seed_pm1 (the usual case): the host has checked, threshold by threshold, that the exact value u the seed approximates
-//     lies within half an index of the count at every switch point (seed_within_one), so floor(u - 1/2) is the count or
-//     one below it: ONE 16-byte LDS access brings that entry's threshold and both candidate colours, one compare picks.
-//     No loop, no second (dependent) LDS access for the colour.  (A NaN power: the seed is 0 and the compare fails ->
-//     index 0, as the walk below gives.)
-//   otherwise (unreachable levels, SGX_FLAG_LUT_WALK): walk from the seed, as the first version of this kernel did.
-__device__ __forceinline__ uchar4 pixel_for(const Params &p, float l, float r, const uint2 *pal)
+//   seed_pm1 (the usual case; the only code of kPixCubic / kPixCosine): the host has checked, threshold by threshold, that the
+//     exact value u the seed approximates lies within half an index of the count at every switch point (seed_within_one), so
+//     floor(u - 1/2) is the count or one below it: ONE 16-byte LDS access brings that entry's threshold and both candidate
+//     colours, one compare picks.  No loop, no second (dependent) LDS access for the colour.  (A NaN power: the seed is 0 and
+//     the compare fails -> index 0, as the walk below gives.)
+//   otherwise (unreachable levels, SGX_FLAG_LUT_WALK; kPixGeneric): walk from the seed, as the first version of this kernel did.
+template <int PIX>
+__device__ __forceinline__ uint32_t pixel_for(const Params &p, float l, float r, const uint2 *pal)
 {
     const float power = (l * l) + (r * r);
     const float u = fmaf(__builtin_amdgcn_logf(power + 1e-7f), p.guess_a, p.guess_b);
-    uint32_t rgba;
-    if (p.seed_pm1) {
+    if (PIX != kPixGeneric || p.seed_pm1) {
         int idx = (int)floorf(u - 0.5f);
         idx = idx < 0 ? 0 : (idx > 254 ? 254 : idx);
         const uint2 e0 = pal[idx], e1 = pal[idx + 1];
-        rgba = power >= __uint_as_float(e0.x) ? e1.y : e0.y;
-    } else {
-        int idx = (int)floorf(u);
-        idx = idx < 0 ? 0 : (idx > 255 ? 255 : idx);
-        while (idx < 255 && power >= __uint_as_float(pal[idx].x)) ++idx;
-        while (idx > 0 && !(power >= __uint_as_float(pal[idx - 1].x))) --idx;
-        rgba = pal[idx].y;
+        return power >= __uint_as_float(e0.x) ? e1.y : e0.y;      // RGBA, alpha = 1.0 -> 255
     }
-    uchar4 c;
-    c.x = rgba & 0xff; c.y = (rgba >> 8) & 0xff; c.z = (rgba >> 16) & 0xff; c.w = rgba >> 24;   // alpha = 1.0 -> 255
-    return c;
+    int idx = (int)floorf(u);
+    idx = idx < 0 ? 0 : (idx > 255 ? 255 : idx);
+    while (idx < 255 && power >= __uint_as_float(pal[idx].x)) ++idx;
+    while (idx > 0 && !(power >= __uint_as_float(pal[idx - 1].x))) --idx;
+    return pal[idx].y;
 }
 
 bool seed_within_one(const std::vector<float> &lut_thr, double guess_a, double guess_b);
 
 // MONO: .x / .y of a sample are the two columns (frames) of the transform, each a (s, s) pixel; else one (l, r) pixel.
+// A thread renders the same four rows tid + 256 i of every column: the loop over i is unrolled, the rows' table words are registers
+// by name.  p.single_rows bit i: EVERY row of block i (rows 256 i .. 256 i + 255) is one sample -- 743 of the 1024 rows at 48 kHz,
+// blocks 0 and 1 whole -- and the block runs without the sample loop, the count test and the divide.
 // (Tried, same-device A/B: the thread's sample-table words and row words requested before the two barriers and the
 // loops unrolled (9 samples, 4 rows side by side, thresholds read four at a time): 182 -> 131 M frames/s -- these
 // kernels sit at the 128-VGPR cap of four waves per SIMD and every extra live value becomes scratch traffic.)
-template <bool MONO>
+template <bool MONO, int PIX>
 __device__ __forceinline__ void row_pass(const Params &p, const uint32_t (&row_words)[4], const float2 *vbuf, uchar4 *dst_a, uchar4 *dst_b,
                                          bool have_a, bool have_b, const uint2 *pal, int tid)
 {
-    int i_row = 0;
-    for (uint32_t py = tid; py < p.R; py += 256, ++i_row) {
-        // a thread renders the same rows (tid + 256 i) of every column: their table words stay in registers (R <= 1024)
+    uint32_t *out_a = reinterpret_cast<uint32_t *>(dst_a), *out_b = reinterpret_cast<uint32_t *>(dst_b);
+#pragma unroll 1
+    for (int i_row = 0; i_row < 4; ++i_row) {
+        const uint32_t py = tid + 256 * i_row;
+        if (py >= p.R) break;
         const uint32_t re = i_row == 0 ? row_words[0] : i_row == 1 ? row_words[1] : i_row == 2 ? row_words[2] : row_words[3];
         const uint32_t first = re & 0xffffu, cnt = re >> 16;
-        float sl = 0.0f, sr = 0.0f;  // Complex::sum starts at zero
-        for (uint32_t i = 0; i < cnt; ++i) {
-            const float2 v = vbuf[first + i];
-            sl = sl + v.x;
-            sr = sr + v.y;
-        }
-        float l = sl, r = sr;
-        if (cnt > 1) {  // x / 1.0 == x: only rows that average several samples divide (:72)
-            const float nf = (float)cnt;
-            l = sl / nf;
-            r = sr / nf;
+        float l, r;
+        if (p.single_rows & (1u << i_row)) {          // (launch-uniform)
+            const float2 v = vbuf[first];
+            l = v.x;                                   // (0 + x and x / 1.0 are x -- but for the sign of a zero, and only l * l + r * r is used)
+            r = v.y;
+        } else {
+            float sl = 0.0f, sr = 0.0f;
+            for (uint32_t i = 0; i < cnt; ++i) {
+                const float2 v = vbuf[first + i];
+                sl = sl + v.x;
+                sr = sr + v.y;
+            }
+            l = sl;
+            r = sr;
+            if (cnt > 1) {  // x / 1.0 == x: only rows that average several samples divide (:72)
+                const float nf = (float)cnt;
+                l = sl / nf;
+                r = sr / nf;
+            }
         }
         const uint32_t y = p.R - 1 - py;  // simple_spectrogram.rs:150
         if (MONO) {  // mono -> (s, s): both channels carry the same magnitude
-            if (have_a) dst_a[y] = pixel_for(p, l, l, pal);
-            if (have_b) dst_b[y] = pixel_for(p, r, r, pal);
+            if (have_a) out_a[y] = pixel_for<PIX>(p, l, l, pal);
+            if (have_b) out_b[y] = pixel_for<PIX>(p, r, r, pal);
         } else {
-            dst_a[y] = pixel_for(p, l, r, pal);
+            out_a[y] = pixel_for<PIX>(p, l, r, pal);
         }
+        // one row at a time: without this fence the scheduler interleaves the four unrolled rows, and the kernels -- at the 128-VGPR cap
+        // of four waves per SIMD -- spill 15 to 34 registers
+        asm volatile("" ::: "memory");
     }
 }
 

@@ -77,7 +77,7 @@ __global__ void __launch_bounds__(256, 4) stft4096_wgp_kernel(Params p)
     // per-thread constants, kept in registers for the life of the (persistent) workgroup
     float win[8];
 #pragma unroll
-#endif
+    for (int a = 0; a < 8; ++a) win[a] = p.window[tid + 256 * a];
     f2v tw1[16];
 #pragma unroll
     for (int q = 1; q < 16; ++q) { const float2 t = p.tw1[q * 256 + tid]; tw1[q] = f2v{t.x, t.y}; }
@@ -243,21 +243,22 @@ __global__ void __launch_bounds__(256, 4) stft4096_wgp_kernel(Params p)
             // ---- fused pixel column(s): magnitude_in -> color_for -> put_pixel
             //      (simple_spectrogram.rs:141-161), magnitudes staged in LDS only
             float2 *m2 = reinterpret_cast<float2 *>(buf);  // [bin - 1]: (l, r), or for mono (frame f0, frame f0 + 1)
-            float2 *vbuf = m2 + 2048;                       // [sample]: the interpolated pair
+            float2 *vbuf = m2 + kColSlots;                  // [sample]: the interpolated pair
             lds_barrier();  // partner reads done: the buffer can be overwritten
 #pragma unroll
             for (int q3 = 0; q3 < 8; ++q3) {
                 const int k = col + 256 * q3;
-                if (k >= 1) m2[k - 1] = make_float2(ml[q3], mr[q3]);
+                if (k >= 1) m2[k] = make_float2(ml[q3], mr[q3]);
+                if (q3 == 0 && col == 1) m2[0] = make_float2(ml[0], mr[0]);                            // bin 1 again in front
+                if (q3 == 7 && col == 255) m2[kM + 1] = m2[kM + 2] = make_float2(ml[7], mr[7]);      // bin 2047 twice behind
             }
             lds_barrier();
-            if (p.interp == SGX_INTERP_COSINE) sample_pass<true>(p, m2, vbuf, tid);
-            else sample_pass<false>(p, m2, vbuf, tid);
+            sample_pass<kPixGeneric>(p, m2, vbuf, tid);   // (the A/B twin keeps the run-time switches)
             lds_barrier();
             uchar4 *rgba = reinterpret_cast<uchar4 *>(p.rgba);
             uchar4 *dst_a = rgba + ((size_t)(have_first ? f0 : 0) * p.pairs + p.pair) * (size_t)p.R;
             uchar4 *dst_b = rgba + ((size_t)f1 * p.pairs + p.pair) * (size_t)p.R;
-            row_pass<MONO>(p, row_words, vbuf, dst_a, dst_b, have_first, have_second, pal, tid);
+            row_pass<MONO, kPixGeneric>(p, row_words, vbuf, dst_a, dst_b, have_first, have_second, pal, tid);
         }
     }
 }
@@ -307,6 +308,7 @@ hipError_t launch_wgp(const sgx_ctx *c, const void *tables, const float *d_pcm, 
             p.guess_a = (float)(10.0 * log10(2.0) * n / span);
             p.guess_b = (float)(-(double)c->cfg.min_db * n / span + (c->cfg.lut_index_mode == SGX_LUT_ROUND_NM1 ? 0.5 : 0.0));
             p.seed_pm1 = wg4096_seed_is_within_one(c) ? 1u : 0u;
+            p.single_rows = t->single_rows;
         }
         // mono normally rides two frames per transform; SGX_FLAG_INDEPENDENT_FRAMES runs it as (s, s) pairs
         const bool mono = channels == 1 && !(c->cfg.flags & SGX_FLAG_INDEPENDENT_FRAMES);
