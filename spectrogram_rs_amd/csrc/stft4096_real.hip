@@ -238,11 +238,9 @@ __global__ void __launch_bounds__(256, 4) stft4096_real_kernel(Params p)
         }
         fft16(xr, xi);
 
-        // the load of the NEXT iteration (its R[9]), ahead of this iteration's stores (vmcnt retires in issue order) and a whole
-        // iteration ahead of its use.  Unconditional (a conditional request keeps the old value alive around the loop); past the end
-        // of the stream it reads zeros.
-        // (The fused pixel path requests it at the END of the iteration instead: its few pixel stores are no queue to wait behind, and
-        // two registers fewer are live through the pixel passes -- with them the kernel spilled.)
+        // ---- rows: the load of the NEXT iteration (its R[9]), ahead of this iteration's stores (vmcnt retires in issue order), into a
+        // second register pair -- L is still needed for the exchange.  Unconditional (a conditional request keeps the old value alive
+        // around the loop); past the end of the stream it reads zeros.
         float2 Ln = make_float2(0.0f, 0.0f);
         if (MODE != kPixels) Ln = column(columns_from(128 * (fa + 2) + 1152), 0);
 
@@ -331,18 +329,21 @@ __global__ void __launch_bounds__(256, 4) stft4096_real_kernel(Params p)
             }
             lds_barrier();
             wg::sample_pass<PIX>(p, mpair, vbuf, tid);
+            // the fused pixel path requests the next iteration's load HERE, straight into L (dead since the slide): requested in front
+            // of the exchange like the rows' it is two more live registers through the sample pass -- two spills, and a spill reload
+            // is a vector-memory load the compiler waits for with vmcnt(0), this load included (same device: 3.79 -> 3.68 ms)
+            L = column(columns_from(128 * (fa + 2) + 1152), 0);
             lds_barrier();
             uchar4 *rgba = reinterpret_cast<uchar4 *>(p.rgba);
             __builtin_amdgcn_s_setprio(3);
             wg::row_pass<true, PIX>(p, row_words, vbuf, rgba + la * (size_t)p.R, rgba + lb * (size_t)p.R, true, have_b, pal, tid);
         }
-        // ---- the next iteration's own load.  Rows: `Ln` is pinned behind the stores -- its copy into L needs the load complete, and
-        // scheduled in front of the stores (where the compiler had put it) that is a vmcnt(0) in the middle of the iteration
         if (MODE != kPixels) {
+            // `Ln` is pinned behind the row stores: its copy into L needs the load complete, and scheduled in front of the stores (where
+            // the compiler had put it) that is a vmcnt(0) in the middle of the iteration; here it is vmcnt(stores since).  (The load
+            // straight into L behind the slide, no second pair: 4 % slower on the same device.)
             asm volatile("" : "+v"(Ln.x), "+v"(Ln.y));
             L = Ln;
-        } else {
-            L = column(columns_from(128 * (fa + 2) + 1152), 0);
         }
     }
 }
