@@ -165,15 +165,15 @@ __global__ void __launch_bounds__(1024, 1) stft16384_d_kernel(Params p)
     // order, so a load issued behind the stores would wait for every one of them to be acknowledged.
     float pl[8], pr[8];
     struct JobIn { const float *base; bool data_second; };   // base: wave-uniform
-    auto job_in = [&](unsigned long long job) {
+    // (hop, pair) of a job: job = hop * pairs + pair.  Carried along the loop -- one 64-bit division at the start; `job / p.pairs`
+    // inside `job_in` and at the loop head was two software divisions, ~220 scalar instructions, per transform and wave
+    auto job_in = [&](unsigned long long job, unsigned long long hop, uint32_t pair) {
         JobIn j{nullptr, true};
         if (MONO) {
             const unsigned long long f = 2 * (p.pair_base + job);
             j.data_second = f + 1 < p.total_frames;
             j.base = p.pcm + ((long long)(f * p.H) - p.sample_base);
         } else {
-            const unsigned long long hop = job / p.pairs;
-            const uint32_t pair = (uint32_t)(job - hop * p.pairs);
             j.base = p.pcm + (size_t)pair * p.plane_floats + 2 * ((long long)((p.first_frame + hop) * p.H) - p.sample_base);
         }
         return j;
@@ -211,7 +211,11 @@ __global__ void __launch_bounds__(1024, 1) stft16384_d_kernel(Params p)
             er[a] = pl[a] * win[a];
             ei[a] = (MONO && !data_second) ? 0.0f : pr[a] * win[a];
         }
-
+        // ... and PINNED there: the products are plain arithmetic, and the compiler sank them into the head of the next iteration,
+        // behind its row stores (`flush`, under branches it cannot count through) -- where the wait for the samples became vmcnt(5) ..
+        // vmcnt(0): every transform waited for the previous one's stores after all (round 4, read off the ISA)
+#pragma unroll
+        for (int a = 0; a < 8; ++a) asm volatile("" : "+v"(er[a]), "+v"(ei[a]));
     };
     // Job order.  Jobs are hop-major (the pairs of one hop position, then the next hop) and consecutive hop positions share
     // 15/16 of their samples.  Workgroup i runs on XCD i % 8 (MI355X in SPX mode: kXcdHint), each XCD has its own L2: every XCD
@@ -224,8 +228,12 @@ __global__ void __launch_bounds__(1024, 1) stft16384_d_kernel(Params p)
     const unsigned long long job_step = gridDim.x / nx;
     const unsigned long long job_begin = xcd * p.jobs_per_xcd + local;
     const unsigned long long job_end = (xcd + 1) * p.jobs_per_xcd < p.n_jobs ? (xcd + 1) * p.jobs_per_xcd : p.n_jobs;
+    unsigned long long hop_c = MONO ? 0 : job_begin / p.pairs;                           // (hop, pair) of the current job
+    uint32_t pair_c = MONO ? 0 : (uint32_t)(job_begin - hop_c * p.pairs);
+    const unsigned long long step_hops = MONO ? 0 : job_step / p.pairs;                  // ... and of one step of the loop
+    const uint32_t step_pairs = MONO ? 0 : (uint32_t)(job_step - step_hops * p.pairs);
     if (job_begin < job_end) {
-        const JobIn first = job_in(job_begin);
+        const JobIn first = job_in(job_begin, hop_c, pair_c);
         prefetch(first);
         take(first.data_second);
     }
@@ -271,12 +279,17 @@ __global__ void __launch_bounds__(1024, 1) stft16384_d_kernel(Params p)
             have_first = f0 >= 0;
             have_second = f1 < (long long)p.n_frames;
         } else {
-            f0 = (long long)(job / p.pairs);
+            f0 = (long long)hop_c;
             f1 = f0;
-            pair = (uint32_t)(job - (unsigned long long)f0 * p.pairs);
+            pair = pair_c;
         }
         const bool more = job + job_step < job_end;
-        const JobIn nxt = job_in(more ? job + job_step : job);
+        if (!MONO && more) {   // the next job's (hop, pair)
+            pair_c += step_pairs;
+            hop_c += step_hops;
+            if (pair_c >= p.pairs) { pair_c -= p.pairs; hop_c += 1; }
+        }
+        const JobIn nxt = job_in(more ? job + job_step : job, hop_c, pair_c);
 
         // ---- Hann (fft.rs:53-63) on the prefetched samples; pass 1: 16-point DFT over a, inputs a >= 8 are the zero padding:
         //      even q1 = FFT8(z), odd q1 = FFT8(z * w_16^a)                                        (as stft4096_wg.hip)
