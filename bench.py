@@ -175,7 +175,7 @@ def csrc_sha16():
     import hashlib
     h = hashlib.sha256()
     for path in sorted(glob.glob(os.path.join(ROOT, "spectrogram_rs_amd", "csrc", "*.*"))):
-        if path.endswith((".hip", ".hpp", ".inc", ".cpp")):
+        if path.endswith((".hip", ".hpp", ".inc", ".cpp")) and not os.path.basename(path).startswith("ab_"):   # (ab_*: patched copies of A/B tools)
             with open(path, "rb") as f:
                 h.update(os.path.basename(path).encode() + b"\0" + f.read())
     return h.hexdigest()[:16]
