@@ -66,9 +66,9 @@ KERNEL_NAMES = {
     0: ("generic power-of-two (workgroup per frame, LDS radix-4)", "sgx::stft_generic_kernel"),
     1: ("stft4096 wave-per-transform", "sgx::stft4096_kernel<6, true>"),
     2: ("stft4096 workgroup-per-transform (256 threads x 16 points, radix-16 x3, mono frame pairs), scalar codelets",
-        "sgx::wg::stft4096_wg_kernel<true, 0, false, false>"),
+        "sgx::wg::stft4096_wg_kernel<true, 0, false, 0>"),
     "real": ("stft4096 real-input: every mono frame its own transform, a 2048-point complex transform of the real frame + one butterfly per bin "
-             "(256 threads x 2 frames x 8 points, radix 8 x 16 x 16, sliding half-row window)", "sgx::wgr::stft4096_real_kernel<0, false>"),
+             "(256 threads x 2 frames x 8 points, radix 8 x 16 x 16, sliding half-row window)", "sgx::wgr::stft4096_real_kernel<0, 0>"),
     3: ("stft4096 workgroup-per-transform (256 threads x 16 points, radix-16 x3, mono frame pairs), packed (re, im) codelets",
         "sgx::wgp::stft4096_wgp_kernel<true, 0, false, false>"),
     5: ("stft16384 as four 4096-point residues (512 threads = 256 lane pairs, DPP decimation)", "sgx::q16k::stft16384_q_kernel<false, true>"),
@@ -451,11 +451,11 @@ def main_rank(args):
             if args.paired_frames > 0:
                 extra["mono_paired_frames"] = mono_mode_leg(args, torch, local_rank, args.paired_frames, dict(paired_frames=True),
                                                             "two frames per transform (SGX_FLAG_PAIRED_FRAMES: the headline mode of rounds 1-3)",
-                                                            "sgx::wg::stft4096_wg_kernel<true, 0, false, false>")
+                                                            "sgx::wg::stft4096_wg_kernel<true, 0, false, 0>")
             if args.complex_frames > 0:
                 extra["mono_complex_frames"] = mono_mode_leg(args, torch, local_rank, args.complex_frames, dict(complex_mono=True),
                                                              "every frame the literal (s, s) 4096-point transform (SGX_FLAG_COMPLEX_MONO; fft.rs:47-57)",
-                                                             "sgx::wg::stft4096_wg_kernel<false, 1, false, false>")
+                                                             "sgx::wg::stft4096_wg_kernel<false, 1, false, 0>")
             if args.app_frames > 0:
                 extra["app_point"] = app_point_leg(args, torch, local_rank)
         elif args.config5_frames > 0:
@@ -637,7 +637,7 @@ def config3_leg(args, torch, eng, pcm, F):
             "bytes_per_frame": ALGO_BYTES_PIXEL, "frames_per_launch": Fp,
             "traffic": ((traffic or {}).get("pixel_bytes_per_frame") or 0) * Fp or None,
             "traffic_source": (traffic or {}).get("source"),
-            "kernel": "sgx::wgr::stft4096_real_kernel<2, true>" if eng.info.render_path & 8 else "sgx::wg::stft4096_wg_kernel<true, 0, false, true>",
+            "kernel": "sgx::wgr::stft4096_real_kernel<2, 2>" if eng.info.render_path & 8 else "sgx::wg::stft4096_wg_kernel<true, 0, false, 2>",
             "mono_mode": "every frame its own transform" if eng.info.render_path & 8 else "two frames per transform",
             "binding_pipe": pipes,
             "note": "48 flop per algorithmic byte: above the FP32 ridge (19.7), so the HBM fraction is low by construction; "
@@ -692,7 +692,7 @@ def stereo_leg(args, torch, device):
         "frames_per_s": Fs / (mean * 1e-3), **leg_times(m),
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "bytes_per_frame": ALGO_BYTES_STEREO, "frames_per_launch": Fs,
-                     "kernel": "sgx::wg::stft4096_wg_kernel<false, 1, true, false>",
+                     "kernel": "sgx::wg::stft4096_wg_kernel<false, 1, true, 0>",
                      "first_allocation": first_allocation_of(torch, first, m, lambda buf: eng.stft_batch(pcm, out=buf), Fs * ALGO_BYTES_STEREO, args),
                      "placement": placement,
                      "note": "bound by the transform rate of the kernel (LDS exchanges + vector issue, DESIGN section 4 K1), not by HBM"},
