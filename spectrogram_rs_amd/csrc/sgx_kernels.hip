@@ -209,14 +209,18 @@ __device__ __forceinline__ uchar4 color_for(const RenderParams &p, const float *
 {
     // colorscheme.rs:59: norm_sqr = l*l + r*r, then the dB ramp as a threshold count
     const float power = (l * l) + (r * r);
-    uchar4 px;
+    // (the pixel as ONE 32-bit word, alpha in its top byte: as a uchar4 whose .w is overwritten the compiler copied the other three bytes
+    // of p.nan_rgba through scratch -- 8 bytes of private segment in every kernel of this file that can reach this function)
+    const uint32_t *lutw = reinterpret_cast<const uint32_t *>(lut);
+    const uint32_t nanw = (uint32_t)p.nan_rgba.x | ((uint32_t)p.nan_rgba.y << 8) | ((uint32_t)p.nan_rgba.z << 16);
+    uint32_t px;
     if (p.stereo) {
         // :63-66
         const float l1 = fabsf(l) + fabsf(r);
         const double t = (double)l / (double)l1;
         if (p.segments) {
             if (t != t) {
-                px = p.nan_rgba;
+                px = nanw;
             } else {
                 uint32_t lo = 0, hi = p.n_lut - 1;  // number of switch points <= t
                 if (tcell) {   // the cells below t's hold switch points t has passed, the cells above it ones it has not
@@ -229,28 +233,32 @@ __device__ __forceinline__ uchar4 color_for(const RenderParams &p, const float *
                     if (t >= tthr[mid]) lo = mid + 1;
                     else hi = mid;
                 }
-                px = lut[lo];
+                px = lutw[lo];
             }
         } else {
             double x = (p.lut_mode == SGX_LUT_ROUND_NM1) ? floor(t * (double)(p.n_lut - 1) + 0.5) : floor(t * (double)p.n_lut);
             uint32_t idx = 0;
             if (x > 0.0) idx = x >= (double)p.n_lut ? p.n_lut - 1 : (uint32_t)x;
-            px = lut[idx];
+            px = lutw[idx];
         }
+        uint32_t alpha;
         if (p.alpha_seed) {   // the seed proof holds on the alpha table (launch_render): one read and one compare instead of eight
             const float ua = fmaf(__builtin_amdgcn_logf(power + 1e-7f), p.guess_a, p.guess_b);
             int ia = (int)floorf(ua - 0.5f);
             ia = ia < 0 ? 0 : (ia > 254 ? 254 : ia);
-            px.w = (unsigned char)((uint32_t)ia + (power >= athr[ia] ? 1u : 0u));
+            alpha = ((uint32_t)ia + (power >= athr[ia] ? 1u : 0u)) & 0xffu;
         } else {
-            px.w = (unsigned char)count_reached(athr, 255, power);  // (alpha * 255.0) as u8, simple_spectrogram.rs:159
+            alpha = count_reached(athr, 255, power) & 0xffu;  // (alpha * 255.0) as u8, simple_spectrogram.rs:159
         }
+        px = (px & 0x00ffffffu) | (alpha << 24);
     } else {
         // :67-70; alpha = 1.0 -> 255
-        px = (p.segments && power != power) ? p.nan_rgba : lut[count_reached(thr, p.n_lut - 1, power)];
-        px.w = 255;
+        px = (p.segments && power != power) ? nanw : lutw[count_reached(thr, p.n_lut - 1, power)];
+        px |= 0xff000000u;
     }
-    return px;
+    uchar4 out;
+    out.x = px & 0xff; out.y = (px >> 8) & 0xff; out.z = (px >> 16) & 0xff; out.w = px >> 24;
+    return out;
 }
 
 // Replaces the body of `for py in 0..buffer.height()` (simple_spectrogram.rs:141-161).
