@@ -60,8 +60,9 @@ if __name__ == "__main__" and "--chirp" in sys.argv:
     sys.exit(0)
 
 if __name__ == "__main__":
-    run("K1 mono (frame pairs)", 2048, 256, 1)
-    run("K1 mono independent", 2048, 256, 1, independent_frames=True)
+    run("K1R mono (default: every frame its own real-input transform)", 2048, 256, 1)
+    run("K1 mono (frame pairs)", 2048, 256, 1, paired_frames=True)
+    run("K1 mono ((s, s) transform per frame)", 2048, 256, 1, complex_mono=True)
     run("K1 stereo", 2048, 256, 2)
     run("K16 stereo (lane quad, round 3)", 8192, 512, 2, frames=8)
     run("K16 stereo (four residues, round 2)", 8192, 512, 2, frames=8, residue_16k=True)
