@@ -4,6 +4,9 @@
 # never combined with tracing on this pool); then tools/pmc_lds.py over every pass
 tag=$1; shift
 repo=$(cd "$(dirname "$0")/.." && pwd)
+script=$1; shift
+case $script in /*) ;; *) script=$PWD/$script;; esac     # (pmc_cmd.sh runs the command from /tmp)
+set -- "$script" "$@"
 i=0
 for grp in "SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_WAIT_INST_ANY" \
