@@ -240,7 +240,8 @@ __global__ void __launch_bounds__(256, 4) stft4096_real_kernel(Params p)
 
         // ---- rows: the load of the NEXT iteration (its R[9]), ahead of this iteration's stores (vmcnt retires in issue order), into a
         // second register pair -- L is still needed for the exchange.  Unconditional (a conditional request keeps the old value alive
-        // around the loop); past the end of the stream it reads zeros.
+        // around the loop); past the end of the stream it reads zeros.  (Requested at the TOP of the iteration instead -- a whole
+        // iteration to return in -- it sits right behind the previous iteration's sixteen stores: 5-7 % slower, same device.)
         float2 Ln = make_float2(0.0f, 0.0f);
         if (MODE != kPixels) Ln = column(columns_from(128 * (fa + 2) + 1152), 0);
 
