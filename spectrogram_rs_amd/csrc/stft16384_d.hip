@@ -121,10 +121,18 @@ __device__ __forceinline__ void store16(u32x4 v, __amdgpu_buffer_rsrc_t r, int v
 #define D_STORE_OK(v) true
 #endif
 
-// Position of slot i of the staged row.  The lanes of a wave write bins 16 apart (u = q1 + 16 q2) and would meet in two banks; bits
-// 4..6 of the slot index folded into bits 1..3 spread them over sixteen (pairs of slots stay together: the row leaves as 16-byte reads
-// of two consecutive bins, and eight consecutive readers permute among themselves).
-__device__ __forceinline__ int stage_slot(int i) { return i ^ (((i >> 4) & 7) << 1); }
+// The staged row (round 4): EVEN bins (0-based) in one 32 KB region, ODD bins in a second one kRegion slots on, bin b at index b >> 1 of
+// its region -- so that the two bins a lane takes back as one 16-byte store come from the same index of the two regions (one
+// ds_read2st64_b64) whatever the index map -- and the index swizzled for the WRITES: a wave holds bins u = q1 + 16 q2 of ONE parity in
+// four parts of the row 2048 bins apart, i.e. sixteen lanes = (q2 & 3) x (part): index bits 3, 4 and 10, 11.  Bit 4 folded onto bit 2
+// and bits 10, 11 onto bits 0, 1 give the sixteen lanes sixteen different bank pairs; thirty-two consecutive readers permute among
+// themselves.  (Round 3 kept neighbouring bins in neighbouring slots for a 16-byte read-back and swizzled around that: with one parity per
+// wave that can do no better than 2-way on the writes; it did 3-way, the read-back 2-way -- the two sources, with the odd special case of
+// wave 0's partner reads, of the 12 % of LDS cycles SQ_LDS_BANK_CONFLICT counted; the three FFT exchanges and the partner exchange are
+// conflict-free under the bank rules of profiles/r04_k1_wg5_bound.txt.)
+constexpr int kRegion = 4096;   // float2 slots per parity region: 32 768 B = 64 x 512 B (the unit of ds_read2st64_b64's offsets)
+__device__ __forceinline__ int stage_index(int idx) { return idx ^ (((idx >> 4) & 1) << 2) ^ ((idx >> 10) & 3); }
+__device__ __forceinline__ int stage_slot(int b) { return (b & 1) * kRegion + stage_index(b >> 1); }
 
 template <bool MONO>
 __global__ void __launch_bounds__(1024, 1) stft16384_d_kernel(Params p)
@@ -242,6 +250,7 @@ __global__ void __launch_bounds__(1024, 1) stft16384_d_kernel(Params p)
     // needs anyway) and on the twiddle multiplies of the first half of its image, instead of on a barrier of their own at the
     // end of the transform (same-device A/B: profiles/r03_k16_ablation.txt).
     constexpr int kStage = 8 * 4 * kS1;   // behind rows 0..7 of the first image (and the partner slots): 8704
+    static_assert(kStage + 2 * kRegion <= kBufComplex, "the staged row must fit behind the partner slots");
     struct Pending { long long f0, f1; uint32_t pair; bool have_first, have_second, valid; } prev{0, 0, 0, false, false, false};
     auto flush = [&](const Pending &o) {
         const float2 *stage = buf + kStage;
@@ -251,7 +260,8 @@ __global__ void __launch_bounds__(1024, 1) stft16384_d_kernel(Params p)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int c = tid + 1024 * i;           // bins 2 c, 2 c + 1 (0-based); the last piece of the row holds one bin
-            const float4 v = *reinterpret_cast<const float4 *>(stage + stage_slot(2 * c + 8 * (c >> 10)));
+            const float2 ev = stage[stage_index(c)], od = stage[kRegion + stage_index(c)];   // bins 2 c and 2 c + 1
+            const float4 v = make_float4(ev.x, ev.y, od.x, od.y);
             if (!D_STORE_OK(v.x)) continue;
             const bool whole = c != 4095;
             if (MONO) {
@@ -414,8 +424,7 @@ __global__ void __launch_bounds__(1024, 1) stft16384_d_kernel(Params p)
         // four 128-byte runs per instruction, 128 instructions per transform -- cost a third of the launch (ablation: 0.90 ms per
         // 20 000 transforms against 0.61 ms without the stores; profiles/r03_k16_ablation.txt).  Staging area: behind the
         // partner slots and the first eight rows of the next image (no barrier between the partner reads and these writes);
-        // bin k at slot (k - 1) + 8 ((k - 1) >> 11): the four parts of the row a wave writes at once are 2048 bins apart and
-        // would meet in the same banks.  The row is read back and stored by the next iteration (`flush`).
+        // bin k at stage_slot(k - 1).  The row is read back and stored by the next iteration (`flush`).
         float2 *stage = buf + kStage;
 #pragma unroll
         for (int qq = 0; qq < 8; ++qq) {
@@ -428,7 +437,7 @@ __global__ void __launch_bounds__(1024, 1) stft16384_d_kernel(Params p)
             const float mr = __builtin_amdgcn_sqrtf(fmaf(dr_, dr_, di_ * di_));
             const bool dc = qq == 0 && tid == 0;   // k = 0 (DC) is not an output (fft.rs:81)
             const int b = kbase + 256 * qq - 1;     // 0-based bin
-            if (!dc) stage[stage_slot(b + 8 * (b >> 11))] = make_float2(ml, mr);
+            if (!dc) stage[stage_slot(b)] = make_float2(ml, mr);
         }
         prev = Pending{f0, f1, pair, have_first, have_second, true};
         if (more) take(nxt.data_second);
