@@ -113,3 +113,55 @@ def test_random_hops_and_channels_at_the_compiled_plans(seed, mags_err):
     px = eng.render_batch(dev).cpu().numpy()
     own = eng.render_mags(torch.from_numpy(got).cuda().reshape(-1, eng.M, 2)).cpu().numpy()
     assert np.array_equal(px.reshape(own.shape), own)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_mono_streams_through_the_real_input_kernel(seed, mags_err, gradients):
+    # The default mono path at W 2048 / H 256 (csrc/stft4096_real.hip): random lengths (workgroups of one job, odd frame counts, a
+    # partner frame past the end of the stream), random level envelopes spanning 100 dB inside one stream (every frame is held to the
+    # tolerance against ITS OWN peak: frames share a workgroup, never a transform), sub-ranges from random first frames, an 8-byte and
+    # a 4-byte aligned start (the latter falls back to frame pairs), half rows and fused pixels against the same rows.
+    import torch
+    from spectrogram_rs_amd import SpectrogramEngine
+    rng = np.random.default_rng(7000 + seed)
+    W, H = 2048, 256
+    frames = int(rng.choice([1, 2, 3, 5, int(rng.integers(6, 300)), int(rng.integers(300, 5000))]))
+    n = (frames - 1) * H + W + int(rng.integers(0, H))
+    pcm = oracle.white_noise(n, seed=seed)
+    knots = np.sort(rng.integers(0, n, int(rng.integers(1, 12))))
+    gain = np.ones(n, np.float32)
+    for k in knots:                                        # level steps of up to +-50 dB each, anywhere (inside hops too)
+        gain[k:] *= np.float32(10.0 ** rng.uniform(-2.5, 2.5))
+    gain = np.clip(gain, 1e-5, 1.0).astype(np.float32)
+    if rng.random() < 0.3:
+        gain[: int(rng.integers(0, n))] = 0.0              # digital silence in front
+    pcm = (pcm * gain).astype(np.float32)
+    eng = SpectrogramEngine(48000.0, window_samples=W, hop_samples=H, channels=1, interp=int(rng.integers(0, 2)), gradient="magma")
+    assert eng.info.render_path & 8
+    buf = torch.zeros(n + 2, dtype=torch.float32, device="cuda")
+    buf[2:] = torch.from_numpy(pcm).cuda()
+    dev = buf[2:]
+    assert dev.data_ptr() % 8 == 0
+    got = eng.stft_batch(dev).cpu().numpy()
+    assert got.shape == (frames, 1, W - 1, 2)
+    pick = np.unique(np.concatenate([rng.integers(0, frames, 12), [0, frames - 1]]))
+    truth = np.stack([oracle.np_truth_frame(np.stack([pcm[t * H:t * H + W]] * 2, 1), W) for t in pick])
+    assert mags_err(got[pick, 0], truth) <= 1.0, (seed, frames)
+    first = int(rng.integers(0, frames))
+    count = int(rng.integers(1, frames - first + 1))
+    assert np.array_equal(eng.stft_batch(dev, first_frame=first, max_frames=count).cpu().numpy(), got[first:first + count])
+    assert torch.equal(eng.stft_batch_f16(dev, first_frame=first, max_frames=count), torch.from_numpy(got[first:first + count]).cuda().to(torch.float16))
+    px = eng.render_batch(dev, first_frame=first, max_frames=count)
+    assert torch.equal(px[:, 0], eng.render_mags(torch.from_numpy(got[first:first + count, 0]).cuda().contiguous()))
+    # the same samples from a 4-byte aligned address: the kernel cannot read them as 8-byte columns; frame pairs take over
+    # (tolerance against the PAIR's peak: on these streams that is checked where both frames of a pair were sampled)
+    odd = buf[1:1 + n].clone()
+    shifted = torch.zeros(n + 1, dtype=torch.float32, device="cuda")
+    shifted[1:] = dev
+    assert shifted[1:].data_ptr() % 8 == 4
+    alt = eng.stft_batch(shifted[1:]).cpu().numpy()
+    ref32 = oracle.stream_process(pcm, 1, W, H, threads=8)
+    pair_peak = np.maximum.reduce([np.abs(ref32).max(axis=(1, 2, 3)), np.abs(np.roll(ref32, 1, 0)).max(axis=(1, 2, 3)), np.abs(np.roll(ref32, -1, 0)).max(axis=(1, 2, 3))])
+    allow = 2e-5 * np.maximum(np.abs(ref32), 0.02 * pair_peak[:, None, None, None]) + 1e-30
+    assert (np.abs(alt - ref32) <= allow).all(), (seed, frames)
+    del odd
