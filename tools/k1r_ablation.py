@@ -3,9 +3,7 @@
 kernel stays as it is); run with `BENCH=tools/stereo_bench.py tools/ab.sh` (the "mono, default" line is this kernel).
 
   a_base     the tree's kernel
-  b_order    every wave stores its row in ascending address order (the eight k runs, then the eight 2048 - k runs from q3 = 7 down)
-             instead of alternating between the two halves of the row
-  c_nostore  one store in sixteen (compute + loads only)
+  b_ln_after_pass1 / c_ln_after_pass2   the next iteration's column requested earlier than the end of pass 3
 (measured and dropped from this script: the descending half stored at ascending lane addresses (wrong bins) -- the lane order inside a
 512-byte run makes no difference; no wave priorities -- 1-3 % slower)"""
 import os
@@ -40,16 +38,13 @@ def main():
     subprocess.run(["make", "-s", "-C", CSRC, "-j8"], check=True)
     base = open(os.path.join(CSRC, "stft4096_real.hip")).read()
     build("a_base", base)
-    # v1: L in flight at the loop entry (the compiler then waits with vmcnt(1) at the exchange write: the previous iteration's stores)
-    t = sub(base, '        L = column(r0, 9216);         // c[128 fa + 1152 + tid]\n', "")
-    t = sub(t, '        asm volatile("" ::"v"(carry.x), "v"(carry.y), "v"(L.x), "v"(L.y));\n', '        asm volatile("" ::"v"(carry.x), "v"(carry.y));\n')
-    t = sub(t, "        // (L as well: in flight at the loop entry", "        L = column(r0, 9216);\n        // (L as well: in flight at the loop entry")
-    build("b_v1_publish_wait", t)
-    # v0: no waits forced in front of the loop at all (loop-header vmcnt(2): every iteration waits for the row stores just issued)
-    t = re.sub(r'\n#pragma unroll\n        for \(int j = 0; j < 8; \+\+j\) asm volatile.*?"v"\(win\[q\]\)\);\n', "\n", base, flags=re.S)
-    assert t != base
-    t = sub(t, '        asm volatile("" : "+v"(Ln.x), "+v"(Ln.y));\n', "")
-    build("c_v0_header_wait", t)
+    # where the next column is requested: after pass 1 / after pass 2 instead of after pass 3 (more time to return, two more live registers)
+    decl = "        float2 Ln = make_float2(0.0f, 0.0f);\n        if (MODE != kPixels) Ln = column(columns_from(128 * (fa + 2) + 1152), 0);\n"
+    t = sub(base, decl, "")
+    build("b_ln_after_pass1", sub(t, "        __builtin_amdgcn_s_setprio(0);  // (wave priorities: stft4096_wg.hip)\n",
+                                  "        __builtin_amdgcn_s_setprio(0);  // (wave priorities: stft4096_wg.hip)\n" + decl))
+    build("c_ln_after_pass2", sub(t, "        // ---- pass 3: thread (F, u): 16-point FFT over t0 -> Z[u + 128 q3]\n",
+                                  decl + "        // ---- pass 3: thread (F, u): 16-point FFT over t0 -> Z[u + 128 q3]\n"))
     return 0
 
 
