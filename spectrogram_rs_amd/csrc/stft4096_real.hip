@@ -1,4 +1,5 @@
-// stft4096_real.hip -- K1R: a mono stream at W = 2048 / H = 256 with EVERY frame its own transform, at the price of half a transform.
+// stft4096_real.hip -- K1R: a mono stream at W = 2048 (H = 256: the tuned form; any even hop) with EVERY frame its own transform, at the
+// price of half a transform.
 //
 // The reference duplicates a mono sample into (s, s) and runs one 4096-point complex transform per frame
 // (audio_input_list_model.rs:67-69, fft.rs:47-99): F = (1 + i) S with S the spectrum of the real windowed frame, and both output
@@ -35,6 +36,7 @@
 // input from L2, the second fetch went to HBM, and the launch took exactly the 5.9 % longer that 18 424 B / frame are more than
 // 17 400: 3.72 ms per 1e6 frames against the paired kernel's 3.50.)
 #include <cmath>
+#include <type_traits>
 
 #include "stft4096_wg.hpp"
 
@@ -97,7 +99,10 @@ __device__ __forceinline__ void fft8_half_zero(const float (&zr)[4], const float
 constexpr int kRowsF32 = 0, kRowsF16 = 1, kPixels = 2;   // what a launch writes: float rows, half-pair rows, RGBA columns (fused pixel path)
 
 // PIX (kPixels only): the pixel code of the instantiation, wg::kPixCubic / kPixCosine / kPixGeneric (stft4096_wg.hpp)
-template <int MODE, int PIX>
+// SLIDE: H = 256, the window slides in registers (above).  Else: any EVEN hop (a frame starts on a column): the eight columns of the
+// next frame pair are requested where the sliding form requests its one, straight into R -- dead since pass 1 -- and every sample is
+// fetched 2048 / H times, through L2.
+template <int MODE, int PIX, bool SLIDE>
 __global__ void __launch_bounds__(256, 4) stft4096_real_kernel(Params p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -157,12 +162,23 @@ __global__ void __launch_bounds__(256, 4) stft4096_real_kernel(Params p)
         return make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
     };
     float2 R[8];        // R[j] = c[128 fa + tid + 128 j]: rows a = j / 2 of frame A (even j) and frame B (odd j)
-    float2 L;           // the next R[7] = c[128 fa + 1152 + tid]
+    float2 L;           // the next R[7] = c[128 fa + 1152 + tid]   (SLIDE)
+    const unsigned long long hc = p.H / 2;    // columns per hop (128 when SLIDE)
+    auto load_pair = [&](unsigned long long fa_) {   // !SLIDE: all eight columns of the pair (fa_, fa_ + 1)
+        const __amdgpu_buffer_rsrc_t r0 = columns_from(fa_ * hc), r1 = columns_from((fa_ + 1) * hc);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) { R[2 * a] = column(r0, 2048 * a); R[2 * a + 1] = column(r1, 2048 * a); }
+    };
     {
         const __amdgpu_buffer_rsrc_t r0 = columns_from(128 * (p.first_frame + 2 * job_begin));
+        if (SLIDE) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) R[j] = column(r0, 1024 * j);
-        L = column(r0, 9216);         // c[128 fa + 1152 + tid]
+            for (int j = 0; j < 8; ++j) R[j] = column(r0, 1024 * j);
+            L = column(r0, 9216);         // c[128 fa + 1152 + tid]
+        } else {
+            load_pair(p.first_frame + 2 * job_begin);
+            L = R[7];
+        }
         // the window is waited for HERE (an empty asm that reads it), so that the loop header carries no pending load of the entry path:
         // merged with the back edge -- where the same registers are long complete -- it made the compiler wait at the top of EVERY
         // iteration with vmcnt(2), i.e. for the sixteen row stores just issued to be acknowledged by memory
@@ -243,7 +259,8 @@ __global__ void __launch_bounds__(256, 4) stft4096_real_kernel(Params p)
         // around the loop); past the end of the stream it reads zeros.  (Requested at the TOP of the iteration instead -- a whole
         // iteration to return in -- it sits right behind the previous iteration's sixteen stores: 5-7 % slower, same device.)
         float2 Ln = make_float2(0.0f, 0.0f);
-        if (MODE != kPixels) Ln = column(columns_from(128 * (fa + 2) + 1152), 0);
+        if (SLIDE && MODE != kPixels) Ln = column(columns_from(128 * (fa + 2) + 1152), 0);
+        if (!SLIDE) load_pair(fa + 2);     // (R is dead since pass 1; past the end of the stream: zeros, never stored)
 
         if (MODE == kPixels) __builtin_amdgcn_s_setprio(1);   // the pixel passes are long: 3 only from the row pass (the pixel stores) on
         else __builtin_amdgcn_s_setprio(3);
@@ -255,15 +272,19 @@ __global__ void __launch_bounds__(256, 4) stft4096_real_kernel(Params p)
             buf[j * 256 + tid] = make_float2(xr[pos], xi[pos]);
         }
         // the next R[6] = c[128 fa + 1024 + tid] of the thread half a row away: its L (lower half publishes) or its R[7] (upper half)
-        xch[tid].x = tid < 128 ? L.x : R[7].x;
-        xch[tid].y = tid < 128 ? L.y : R[7].y;
+        if (SLIDE) {
+            xch[tid].x = tid < 128 ? L.x : R[7].x;
+            xch[tid].y = tid < 128 ? L.y : R[7].y;
+        }
         lds_barrier();
-        const float2 Y = xch[(tid + 128) & 255];
-        // ---- slide the window by two half rows, here: L is dead from now on (the Hann products of this iteration were taken at its top)
+        if (SLIDE) {
+            const float2 Y = xch[(tid + 128) & 255];
+            // ---- slide the window by two half rows, here: L is dead from now on (the Hann products of this iteration were taken at its top)
 #pragma unroll
-        for (int j = 0; j < 6; ++j) R[j] = R[j + 2];
-        R[6] = Y;
-        R[7] = L;
+            for (int j = 0; j < 6; ++j) R[j] = R[j + 2];
+            R[6] = Y;
+            R[7] = L;
+        }
 
         // ---- untangle + magnitude: bins k = u + 128 q3 and 2048 - k.  Z[2048 - k] is register 15 - q3 of thread 128 - u (row 7 - q3);
         // thread 0 holds its own partners one row up (register 16 - q3), and spends its q3 = 0 slot -- DC and Nyquist are not outputs
@@ -333,13 +354,13 @@ __global__ void __launch_bounds__(256, 4) stft4096_real_kernel(Params p)
             // the fused pixel path requests the next iteration's load HERE, straight into L (dead since the slide): requested in front
             // of the exchange like the rows' it is two more live registers through the sample pass -- two spills, and a spill reload
             // is a vector-memory load the compiler waits for with vmcnt(0), this load included (same device: 3.79 -> 3.68 ms)
-            L = column(columns_from(128 * (fa + 2) + 1152), 0);
+            if (SLIDE) L = column(columns_from(128 * (fa + 2) + 1152), 0);
             lds_barrier();
             uchar4 *rgba = reinterpret_cast<uchar4 *>(p.rgba);
             __builtin_amdgcn_s_setprio(3);
             wg::row_pass<true, PIX>(p, row_words, vbuf, rgba + la * (size_t)p.R, rgba + lb * (size_t)p.R, true, have_b, pal, tid);
         }
-        if (MODE != kPixels) {
+        if (SLIDE && MODE != kPixels) {
             // `Ln` is pinned behind the row stores: its copy into L needs the load complete, and scheduled in front of the stores (where
             // the compiler had put it) that is a vmcnt(0) in the middle of the iteration; here it is vmcnt(stores since).  (The load
             // straight into L behind the slide, no second pair: 4 % slower on the same device.)
@@ -403,10 +424,11 @@ void real4096_destroy(void *tables)
     delete t;
 }
 
-// the streams this kernel serves: one channel, W = 2048, H = 256, every frame start 8-byte aligned (rows arrive as float2)
+// the streams this kernel serves: one channel, W = 2048, an EVEN hop and an 8-byte aligned stream (every frame starts on an 8-byte
+// column; H = 256 slides its window in registers)
 bool real4096_serves(const sgx_ctx *c, const float *d_pcm, uint32_t channels)
 {
-    return channels == 1 && c->d_real && c->W == (uint32_t)wgr::kW && c->H == 256 && (reinterpret_cast<uintptr_t>(d_pcm) & 7u) == 0;
+    return channels == 1 && c->d_real && c->W == (uint32_t)wgr::kW && c->H % 2 == 0 && (reinterpret_cast<uintptr_t>(d_pcm) & 7u) == 0;
 }
 
 namespace wg {
@@ -421,7 +443,7 @@ hipError_t launch_real4096(const sgx_ctx *c, const void *real_tables, Params p, 
     p.tw1 = t->d_tw1;
     p.tw2 = t->d_tw2;
     p.twu = t->d_twu;
-    p.stream_samples = p.total_frames ? (p.total_frames - 1) * 256ull + (unsigned long long)kW : 0;   // what the stream's frames cover (the caller may hold more)
+    p.stream_samples = p.total_frames ? (p.total_frames - 1) * (unsigned long long)c->H + (unsigned long long)kW : 0;   // what the stream's frames cover (the caller may hold more)
     p.n_jobs = (p.n_frames + 1) / 2;
     unsigned long long blocks = (unsigned long long)c->n_cu * 4;   // persistent workgroups, four per CU, each a contiguous run of frame pairs
     unsigned long long per = (p.n_jobs + blocks - 1) / blocks;
@@ -429,15 +451,20 @@ hipError_t launch_real4096(const sgx_ctx *c, const void *real_tables, Params p, 
     blocks = (p.n_jobs + per - 1) / per;
     p.jobs_per_block = per;
     const dim3 grid((unsigned)blocks), block(256);
-    if (render) {
-        if (!p.seed_pm1) hipLaunchKernelGGL((stft4096_real_kernel<kPixels, kPixGeneric>), grid, block, kLdsBytesRender, c->stream, p);
-        else if (p.interp == SGX_INTERP_COSINE) hipLaunchKernelGGL((stft4096_real_kernel<kPixels, kPixCosine>), grid, block, kLdsBytesRender, c->stream, p);
-        else hipLaunchKernelGGL((stft4096_real_kernel<kPixels, kPixCubic>), grid, block, kLdsBytesRender, c->stream, p);
-    } else if (out_f16) {
-        hipLaunchKernelGGL((stft4096_real_kernel<kRowsF16, kPixNone>), grid, block, kLdsBytes, c->stream, p);
-    } else {
-        hipLaunchKernelGGL((stft4096_real_kernel<kRowsF32, kPixNone>), grid, block, kLdsBytes, c->stream, p);
-    }
+    auto launch = [&](auto slide_c) {
+        constexpr bool S_ = decltype(slide_c)::value;
+        if (render) {
+            if (!p.seed_pm1) hipLaunchKernelGGL((stft4096_real_kernel<kPixels, kPixGeneric, S_>), grid, block, kLdsBytesRender, c->stream, p);
+            else if (p.interp == SGX_INTERP_COSINE) hipLaunchKernelGGL((stft4096_real_kernel<kPixels, kPixCosine, S_>), grid, block, kLdsBytesRender, c->stream, p);
+            else hipLaunchKernelGGL((stft4096_real_kernel<kPixels, kPixCubic, S_>), grid, block, kLdsBytesRender, c->stream, p);
+        } else if (out_f16) {
+            hipLaunchKernelGGL((stft4096_real_kernel<kRowsF16, kPixNone, S_>), grid, block, kLdsBytes, c->stream, p);
+        } else {
+            hipLaunchKernelGGL((stft4096_real_kernel<kRowsF32, kPixNone, S_>), grid, block, kLdsBytes, c->stream, p);
+        }
+    };
+    if (c->H == 256) launch(std::true_type{});
+    else launch(std::false_type{});
     return hipGetLastError();
 }
 

@@ -960,6 +960,35 @@ def test_real_input_kernel_for_independent_mono_frames(torch_cuda, mags_err, n_f
     assert np.array_equal(real.stft_batch(dev).cpu().numpy(), got)
 
 
+@pytest.mark.parametrize("Ht", [2, 100, 128, 512, 1000, 2048, 3000, 255])
+def test_real_input_kernel_at_other_hops(torch_cuda, mags_err, Ht):
+    # W 2048 at any EVEN hop: the default mono mode is the real-input kernel too (no sliding window: the eight columns of a frame pair
+    # are requested ahead of the stores); an odd hop (255) cannot be read as 8-byte columns and keeps frame pairs
+    torch = torch_cuda
+    frames = 37
+    n = W + (frames - 1) * Ht + min(5, Ht - 1)        # a ragged tail shorter than one hop
+    pcm = oracle.white_noise(n, seed=500 + Ht)
+    pcm[n // 2:] *= np.float32(1e-3)
+    dev = to_dev(torch, pcm)
+    eng = engine(window_samples=W, hop_samples=Ht, channels=1, interp=1, gradient="inferno")
+    assert bool(eng.info.render_path & 8) == (Ht % 2 == 0)
+    got = eng.stft_batch(dev).cpu().numpy()
+    truth = np.stack([oracle.np_truth_frame(np.stack([pcm[t * Ht:t * Ht + W]] * 2, 1), W) for t in range(frames)])
+    assert got.shape == (frames, 1, M, 2)
+    if Ht % 2 == 0:
+        assert mags_err(got[:, 0], truth) <= 1.0                         # every frame, own peak
+    else:
+        assert _pair_error(got[:, 0], truth) <= 1.0                      # frame pairs: the pair's peak
+    cplx = engine(window_samples=W, hop_samples=Ht, channels=1, complex_mono=True).stft_batch(dev).cpu().numpy()
+    assert mags_err(got, cplx.astype(np.float64)) <= (2.0 if Ht % 2 == 0 else 400.0)
+    for first, cnt in ((1, 1), (3, 6), (36, 1), (8, 100)):
+        assert np.array_equal(eng.stft_batch(dev, first_frame=first, max_frames=cnt).cpu().numpy(), got[first:first + cnt])
+    assert torch.equal(eng.stft_batch_f16(dev), torch.from_numpy(got).cuda().to(torch.float16))
+    px = eng.render_batch(dev)
+    assert torch.equal(px[:, 0], eng.render_mags(torch.from_numpy(got[:, 0]).cuda().contiguous()))
+    assert torch.equal(eng.render_batch(dev, first_frame=5, max_frames=7), px[5:12])
+
+
 def _pair_error(x, ref, first_frame=0):
     """mags_error with the PAIR's peak (frames 2j, 2j+1 by global index) in place of the frame's own: the tolerance a mono
     frame meets when it shares its transform with its neighbour, as left and right do in the reference (fft.rs:57,87-88)"""

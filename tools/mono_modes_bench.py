@@ -18,13 +18,14 @@ ap.add_argument("--frames", type=int, default=1_000_000)
 ap.add_argument("--seconds", type=float, default=0.7)
 ap.add_argument("--rounds", type=int, default=3)
 ap.add_argument("--modes", default="default,paired")
+ap.add_argument("--hop", type=int, default=256)
 ap.add_argument("--pixels", action="store_true", help="the fused PCM -> RGBA path (cosine, Viridis) instead of float rows")
 args = ap.parse_args()
 F = args.frames
 FLAGS = {"default": {}, "paired": dict(paired_frames=True), "complex": dict(complex_mono=True)}
-engs = {m: SpectrogramEngine(48000.0, window_samples=2048, hop_samples=256, channels=1, interp=1, gradient="viridis", **FLAGS[m]) for m in args.modes.split(",")}
+engs = {m: SpectrogramEngine(48000.0, window_samples=2048, hop_samples=args.hop, channels=1, interp=1, gradient="viridis", **FLAGS[m]) for m in args.modes.split(",")}
 first = next(iter(engs.values()))
-pcm = first.white_noise((F - 1) * 256 + 2048)
+pcm = first.white_noise((F - 1) * args.hop + 2048)
 out = torch.empty((F, 1, 1024, 4), dtype=torch.uint8, device="cuda") if args.pixels else torch.empty((F, 1, 2047, 2), dtype=torch.float32, device="cuda")
 out.zero_()
 
@@ -49,4 +50,4 @@ for _ in range(args.rounds):
         res[m].append(window(e, args.seconds))
 lib = os.path.basename(os.environ.get("SGX_LIB", "libsgx.so"))
 for m, v in res.items():
-    print(f"{lib:28s} {'pixels' if args.pixels else 'rows':6s} {m:8s} " + "  ".join(f"{x:.3f}" for x in v) + f"  ms per {F} frames   best {F / min(v) / 1e3:.1f} M frames/s", flush=True)
+    print(f"{lib:28s} hop {args.hop:4d} {'pixels' if args.pixels else 'rows':6s} {m:8s} " + "  ".join(f"{x:.3f}" for x in v) + f"  ms per {F} frames   best {F / min(v) / 1e3:.1f} M frames/s", flush=True)
