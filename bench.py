@@ -68,7 +68,7 @@ KERNEL_NAMES = {
     2: ("stft4096 workgroup-per-transform (256 threads x 16 points, radix-16 x3, mono frame pairs), scalar codelets",
         "sgx::wg::stft4096_wg_kernel<true, 0, false, 0>"),
     "real": ("stft4096 real-input: every mono frame its own transform, a 2048-point complex transform of the real frame + one butterfly per bin "
-             "(256 threads x 2 frames x 8 points, radix 8 x 16 x 16, sliding half-row window)", "sgx::wgr::stft4096_real_kernel<0, 0>"),
+             "(256 threads x 2 frames x 8 points, radix 8 x 16 x 16, sliding half-row window)", "sgx::wgr::stft4096_real_kernel<0, 0, true>"),
     3: ("stft4096 workgroup-per-transform (256 threads x 16 points, radix-16 x3, mono frame pairs), packed (re, im) codelets",
         "sgx::wgp::stft4096_wgp_kernel<true, 0, false, false>"),
     5: ("stft16384 as four 4096-point residues (512 threads = 256 lane pairs, DPP decimation)", "sgx::q16k::stft16384_q_kernel<false, true>"),
@@ -637,7 +637,7 @@ def config3_leg(args, torch, eng, pcm, F):
             "bytes_per_frame": ALGO_BYTES_PIXEL, "frames_per_launch": Fp,
             "traffic": ((traffic or {}).get("pixel_bytes_per_frame") or 0) * Fp or None,
             "traffic_source": (traffic or {}).get("source"),
-            "kernel": "sgx::wgr::stft4096_real_kernel<2, 2>" if eng.info.render_path & 8 else "sgx::wg::stft4096_wg_kernel<true, 0, false, 2>",
+            "kernel": "sgx::wgr::stft4096_real_kernel<2, 2, true>" if eng.info.render_path & 8 else "sgx::wg::stft4096_wg_kernel<true, 0, false, 2>",
             "mono_mode": "every frame its own transform" if eng.info.render_path & 8 else "two frames per transform",
             "binding_pipe": pipes,
             "note": "48 flop per algorithmic byte: above the FP32 ridge (19.7), so the HBM fraction is low by construction; "

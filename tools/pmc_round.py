@@ -61,8 +61,8 @@ def traffic(name, units, algorithmic):
 
 F = 1_000_000
 # config 2 / 3: the default mono mode is the real-input kernel (every frame its own transform); rows = <0, 0>, cosine pixels = <2, 2>
-t2 = traffic("stft4096_real_kernel<0, 0>", F, 17400)
-t3 = traffic("stft4096_real_kernel<2, 2>", F, 5120)
+t2 = traffic("stft4096_real_kernel<0, 0, true>", F, 17400)
+t3 = traffic("stft4096_real_kernel<2, 2, true>", F, 5120)
 t2p = traffic("stft4096_wg_kernel<true, 0, false, 0>", F, 17400)     # the paired leg (SGX_FLAG_PAIRED_FRAMES), if the pass ran it
 hops = 20_000      # (tools/pmc_bench.sh runs the config-4 leg at 20 000 hop positions: a counter pass serialises every dispatch)
 t4a = traffic("stft16384_d_kernel<false", hops, 278496) or traffic("stft16384_q_kernel<false", hops, 278496)
@@ -90,7 +90,7 @@ if t4a:
 json.dump(out, open(os.path.join(root, "profiles", f"{rnd}_hbm_traffic.json"), "w"), indent=1)
 
 # ---- pipes of the fused pixel kernel -------------------------------------------------------------------------------
-name = "stft4096_real_kernel<2, 2>"
+name = "stft4096_real_kernel<2, 2, true>"
 g = lambda acc, c: pick(acc, name, c)  # noqa: E731
 pipes = {"csrc_sha16": csrc_sha16(), "how": "rocprofv3 --pmc SQ counters (two passes) over the same bench.py command; per launch of 1e6 frames = 5e5 transforms; "
                 "SQ_*_CYCLES / ACTIVE counters are in units of 4 clocks summed over waves; GRBM_GUI_ACTIVE summed over the 8 XCDs",
