@@ -87,17 +87,20 @@ typedef struct sgx_config {
 #define SGX_FLAG_NO_FUSED_RENDER 4u /* sgx_render_batch: run STFT and pixel stage as two kernels even where the fused one applies (A/B) */
 #define SGX_FLAG_PACKED_KERNEL 8u  /* W = 2048: workgroup-per-transform kernel with packed (re, im) arithmetic instead of scalar (A/B) */
 /* Mono streams.  The reference duplicates a mono sample into (s, s) and transforms every frame on its own
- * (audio_input_list_model.rs:67-69, fft.rs:47-99).  DEFAULT here: at W 2048 and any EVEN hop (8-byte aligned stream) exactly that
- * dataflow, one transform per frame, computed as the 4096-point spectrum of a REAL frame -- a 2048-point complex transform + one
- * butterfly per bin (stft4096_real.hip; at H 256, the BASELINE shape, with the window sliding in registers): every frame within
- * north_star's tolerance of its OWN peak, at the cost of half a transform.  Every other window, and odd hops: two frames (2j, 2j+1)
- * per transform in its real and imaginary part -- half the work, but the quieter frame of a pair carries the louder one's float32
- * rounding floor (1e-7 of the PAIR's peak). */
-#define SGX_FLAG_INDEPENDENT_FRAMES 16u /* mono: never pair -- one transform per frame at every window / hop (the (s, s) transform
-                                           where there is no real-input kernel: half the throughput of pairing) */
-#define SGX_FLAG_PAIRED_FRAMES 1024u /* mono: two frames per transform even at W 2048 (the default of rounds 1-3; A/B) */
+ * (audio_input_list_model.rs:67-69, fft.rs:47-99).  DEFAULT here, at every window and hop: exactly that dataflow, one transform per
+ * frame -- every frame within north_star's tolerance of its OWN peak on any input.  At W 2048 and an even hop (8-byte aligned stream)
+ * it is computed as the 4096-point spectrum of a REAL frame, a 2048-point complex transform + one butterfly per bin
+ * (stft4096_real.hip; at H 256, the BASELINE shape, with the window sliding in registers): the cost of half a transform.  Elsewhere
+ * it is the (s, s) transform itself.
+ * SGX_FLAG_PAIRED_FRAMES (opt-in): two frames (2j, 2j+1) per transform in its real and imaginary part -- half the work of the (s, s)
+ * transform, but the quieter frame of a pair carries the louder one's float32 rounding floor: the tolerance then holds against the
+ * PAIR's peak only (measured: up to 4.7 x the own-peak tolerance across a 60 dB step inside one hop, unbounded next to digital
+ * silence; invisible on stationary signals.  DESIGN.md section 4). */
+#define SGX_FLAG_PAIRED_FRAMES 1024u /* mono: two frames per transform (the default of rounds 1-3) */
+#define SGX_FLAG_INDEPENDENT_FRAMES 16u /* mono: never pair.  The default since round 4; kept for callers that set it, and it wins over
+                                           SGX_FLAG_PAIRED_FRAMES where both are given */
 #define SGX_FLAG_COMPLEX_MONO 512u /* mono at W 2048: the literal (s, s) 4096-point complex transform per frame -- fft.rs:47-57 --
-                                      wherever a frame gets its own transform, instead of the real-input kernel (A/B; implies no pairing) */
+                                      instead of the real-input kernel (A/B; implies no pairing) */
 #define SGX_FLAG_LUT_WALK 64u      /* fused pixel kernel: walk the dB thresholds from the log2 seed even where the host has shown that one compare pair settles the LUT index (A/B, and the test of the fallback) */
 #define SGX_FLAG_LEGACY_16K 32u    /* W = 8192: the first 16384-point kernel (whole transform in LDS, one workgroup per CU) instead of the four-residue one (A/B) */
 #define SGX_FLAG_RESIDUE_16K 128u  /* W = 8192: the second 16384-point kernel (four 4096-point residues of the OUTPUT, two passes of a 512-thread workgroup) instead of the time-decimated one (A/B) */
@@ -122,8 +125,8 @@ typedef struct sgx_info {
                                  bit 2 = the transform runs a compile-time plan of the composite-radix stages: stft_kernel 6 at the
                                  0.05 s windows of the usual sample rates (8 kHz to 192 kHz) and the powers of two from 512 on;
                                  stft_kernel 4 (chirp-z) for W = 86 .. 5461, e.g. 1102 at 22.05 kHz;
-                                 bit 3 = a mono stream runs the real-input kernel, every frame its own transform (W 2048, even hop,
-                                 unless SGX_FLAG_PAIRED_FRAMES / SGX_FLAG_COMPLEX_MONO; needs an 8-byte aligned stream) */
+                                 bit 3 = a mono stream runs the real-input kernel (W 2048, even hop, unless SGX_FLAG_PAIRED_FRAMES /
+                                 SGX_FLAG_COMPLEX_MONO; needs an 8-byte aligned stream, else the (s, s) kernel takes it) */
     uint64_t mags_bytes_per_frame; /* pairs * M * 2 * 4 */
     uint64_t rgba_bytes_per_frame; /* pairs * R * 4     */
 } sgx_info;

@@ -226,7 +226,7 @@ hipError_t run_stft(const sgx_ctx *c, const float *d_pcm, uint32_t channels, uin
     // W = 8192: the four-residue kernel, (l, r) streams and mono frame pairs alike (independent mono frames: generic)
     if (c->stft_kernel == 5 && (channels != 1 || !(c->cfg.flags & SGX_FLAG_INDEPENDENT_FRAMES)))
         return sgx::launch_stft_q16384(c, c->d_q16k, d_pcm, channels, pairs, first, n, total, d_mags);
-    if (c->stft_kernel == 8 && (channels != 1 || !(c->cfg.flags & SGX_FLAG_INDEPENDENT_FRAMES)))
+    if (c->stft_kernel == 8)   // (a mono stream whose frames are not paired: as an (s, s) plane through the two-channel kernel)
         return sgx::launch_stft_d16384(c, c->d_d16k, d_pcm, channels, pairs, first, n, total, d_mags);
     if (c->stft_kernel == 7 && (channels != 1 || !(c->cfg.flags & SGX_FLAG_INDEPENDENT_FRAMES)))
         return sgx::launch_stft_wg16384(c, c->d_fast_16k, d_pcm, channels, pairs, first, n, total, d_mags);
@@ -286,6 +286,10 @@ int sgx_create(const sgx_config *cfg, sgx_ctx **out_ctx)
     sgx_ctx *c = new (std::nothrow) sgx_ctx();
     if (!c) return fail(nullptr, SGX_ERR_NOMEM, "sgx_create: out of host memory");
     c->cfg = *cfg;
+    // Mono streams (include/sgx.h): every frame its own transform unless SGX_FLAG_PAIRED_FRAMES asks for frame pairs -- the kernels
+    // test SGX_FLAG_INDEPENDENT_FRAMES, which is therefore set whenever pairing was not asked for (and wins where both are given)
+    if (!(c->cfg.flags & SGX_FLAG_PAIRED_FRAMES)) c->cfg.flags |= SGX_FLAG_INDEPENDENT_FRAMES;
+    if (c->cfg.flags & (SGX_FLAG_INDEPENDENT_FRAMES | SGX_FLAG_COMPLEX_MONO)) c->cfg.flags &= ~SGX_FLAG_PAIRED_FRAMES;
 
     // fft.rs:19 / audio_transform.rs:35: f32 product, truncating cast
     c->W = cfg->window_samples ? cfg->window_samples : f32_as_u32(cfg->period * cfg->sample_rate);
@@ -457,8 +461,7 @@ int sgx_query(const sgx_ctx *c, sgx_info *out)
     if ((c->stft_kernel == 2 || c->stft_kernel == 3) && !(c->cfg.flags & SGX_FLAG_NO_FUSED_RENDER) && sgx::wg4096_can_fuse_render(c, c->d_fast_wg))
         out->render_path = 1u | (sgx::wg4096_seed_is_within_one(c) ? 2u : 0u);
     if ((c->stft_kernel == 6 || c->stft_kernel == 9) && sgx::mixed_fixed_plan(c->d_mix)) out->render_path |= 4u;
-    if (c->stft_kernel == 2 && c->d_real && !(c->cfg.flags & SGX_FLAG_COMPLEX_MONO)
-        && ((c->cfg.flags & SGX_FLAG_INDEPENDENT_FRAMES) || !(c->cfg.flags & SGX_FLAG_PAIRED_FRAMES))) out->render_path |= 8u;
+    if (c->stft_kernel == 2 && c->d_real && !(c->cfg.flags & SGX_FLAG_COMPLEX_MONO) && (c->cfg.flags & SGX_FLAG_INDEPENDENT_FRAMES)) out->render_path |= 8u;
     if (c->stft_kernel == 4 && c->d_chz) out->render_path |= 4u;
     if ((c->stft_kernel == 6 || c->stft_kernel == 9) && !(c->cfg.flags & SGX_FLAG_NO_FUSED_RENDER) && sgx::mixed_can_fuse_render(c, c->d_mix)) out->render_path |= 3u;
     out->mags_bytes_per_frame = (uint64_t)c->pairs * c->M * 2 * sizeof(float);

@@ -134,6 +134,15 @@ constexpr int kRegion = 4096;   // float2 slots per parity region: 32 768 B = 64
 __device__ __forceinline__ int stage_index(int idx) { return idx ^ (((idx >> 4) & 1) << 2) ^ ((idx >> 10) & 3); }
 __device__ __forceinline__ int stage_slot(int b) { return (b & 1) * kRegion + stage_index(b >> 1); }
 
+// a mono sample range as one (s, s) plane: what the reference's capture callback does to a mono device (audio_input_list_model.rs:67-69)
+__global__ void __launch_bounds__(256) duplicate_mono_kernel(const float *pcm, float *plane, size_t first, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float s = pcm[first + i];
+        reinterpret_cast<float2 *>(plane)[i] = make_float2(s, s);
+    }
+}
+
 template <bool MONO>
 __global__ void __launch_bounds__(1024, 1) stft16384_d_kernel(Params p)
 {
@@ -541,10 +550,12 @@ hipError_t launch_stft_d16384(const sgx_ctx *c, void *tables, const float *d_pcm
     p.H = c->H;
     p.pairs = pairs;
     const bool mono = channels == 1 && !(c->cfg.flags & SGX_FLAG_INDEPENDENT_FRAMES);
-    if (channels == 1 && !mono) return hipErrorNotSupported;  // caller falls back to the generic kernel
+    // a mono stream whose frames are not paired (the default): every frame the (s, s) transform of the reference
+    // (audio_input_list_model.rs:67-69) -- the sample range duplicated into one (s, s) plane, then the two-channel kernel
+    const bool dup = channels == 1 && !mono;
     p.pair_base = mono ? first_frame / 2 : 0;
     p.n_jobs = mono ? (first_frame + n_frames + 1) / 2 - first_frame / 2 : (unsigned long long)n_frames * pairs;
-    if (channels > 2) {
+    if (channels > 2 || dup) {
         // per-pair planes of the sample range these frames read: [first_frame H, (first_frame + n - 1) H + W)
         const size_t first_sample = first_frame * (size_t)c->H;
         const size_t n_samp = (n_frames - 1) * (size_t)c->H + kW;
@@ -557,7 +568,14 @@ hipError_t launch_stft_d16384(const sgx_ctx *c, void *tables, const float *d_pcm
             if (e != hipSuccess) return e;
             t->planes_floats = plane * pairs;
         }
-        hipError_t e = launch_deinterleave_pairs(c, d_pcm, t->d_planes, plane, first_sample, n_samp, channels, pairs);
+        hipError_t e = hipSuccess;
+        if (dup) {
+            const unsigned blocks = (unsigned)std::min<size_t>((n_samp + 255) / 256, (size_t)c->n_cu * 16);
+            hipLaunchKernelGGL(d16k::duplicate_mono_kernel, dim3(blocks), dim3(256), 0, c->stream, d_pcm, t->d_planes, first_sample, n_samp);
+            e = hipGetLastError();
+        } else {
+            e = launch_deinterleave_pairs(c, d_pcm, t->d_planes, plane, first_sample, n_samp, channels, pairs);
+        }
         if (e != hipSuccess) return e;
         p.pcm = t->d_planes;
         p.plane_floats = plane;

@@ -48,7 +48,7 @@ def has_variants():
 
 # ---- the transform -----------------------------------------------------------------------------
 
-@pytest.mark.parametrize("variant", ["default", "paired", "complex", "packed", "wave", "generic"])
+@pytest.mark.parametrize("variant", ["default", "paired", "complex", "packed", "wave", "generic", "generic_paired", "packed_paired", "wave_paired"])
 @pytest.mark.parametrize("channels", [1, 2])
 def test_stft_batch_matches_oracle(torch_cuda, mags_err, variant, channels):
     # every kernel that can serve W = 2048: workgroup-per-transform (default; a mono stream: the real-input kernel, "paired": two
@@ -56,14 +56,15 @@ def test_stft_batch_matches_oracle(torch_cuda, mags_err, variant, channels):
     # kernel, and the generic power-of-two kernel
     torch = torch_cuda
     kw = {"default": {}, "paired": {"paired_frames": True}, "complex": {"complex_mono": True}, "packed": {"packed_kernel": True},
-          "wave": {"wave_kernel": True}, "generic": {"force_generic": True}}[variant]
-    if variant in ("packed", "wave") and not has_variants():
+          "wave": {"wave_kernel": True}, "generic": {"force_generic": True}, "generic_paired": {"force_generic": True, "paired_frames": True},
+          "packed_paired": {"packed_kernel": True, "paired_frames": True}, "wave_paired": {"wave_kernel": True, "paired_frames": True}}[variant]
+    if variant.split("_")[0] in ("packed", "wave") and not has_variants():
         from spectrogram_rs_amd import SgxError
         with pytest.raises(SgxError, match="VARIANTS=1"):   # the default build leaves the superseded kernels out and says so
             engine(window_samples=W, hop_samples=H, channels=channels, **kw)
         pytest.skip("superseded A/B kernel: not in the default build (make VARIANTS=1)")
     eng = engine(window_samples=W, hop_samples=H, channels=channels, **kw)
-    assert eng.info.stft_kernel == {"default": 2, "paired": 2, "complex": 2, "packed": 3, "wave": 1, "generic": 0}[variant]
+    assert eng.info.stft_kernel == {"default": 2, "paired": 2, "complex": 2, "packed": 3, "wave": 1, "generic": 0}[variant.split("_")[0]]
     assert bool(eng.info.render_path & 8) == (variant == "default" and channels == 1)
     n = W + H * 130 + 77
     pcm = oracle.white_noise(n * channels, seed=11 + channels)
@@ -133,15 +134,15 @@ def test_4096_point_kernel_on_interleaved_channel_pairs(torch_cuda, mags_err, gr
     assert px.shape == (14, ch // 2, R, 4) and np.array_equal(px.reshape(own.shape), own)
 
 
-@pytest.mark.parametrize("ch,independent", [(2, False), (1, False), (1, True), (4, False)])
+@pytest.mark.parametrize("ch,paired", [(2, False), (1, True), (1, False), (4, False)])
 @pytest.mark.parametrize("variant", ["tuned", "composite"])
-def test_app_point_4800_point_kernel(torch_cuda, mags_err, gradients, ch, independent, variant):
+def test_app_point_4800_point_kernel(torch_cuda, mags_err, gradients, ch, paired, variant):
     # The application's own window (48 kHz x 0.05 s = W 2400, 2W = 4800 = 16 x 20 x 15; hop 93 = (2 / 1024) s): the tuned
     # workgroup-per-transform kernel (default for one and two channels; more channels run the composite-radix kernel of any smooth
     # length) and that kernel itself (SGX_FLAG_MIXED_GENERIC), each against the oracle -- rows, half rows, pixel columns
     torch = torch_cuda
     Wt, Ht = 2400, 93
-    eng = engine(window_samples=Wt, hop_samples=Ht, channels=ch, independent_frames=independent, mixed_generic=(variant == "composite"),
+    eng = engine(window_samples=Wt, hop_samples=Ht, channels=ch, paired_frames=paired, mixed_generic=(variant == "composite"),
                  gradient="viridis")
     assert eng.info.stft_kernel == (9 if variant == "tuned" else 6)
     # 768 persistent workgroups on a 256-CU device: mono pairs -> 951 jobs, two per workgroup for some; stereo -> 3 per workgroup.
@@ -171,7 +172,7 @@ def test_app_point_4800_point_kernel(torch_cuda, mags_err, gradients, ch, indepe
     assert px.shape == (frames, max(ch // 2, 1), R, 4)
     assert bool(eng.info.render_path & 1)
     assert np.array_equal(eng.render_batch(dev, first_frame=3, max_frames=50).cpu().numpy(), px[3:53])
-    split = engine(window_samples=Wt, hop_samples=Ht, channels=ch, independent_frames=independent, mixed_generic=(variant == "composite"),
+    split = engine(window_samples=Wt, hop_samples=Ht, channels=ch, paired_frames=paired, mixed_generic=(variant == "composite"),
                    gradient="viridis", fused_render=False)
     own = oracle.render_columns(got.reshape(-1, Wt - 1, 2), SR, gradients["viridis"])
     assert np.array_equal(split.render_batch(dev).cpu().numpy().reshape(own.shape), own)
@@ -179,20 +180,25 @@ def test_app_point_4800_point_kernel(torch_cuda, mags_err, gradients, ch, indepe
     if variant == "composite" or ch > 2:
         assert np.array_equal(px.reshape(own.shape), own)
     else:
-        comp = engine(window_samples=Wt, hop_samples=Ht, channels=ch, independent_frames=independent, mixed_generic=True, gradient="viridis")
+        comp = engine(window_samples=Wt, hop_samples=Ht, channels=ch, paired_frames=paired, mixed_generic=True, gradient="viridis")
         assert np.array_equal(comp.render_batch(dev).cpu().numpy(), px)
         comp.close()
     eng.close()
 
 
-@pytest.mark.parametrize("ch,variant", [(8, "quad"), (2, "quad"), (1, "quad"), (8, "residue"), (2, "residue"), (1, "residue"), (8, "generic")])
+@pytest.mark.parametrize("ch,variant", [(8, "quad"), (2, "quad"), (1, "quad"), (1, "quad_paired"), (8, "residue"), (2, "residue"), (1, "residue"),
+                                        (1, "residue_paired"), (8, "generic")])
 def test_config4_16384_point_kernel(torch_cuda, mags_err, ch, variant):
     # BASELINE config 4: W 8192 / P 16384, hop 512, interleaved channel pairs; the time-decimated lane-quad kernel (default), the
     # four-residue kernel of round 2 (SGX_FLAG_RESIDUE_16K) and the generic kernel, each against the oracle
     torch = torch_cuda
     Wt, Ht = 8192, 512
+    # (a mono stream: by default every frame its own (s, s) transform -- the lane-quad kernel on a duplicated plane, the four-residue
+    # design through the generic kernel --, "_paired": two frames per transform, SGX_FLAG_PAIRED_FRAMES)
+    paired = variant.endswith("_paired")
+    variant = variant.split("_")[0]
     force_generic = variant == "generic"
-    eng = engine(window_samples=Wt, hop_samples=Ht, channels=ch, force_generic=force_generic, residue_16k=(variant == "residue"))
+    eng = engine(window_samples=Wt, hop_samples=Ht, channels=ch, force_generic=force_generic, residue_16k=(variant == "residue"), paired_frames=paired)
     assert eng.info.stft_kernel == {"quad": 8, "residue": 5, "generic": 0}[variant]
     n = Wt + 21 * Ht + 9
     pcm = oracle.white_noise(n * ch, seed=40 + ch)
@@ -242,7 +248,7 @@ def test_generic_kernel_pairs_mono_frames_by_global_index(torch_cuda, mags_err, 
     pcm = oracle.white_noise(Wt + 37 * Ht + 5, seed=Wt)
     dev = to_dev(torch, pcm)
     ref = oracle.stream_process(pcm, 1, Wt, Ht, threads=8)
-    eng = engine(window_samples=Wt, hop_samples=Ht, channels=1)
+    eng = engine(window_samples=Wt, hop_samples=Ht, channels=1, paired_frames=True)
     assert eng.info.stft_kernel == ((0 if Wt < 512 else 6) if Wt & (Wt - 1) == 0 else (4 if Wt == 1102 else (9 if Wt == 2400 else 6)))
     tol = 2.0
     got = eng.stft_batch(dev).cpu().numpy()
@@ -250,8 +256,12 @@ def test_generic_kernel_pairs_mono_frames_by_global_index(torch_cuda, mags_err, 
     assert mags_err(got, ref) <= tol and np.array_equal(got[..., 0], got[..., 1])
     for first, count in [(1, 36), (7, 1), (36, 2), (0, 37), (5, 6)]:
         assert np.array_equal(eng.stft_batch(dev, first_frame=first, max_frames=count).cpu().numpy(), got[first:first + count])
-    ind = engine(window_samples=Wt, hop_samples=Ht, channels=1, independent_frames=True).stft_batch(dev).cpu().numpy()
+    ind_eng = engine(window_samples=Wt, hop_samples=Ht, channels=1)            # the default: every frame its own (s, s) transform
+    ind = ind_eng.stft_batch(dev).cpu().numpy()
     assert mags_err(ind, ref) <= tol and mags_err(ind, got.astype(np.float64)) <= tol
+    assert np.array_equal(engine(window_samples=Wt, hop_samples=Ht, channels=1, independent_frames=True).stft_batch(dev).cpu().numpy(), ind)
+    for first, count in [(1, 36), (7, 1), (5, 6)]:
+        assert np.array_equal(ind_eng.stft_batch(dev, first_frame=first, max_frames=count).cpu().numpy(), ind[first:first + count])
 
 
 def test_short_ragged_and_empty_inputs(torch_cuda):
@@ -947,15 +957,13 @@ def test_real_input_kernel_for_independent_mono_frames(torch_cuda, mags_err, n_f
     h = real.stft_batch_f16(dev)
     assert torch.equal(h, torch.from_numpy(got).cuda().to(torch.float16))
     assert torch.equal(real.stft_batch_f16(dev, first_frame=1, max_frames=3), h[1:4])
-    # a stream that is 4- but not 8-byte aligned cannot be read as float2 rows: "never pair" sends it to the (s, s) kernel (own-peak
-    # tolerance), the default to the paired kernel (pair-peak tolerance; on this stream of one level step: the own-peak one too
-    # except around the step)
+    # a stream that is 4- but not 8-byte aligned cannot be read as 8-byte columns: the (s, s) kernel takes it (own-peak tolerance)
     shifted = torch.empty(dev.numel() + 1, dtype=dev.dtype, device=dev.device)
     shifted[1:] = dev
     assert shifted[1:].data_ptr() % 8 == 4
     alt = engine(window_samples=W, hop_samples=H, channels=1, independent_frames=True).stft_batch(shifted[1:]).cpu().numpy()
     assert mags_err(alt[pick, 0], truth) <= 1.0
-    assert mags_err(real.stft_batch(shifted[1:]).cpu().numpy(), ref32) <= 4.0
+    assert np.array_equal(real.stft_batch(shifted[1:]).cpu().numpy(), alt)
     # determinism
     assert np.array_equal(real.stft_batch(dev).cpu().numpy(), got)
 
@@ -963,7 +971,7 @@ def test_real_input_kernel_for_independent_mono_frames(torch_cuda, mags_err, n_f
 @pytest.mark.parametrize("Ht", [2, 100, 128, 512, 1000, 2048, 3000, 255])
 def test_real_input_kernel_at_other_hops(torch_cuda, mags_err, Ht):
     # W 2048 at any EVEN hop: the default mono mode is the real-input kernel too (no sliding window: the eight columns of a frame pair
-    # are requested ahead of the stores); an odd hop (255) cannot be read as 8-byte columns and keeps frame pairs
+    # are requested ahead of the stores); an odd hop (255) cannot be read as 8-byte columns: the (s, s) kernel
     torch = torch_cuda
     frames = 37
     n = W + (frames - 1) * Ht + min(5, Ht - 1)        # a ragged tail shorter than one hop
@@ -975,12 +983,11 @@ def test_real_input_kernel_at_other_hops(torch_cuda, mags_err, Ht):
     got = eng.stft_batch(dev).cpu().numpy()
     truth = np.stack([oracle.np_truth_frame(np.stack([pcm[t * Ht:t * Ht + W]] * 2, 1), W) for t in range(frames)])
     assert got.shape == (frames, 1, M, 2)
-    if Ht % 2 == 0:
-        assert mags_err(got[:, 0], truth) <= 1.0                         # every frame, own peak
-    else:
-        assert _pair_error(got[:, 0], truth) <= 1.0                      # frame pairs: the pair's peak
+    assert mags_err(got[:, 0], truth) <= 1.0                             # every frame, own peak (an odd hop: the (s, s) kernel)
     cplx = engine(window_samples=W, hop_samples=Ht, channels=1, complex_mono=True).stft_batch(dev).cpu().numpy()
-    assert mags_err(got, cplx.astype(np.float64)) <= (2.0 if Ht % 2 == 0 else 400.0)
+    assert mags_err(got, cplx.astype(np.float64)) <= 2.0
+    pair = engine(window_samples=W, hop_samples=Ht, channels=1, paired_frames=True).stft_batch(dev).cpu().numpy()
+    assert _pair_error(pair[:, 0], truth) <= 1.0                         # frame pairs (opt-in): the pair's peak
     for first, cnt in ((1, 1), (3, 6), (36, 1), (8, 100)):
         assert np.array_equal(eng.stft_batch(dev, first_frame=first, max_frames=cnt).cpu().numpy(), got[first:first + cnt])
     assert torch.equal(eng.stft_batch_f16(dev), torch.from_numpy(got).cuda().to(torch.float16))
@@ -1048,6 +1055,7 @@ def test_onsets_inside_one_hop_own_peak_tolerance_and_the_paired_bound(torch_cud
 
 @pytest.mark.parametrize("kw", [dict(channels=1), dict(channels=1, paired_frames=True), dict(channels=2), dict(channels=1, force_generic=True),
                                 dict(channels=2, window_samples=2400, hop_samples=93), dict(channels=1, window_samples=2400, hop_samples=93),
+                                dict(channels=1, window_samples=2400, hop_samples=93, paired_frames=True), dict(channels=1, window_samples=1024, hop_samples=100, paired_frames=True),
                                 dict(channels=2, window_samples=2205, hop_samples=86), dict(channels=4, window_samples=1600, hop_samples=50),
                                 dict(channels=2, window_samples=1102, hop_samples=100)])
 def test_half_precision_ring_rows(torch_cuda, kw):
