@@ -32,8 +32,8 @@ Extra objects on the same line:
   config3      -- (N = 1) BASELINE config 3: the same stream -> RGBA pixel columns, with its own roofline
   config4      -- (N = 1) BASELINE config 4 at its own size: 16384-point, hop 512, 8 interleaved channels, 1e5 hop positions
                   (26 GB of output), with its own roofline
-  mono_paired_frames -- (N = 1) the headline stream with two frames per transform (SGX_FLAG_PAIRED_FRAMES), the headline mode of
-                  rounds 1-3.  The headline itself now runs the reference's dataflow -- every mono frame its own transform
+  mono_paired_frames -- (N = 1) the headline stream with two frames per transform (SGX_FLAG_PAIRED_FRAMES, opt-in), the headline mode
+                  of rounds 1-3.  The headline itself runs the library's default, the reference's dataflow -- every mono frame its own transform
                   (audio_input_list_model.rs:67-69), as a real-input 2048-point transform (csrc/stft4096_real.hip) -- so that
                   north_star's tolerance holds against every frame's OWN peak on any input; this leg says what that costs
   mono_complex_frames -- (N = 1) the same stream with every frame as the literal (s, s) 4096-point transform (SGX_FLAG_COMPLEX_MONO)
@@ -756,25 +756,31 @@ def app_point_leg(args, torch, device):
     name = KERNEL_NAMES.get(eng.info.stft_kernel, ("?", "?"))
     # the same point for a mono device (audio_input_list_model.rs:67-69 duplicates the sample into (s, s)): two frames per transform
     del rgba, pcm
-    mono = SpectrogramEngine(48000.0, period=0.05, hop_samples=H_APP, channels=1, device=device)
+    mono = SpectrogramEngine(48000.0, period=0.05, hop_samples=H_APP, channels=1, device=device)                       # default: every frame its own (s, s) transform
+    monop = SpectrogramEngine(48000.0, period=0.05, hop_samples=H_APP, channels=1, device=device, paired_frames=True)   # opt-in: two frames per transform
     pcm1 = mono.white_noise((Fa - 1) * H_APP + W_APP)
     out1 = torch.empty((Fa, 1, W_APP - 1, 2), dtype=torch.float32, device=mono.device)
     out1.zero_()
     m1 = measure_leg(torch, lambda: mono.stft_batch(pcm1, out=out1), args.leg_sustain_s)
-    mean1 = m1["mean_ms"]
+    m1p = measure_leg(torch, lambda: monop.stft_batch(pcm1, out=out1), args.leg_sustain_s)
+    mean1, mean1p = m1["mean_ms"], m1p["mean_ms"]
     bytes1 = H_APP * 4 + (W_APP - 1) * 8
-    ach1 = Fa * bytes1 / (mean1 * 1e-3) / 1e9
+    ach1, ach1p = Fa * bytes1 / (mean1 * 1e-3) / 1e9, Fa * bytes1 / (mean1p * 1e-3) / 1e9
     del out1, pcm1
     mono.close()
+    monop.close()
     res = {
         "workload": f"the application's operating point: 48 kHz x 0.05 s = W 2400 (4800-point transform), hop 93, (l, r) stream, {Fa} frames",
         "kernel": name[0], "real_time_factor": Fa / (mean * 1e-3) * H_APP / 48000.0,
         "rows_f32": {"frames_per_s": Fa / (mean * 1e-3), **leg_times(m),
                      "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                                   "bytes_per_frame": ALGO_BYTES_APP, "frames_per_launch": Fa}},
-        "mono_rows_f32": {"frames_per_s": Fa / (mean1 * 1e-3), **leg_times(m1),
+        "mono_rows_f32": {"frames_per_s": Fa / (mean1 * 1e-3), **leg_times(m1), "mono_mode": "every frame its own (s, s) transform (default)",
                           "roofline": {"bound": "hbm", "achieved": ach1, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach1 / HBM_PEAK_GBS,
                                        "bytes_per_frame": bytes1, "frames_per_launch": Fa}},
+        "mono_rows_f32_paired_frames": {"frames_per_s": Fa / (mean1p * 1e-3), **leg_times(m1p), "mono_mode": "two frames per transform (SGX_FLAG_PAIRED_FRAMES)",
+                                        "roofline": {"bound": "hbm", "achieved": ach1p, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach1p / HBM_PEAK_GBS,
+                                                     "bytes_per_frame": bytes1, "frames_per_launch": Fa}},
         "pcm_to_rgba": {"frames_per_s": Fa / (meanp * 1e-3), **leg_times(mp), "fused_kernel": bool(eng.info.render_path & 1),
                         "roofline": {"bound": "hbm", "achieved": achp, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achp / HBM_PEAK_GBS,
                                      "bytes_per_frame": ALGO_BYTES_APP_PIXEL, "frames_per_launch": Fa}},
