@@ -11,7 +11,8 @@ from spectrogram_rs_amd import SpectrogramEngine
 
 F = int(sys.argv[1]) if len(sys.argv) > 1 else 262144
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 7
-W, H = 2400, int(os.environ.get("APP_HOP", "93"))
+RATE = float(os.environ.get("APP_RATE", "48000"))   # 44100 -> W 2205, the 4410-point mixed-radix kernel
+W, H = int(round(RATE * 0.05)), int(os.environ.get("APP_HOP", "93"))
 
 
 def timeit(fn):
@@ -27,7 +28,7 @@ def timeit(fn):
 
 
 for ch in (2, 1):
-    eng = SpectrogramEngine(48000.0, period=0.05, hop_samples=H, channels=ch, interp=0, gradient="viridis",
+    eng = SpectrogramEngine(RATE, period=0.05, hop_samples=H, channels=ch, interp=0, gradient="viridis",
                             mixed_generic=bool(os.environ.get("APP_GENERIC")))
     assert eng.W == W
     pcm = eng.white_noise((F - 1) * H + W)
