@@ -125,8 +125,10 @@ typedef struct sgx_info {
                                  bit 2 = the transform runs a compile-time plan of the composite-radix stages: stft_kernel 6 at the
                                  0.05 s windows of the usual sample rates (8 kHz to 192 kHz) and the powers of two from 512 on;
                                  stft_kernel 4 (chirp-z) for W = 86 .. 5461, e.g. 1102 at 22.05 kHz;
-                                 bit 3 = a mono stream runs the real-input kernel (W 2048, even hop, unless SGX_FLAG_PAIRED_FRAMES /
-                                 SGX_FLAG_COMPLEX_MONO; needs an 8-byte aligned stream, else the (s, s) kernel takes it) */
+                                 bit 3 = a mono stream runs a real-input kernel, the W-point transform of sample pairs (unless
+                                 SGX_FLAG_PAIRED_FRAMES / SGX_FLAG_COMPLEX_MONO): at W 2048 with an even hop (needs an 8-byte aligned
+                                 stream, else the (s, s) kernel takes it), and at every window the mixed-radix kernel serves
+                                 (stft_kernel 6 and 9, any hop and alignment) */
     uint64_t mags_bytes_per_frame; /* pairs * M * 2 * 4 */
     uint64_t rgba_bytes_per_frame; /* pairs * R * 4     */
 } sgx_info;

@@ -230,7 +230,8 @@ hipError_t run_stft(const sgx_ctx *c, const float *d_pcm, uint32_t channels, uin
         return sgx::launch_stft_d16384(c, c->d_d16k, d_pcm, channels, pairs, first, n, total, d_mags);
     if (c->stft_kernel == 7 && (channels != 1 || !(c->cfg.flags & SGX_FLAG_INDEPENDENT_FRAMES)))
         return sgx::launch_stft_wg16384(c, c->d_fast_16k, d_pcm, channels, pairs, first, n, total, d_mags);
-    if (c->stft_kernel == 9 && channels <= 2) return sgx::launch_stft_w4800(c, c->d_w4800, d_pcm, channels, first, n, total, d_mags, false);
+    // (a mono stream, every frame its own transform: real-input mode of the mixed-radix kernel, 2400 points instead of 4800 on (s, s))
+    if (c->stft_kernel == 9 && channels <= 2 && !sgx::mixed_real_serves(c, c->d_mix, channels)) return sgx::launch_stft_w4800(c, c->d_w4800, d_pcm, channels, first, n, total, d_mags, false);
     if (c->stft_kernel == 6 || c->stft_kernel == 9) return sgx::launch_stft_mixed(c, c->d_mix, d_pcm, channels, pairs, first, n, total, d_mags);
     if (c->stft_kernel == 4 && c->d_chz) return sgx::launch_stft_chirpz(c, c->d_chz, d_pcm, channels, pairs, first, n, total, d_mags);
     if (c->stft_kernel == 4) return sgx::launch_stft_bluestein(c, c->d_blu, d_pcm, channels, pairs, first, n, total, d_mags);
@@ -462,6 +463,7 @@ int sgx_query(const sgx_ctx *c, sgx_info *out)
         out->render_path = 1u | (sgx::wg4096_seed_is_within_one(c) ? 2u : 0u);
     if ((c->stft_kernel == 6 || c->stft_kernel == 9) && sgx::mixed_fixed_plan(c->d_mix)) out->render_path |= 4u;
     if (c->stft_kernel == 2 && c->d_real && !(c->cfg.flags & SGX_FLAG_COMPLEX_MONO) && (c->cfg.flags & SGX_FLAG_INDEPENDENT_FRAMES)) out->render_path |= 8u;
+    if ((c->stft_kernel == 6 || c->stft_kernel == 9) && sgx::mixed_real_serves(c, c->d_mix, c->C)) out->render_path |= 8u;
     if (c->stft_kernel == 4 && c->d_chz) out->render_path |= 4u;
     if ((c->stft_kernel == 6 || c->stft_kernel == 9) && !(c->cfg.flags & SGX_FLAG_NO_FUSED_RENDER) && sgx::mixed_can_fuse_render(c, c->d_mix)) out->render_path |= 3u;
     out->mags_bytes_per_frame = (uint64_t)c->pairs * c->M * 2 * sizeof(float);
@@ -521,7 +523,7 @@ int sgx_stft_batch_f16(sgx_ctx *c, const float *d_pcm, size_t n_samples, size_t 
     if (c->stft_kernel == 2) {
         hipError_t e = sgx::launch_stft_wg4096_f16(c, c->d_fast_wg, d_pcm, c->C, c->pairs, first_frame, n, total, d_mags_f16);
         if (e != hipSuccess) return fail_hip(c, e, "sgx_stft_batch_f16: kernel launch");
-    } else if (c->stft_kernel == 9 && c->C <= 2) {
+    } else if (c->stft_kernel == 9 && c->C <= 2 && !sgx::mixed_real_serves(c, c->d_mix, c->C)) {
         hipError_t e = sgx::launch_stft_w4800(c, c->d_w4800, d_pcm, c->C, first_frame, n, total, static_cast<float *>(d_mags_f16), true);
         if (e != hipSuccess) return fail_hip(c, e, "sgx_stft_batch_f16: kernel launch");
     } else if (c->stft_kernel == 6 || c->stft_kernel == 9) {

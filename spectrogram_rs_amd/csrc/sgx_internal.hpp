@@ -206,6 +206,7 @@ bool mixed_supported(uint32_t W);
 hipError_t mixed_init(sgx_ctx *c, void **out);
 void mixed_destroy(void *tables);
 uint32_t mixed_fixed_plan(const void *tables);
+bool mixed_real_serves(const sgx_ctx *c, const void *tables, uint32_t channels);   // real-input mode: a mono stream, every frame its own W-point transform
 // chirp-z through the composite stages of the mixed-radix kernel (stft_mixed.hip): L = 512 .. 16384, i.e. W = 86 .. 5461
 bool chirpz_supported(uint32_t W);
 hipError_t chirpz_init(sgx_ctx *c, void **out);

@@ -46,6 +46,10 @@ struct MixTables {
     float2 *d_tw = nullptr;       // per stage: [m][R - 1] w_Ns^{j k}
     uint32_t n_stages = 0, pad_every = 0, lds_points = 0, threads = 0;
     int fixed = 0;                // P when the host's plan is the compile-time one of a fixed kernel (MIX_FIXED_PLANS), else 0
+    // real-input mode (a mono stream, every frame its own transform): the plan of the W-point transform of z[m] = x[2m] + i x[2m+1]
+    // with its own d_split ([W / 2]: positions of Z[k] and Z[W - k], k = j + 1) and the untangling twiddles w_2W^k
+    MixTables *half = nullptr;
+    float2 *d_twr = nullptr;
     uint32_t ra[kMaxStages] = {}, rb[kMaxStages] = {}, m[kMaxStages] = {}, tw_off[kMaxStages] = {};
     uint32_t q_stride[kMaxStages] = {}, blk_stride[kMaxStages] = {};   // padded LDS positions: see stage()
     float inv_m[kMaxStages] = {};
@@ -59,6 +63,8 @@ struct Params {
     float *mags;
     unsigned long long first_frame, pair_base, n_frames, total_frames;
     uint32_t mono_pairs, W, P, H, C, pairs, n_stages, vec2;
+    uint32_t real;       // real-input mode: P = W points, the first stage reads sample PAIRS, the epilogue untangles (untangle_store)
+    const float2 *twr;   // [W / 2] w_2W^k, k = j + 1
     uint32_t out_f16;   // magnitudes are stored as (l, r) half pairs, 4 B per bin (the F16F16 ring of gpu_spectrogram.rs:218-226)
     float scale, inv_pad;
     // fused pixel stage (fixed plans only): magnitudes never leave LDS
@@ -118,10 +124,13 @@ struct FixGeo {
     __device__ __forceinline__ uint32_t base_of(uint32_t blk, uint32_t j) const { return blk * BS + j + (PAD ? j / (PAD ? PAD : 1u) : 0u); }
 };
 
-template <int RA, int RB, typename Geo>
+// REAL: 1 / 0 at compile time, -1 = p.real (the run-time plan).  Real-input mode: complex sample n of the first stage is
+// (x[2n] hann[2n], x[2n + 1] hann[2n + 1]) of the one mono frame, g.W() = ceil(W / 2) of them; p.vec2 = both as 8-byte words.
+template <int RA, int RB, typename Geo, int REAL = 0>
 __device__ __forceinline__ void stage(float2 *s, const Params &p, const float2 *tw, const Geo g, const Source &src, uint32_t tid)
 {
     constexpr int R = RA * RB;
+    const bool real = REAL < 0 ? p.real != 0 : REAL != 0;
     const uint32_t m = g.m(), qs = g.qs();
     const uint32_t q_nz = g.first() ? (g.W() + m - 1) / m : (uint32_t)R;   // first stage: rows q >= q_nz lie wholly in the padding
     for (uint32_t b = tid; b < g.count(); b += g.nt()) {
@@ -135,6 +144,19 @@ __device__ __forceinline__ void stage(float2 *s, const Params &p, const float2 *
                 x[q] = make_float2(0.0f, 0.0f);
                 if ((uint32_t)q < q_nz) {   // uniform
                     const uint32_t n = q * m + j, nc = n < g.W() ? n : g.W() - 1;
+                    if (real) {   // uniform
+                        float2 x2, w2;
+                        if (p.vec2) {
+                            x2 = *reinterpret_cast<const float2 *>(src.a + 2 * nc);
+                            w2 = *reinterpret_cast<const float2 *>(p.window + 2 * nc);
+                        } else {   // an odd W ends on half a pair
+                            const bool whole = 2 * nc + 1 < p.W;
+                            x2 = make_float2(src.a[2 * nc], whole ? src.a[2 * nc + 1] : 0.0f);
+                            w2 = make_float2(p.window[2 * nc], whole ? p.window[2 * nc + 1] : 0.0f);
+                        }
+                        if (n < g.W()) x[q] = make_float2(x2.x * w2.x, x2.y * w2.y);
+                        continue;
+                    }
                     const float w = p.window[nc];
                     float l, r;
                     if (p.vec2) {   // uniform
@@ -259,6 +281,63 @@ __device__ __forceinline__ void split_store(const Params &p, const float2 *s, ui
     }
 }
 
+// Real-input mode: the image holds Z = FFT_W(z), z[m] = x[2m] + i x[2m+1] of ONE real frame x.  With E / O the transforms of the
+// even / odd samples, 2 E[k] = Z[k] + conj Z[W-k], 2 O[k] = -i (Z[k] - conj Z[W-k]), the frame's 2W-point spectrum is
+// S[k] = E[k] + w_2W^k O[k] and S[W-k] = conj(E[k] - w_2W^k O[k]): one (k, W-k) pair of the image gives bins k and W-k, k = 1 .. W/2
+// (the same identity as stft4096_real.hip; W even: k = W/2 is its own partner and both formulas give the same magnitude).
+__device__ __forceinline__ float2 untangle(const Params &p, const float2 *s, uint32_t k1)
+{
+    const uint32_t w = p.split[k1];
+    const float2 a = s[w & 0xffffu], b = s[w >> 16], t = p.twr[k1];
+    const float sre = a.x + b.x, sim = a.y - b.y;     // 2 E
+    const float dre = a.x - b.x, dim = a.y + b.y;     // 2 i O
+    const float tx = t.x * dim + t.y * dre, ty = t.y * dim - t.x * dre;   // w (dim, -dre) = 2 w O
+    const float ux = sre + tx, uy = sim + ty, vx = sre - tx, vy = sim - ty;
+    return make_float2(sqrtf(fmaf(ux, ux, uy * uy)) * 0.5f * p.scale, sqrtf(fmaf(vx, vx, vy * vy)) * 0.5f * p.scale);
+}
+
+__device__ __forceinline__ void untangle_store(const Params &p, const float2 *s, long long row, uint32_t tid, uint32_t nt)
+{
+    const uint32_t M = p.W - 1, K = p.W / 2;
+    float2 *out = reinterpret_cast<float2 *>(p.mags) + (size_t)row * M;
+    __half2 *half = reinterpret_cast<__half2 *>(p.mags) + (size_t)row * M;
+    for (uint32_t k1 = tid; k1 < K; k1 += nt) {   // bin k = k1 + 1 is row element k1, bin W - k element M - 1 - k1
+        const float2 m = untangle(p, s, k1);
+        if (p.out_f16) {
+            half[k1] = __floats2half2_rn(m.x, m.x);
+            half[M - 1 - k1] = __floats2half2_rn(m.y, m.y);
+        } else {
+            st_stream(out + k1, m.x, m.x);
+            st_stream(out + (M - 1 - k1), m.y, m.y);
+        }
+    }
+}
+
+// ... and the pixel stage on it: the column (s, s) of the one frame, then pixel_passes as below (the launch asks for LDS for the column
+// and its samples, which the W-point image alone would not hold).
+template <uint32_t NT, uint32_t WN>
+__device__ __forceinline__ void pixel_epilogue_real(const Params &p, float2 *s, long long row, uint32_t tid)
+{
+    constexpr uint32_t M = WN - 1, K = WN / 2, kPer = (K + NT - 1) / NT;
+    float2 mg[kPer];
+#pragma unroll
+    for (uint32_t i = 0; i < kPer; ++i) {
+        const uint32_t k1 = tid + NT * i;
+        mg[i] = k1 < K ? untangle(p, s, k1) : make_float2(0.0f, 0.0f);
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t i = 0; i < kPer; ++i) {
+        const uint32_t k1 = tid + NT * i;
+        if (k1 < K) {
+            s[k1] = make_float2(mg[i].x, mg[i].x);
+            s[M - 1 - k1] = make_float2(mg[i].y, mg[i].y);
+        }
+    }
+    __syncthreads();
+    pixel_passes<NT>(p, s, s + M + 1, M, false, 0u, row, -1, tid);
+}
+
 // The pixel stage on the transform's own LDS image (magnitude_in -> color_for -> put_pixel, simple_spectrogram.rs:141-161), as
 // the two-pass kernel of sgx_kernels.hip does it on magnitudes from HBM: every thread first takes its bins' magnitudes
 // into registers (all reads of the transform happen before anything is written over it), the column goes to s[0 .. M), the
@@ -309,20 +388,21 @@ __global__ void __launch_bounds__(1024) stft_mixed_kernel(Params p)
         g.count_ = p.P / (p.ra[st] * p.rb[st]);
         g.qs_ = p.q_stride[st];
         g.bs_ = p.blk_stride[st];
-        g.W_ = p.W;
+        g.W_ = p.real ? (p.W + 1) / 2 : p.W;
         g.nt_ = nt;
         g.inv_m_ = p.inv_m[st];
         g.inv_pad_ = p.inv_pad;
         g.first_ = st == 0;
         const float2 *tw = p.tw + p.tw_off[st];
         switch (code) {
-#define X(A, B) case A * 8 + B: stage<A, B>(s, p, tw, g, src, tid); break;
+#define X(A, B) case A * 8 + B: stage<A, B, DynGeo, -1>(s, p, tw, g, src, tid); break;
             MIX_STAGE_CASES(X)
 #undef X
         default: break;
         }
     }
-    split_store(p, s, pair, row_a, row_b, tid, nt);
+    if (p.real) untangle_store(p, s, row_a, tid, nt);
+    else split_store(p, s, pair, row_a, row_b, tid, nt);
 }
 
 // The two lengths the application produces (0.05 s at 48 and 44.1 kHz), three stages each, everything about the plan a
@@ -330,7 +410,7 @@ __global__ void __launch_bounds__(1024) stft_mixed_kernel(Params p)
 // exactly this one before it launches these (mixed_init).
 template <int P_, int R0A, int R0B, int R1A, int R1B, int R2A, int R2B, int NT_>
 struct Fixed3 {
-    static constexpr uint32_t P = P_, W = P_ / 2, NT = NT_;
+    static constexpr uint32_t P = P_, W = (P_ + 1) / 2, NT = NT_;   // W: the non-zero inputs (real-input mode runs odd P)
     static constexpr uint32_t R0 = R0A * R0B, R1 = R1A * R1B, R2 = R2A * R2B;
     static constexpr uint32_t M0 = P / R0, M1 = M0 / R1, M2 = 1;
     static constexpr uint32_t PAD = R2 % 2 == 0 ? R2 : 0;   // an odd lane stride needs no padding
@@ -341,7 +421,7 @@ struct Fixed3 {
 
 template <int P_, int R0A, int R0B, int R1A, int R1B, int R2A, int R2B, int R3A, int R3B, int NT_>
 struct Fixed4 {
-    static constexpr uint32_t P = P_, W = P_ / 2, NT = NT_;
+    static constexpr uint32_t P = P_, W = (P_ + 1) / 2, NT = NT_;   // W: the non-zero inputs (real-input mode runs odd P)
     static constexpr uint32_t R0 = R0A * R0B, R1 = R1A * R1B, R2 = R2A * R2B, R3 = R3A * R3B;
     static constexpr uint32_t M0 = P / R0, M1 = M0 / R1, M2 = M1 / R2;
     static constexpr uint32_t PAD = R3 % 2 == 0 ? R3 : 0;
@@ -350,8 +430,8 @@ struct Fixed4 {
     static_assert(M2 == R3 && M1 % R3 == 0 && M0 % R3 == 0 && R0 * R1 * R2 * R3 == P, "plan shape");
 };
 
-template <typename F, int R0A, int R0B, int R1A, int R1B, int R2A, int R2B>
-__global__ void __launch_bounds__(F::NT, F::NT == 256 ? 4 : 8) stft_mixed_fixed_kernel(Params p)
+template <typename F, int R0A, int R0B, int R1A, int R1B, int R2A, int R2B, bool REAL>
+__global__ void __launch_bounds__(F::NT, F::NT <= 256 ? 4 : 8) stft_mixed_fixed_kernel(Params p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float2 *s = reinterpret_cast<float2 *>(smem_raw);
@@ -360,14 +440,21 @@ __global__ void __launch_bounds__(F::NT, F::NT == 256 ? 4 : 8) stft_mixed_fixed_
     long long row_a, row_b;
     Source src;
     frame_source(p, pair, src, row_a, row_b);
-    stage<R0A, R0B>(s, p, p.tw, FixGeo<F::M0, F::P / F::R0, F::pp(F::M0), F::pp(F::P), F::W, F::PAD, F::NT, true>{}, src, tid);
+    using G0 = FixGeo<F::M0, F::P / F::R0, F::pp(F::M0), F::pp(F::P), F::W, F::PAD, F::NT, true>;
+    stage<R0A, R0B, G0, REAL>(s, p, p.tw, G0{}, src, tid);
     stage<R1A, R1B>(s, p, p.tw + F::TW1, FixGeo<F::M1, F::P / F::R1, F::pp(F::M1), F::pp(F::M0), F::W, F::PAD, F::NT, false>{}, src, tid);
     stage<R2A, R2B>(s, p, p.tw, FixGeo<1, F::P / F::R2, 1, F::pp(F::M1), F::W, F::PAD, F::NT, false>{}, src, tid);
-    if (p.render) pixel_epilogue<F::NT, F::W>(p, s, pair, row_a, row_b, tid);
-    else split_store(p, s, pair, row_a, row_b, tid, F::NT);
+    if constexpr (REAL) {   // P is the WINDOW here
+        if (p.render) pixel_epilogue_real<F::NT, F::P>(p, s, row_a, tid);
+        else untangle_store(p, s, row_a, tid, F::NT);
+    } else if (p.render) {
+        pixel_epilogue<F::NT, F::W>(p, s, pair, row_a, row_b, tid);
+    } else {
+        split_store(p, s, pair, row_a, row_b, tid, F::NT);
+    }
 }
 
-template <typename F, int R0A, int R0B, int R1A, int R1B, int R2A, int R2B, int R3A, int R3B>
+template <typename F, int R0A, int R0B, int R1A, int R1B, int R2A, int R2B, int R3A, int R3B, bool REAL>
 __global__ void __launch_bounds__(F::NT, F::NT == 256 ? 4 : (F::NT == 512 ? 8 : 4)) stft_mixed_fixed4_kernel(Params p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -377,12 +464,19 @@ __global__ void __launch_bounds__(F::NT, F::NT == 256 ? 4 : (F::NT == 512 ? 8 : 
     long long row_a, row_b;
     Source src;
     frame_source(p, pair, src, row_a, row_b);
-    stage<R0A, R0B>(s, p, p.tw, FixGeo<F::M0, F::P / F::R0, F::pp(F::M0), F::pp(F::P), F::W, F::PAD, F::NT, true>{}, src, tid);
+    using G0 = FixGeo<F::M0, F::P / F::R0, F::pp(F::M0), F::pp(F::P), F::W, F::PAD, F::NT, true>;
+    stage<R0A, R0B, G0, REAL>(s, p, p.tw, G0{}, src, tid);
     stage<R1A, R1B>(s, p, p.tw + F::TW1, FixGeo<F::M1, F::P / F::R1, F::pp(F::M1), F::pp(F::M0), F::W, F::PAD, F::NT, false>{}, src, tid);
     stage<R2A, R2B>(s, p, p.tw + F::TW2, FixGeo<F::M2, F::P / F::R2, F::pp(F::M2), F::pp(F::M1), F::W, F::PAD, F::NT, false>{}, src, tid);
     stage<R3A, R3B>(s, p, p.tw, FixGeo<1, F::P / F::R3, 1, F::pp(F::M2), F::W, F::PAD, F::NT, false>{}, src, tid);
-    if (p.render) pixel_epilogue<F::NT, F::W>(p, s, pair, row_a, row_b, tid);
-    else split_store(p, s, pair, row_a, row_b, tid, F::NT);
+    if constexpr (REAL) {
+        if (p.render) pixel_epilogue_real<F::NT, F::P>(p, s, row_a, tid);
+        else untangle_store(p, s, row_a, tid, F::NT);
+    } else if (p.render) {
+        pixel_epilogue<F::NT, F::W>(p, s, pair, row_a, row_b, tid);
+    } else {
+        split_store(p, s, pair, row_a, row_b, tid, F::NT);
+    }
 }
 
 // ---- chirp-z (Bluestein) through the same stages: F[k] = c[k] sum_{n<W} (z[n] c[n]) conj(c)[k - n], c[n] = exp(-i pi n^2 / P), as a
@@ -457,7 +551,13 @@ struct ChirpTables {
 // stereo frames, 320 1.31, 512 1.33; at 4410: 1.21 / 1.17 / 1.14).
 #define MIX_FIXED_PLANS(X) X(4800, 5, 4, 5, 3, 4, 4, 512) X(4410, 7, 3, 5, 3, 7, 2, 512) X(3200, 5, 4, 5, 2, 4, 4, 512) \
                            X(1600, 5, 4, 5, 1, 4, 4, 512) X(800, 5, 2, 5, 1, 4, 4, 256) X(8820, 7, 3, 7, 3, 5, 4, 512) \
-                           X(2048, 4, 2, 4, 4, 4, 4, 256) X(1024, 4, 1, 4, 4, 4, 4, 256)
+                           X(2048, 4, 2, 4, 4, 4, 4, 256) X(1024, 4, 1, 4, 4, 4, 4, 256) \
+                           X(2400, 5, 3, 5, 2, 4, 4, 256) X(2205, 7, 3, 5, 3, 7, 1, 192)
+// (the last two: the W-point transforms of real-input mode at 48 and 44.1 kHz; every plan is instantiated for both modes.  Same-device
+// A/B, mono, 262 144 frames at hop 93, rows / PCM -> pixels: 2400 points at 192 threads 2.07 / 3.86 ms, 256 2.03 / 3.25, 320 2.17 / 3.07,
+// 512 2.23 / 2.77; 2205 points at 160 2.02 / 4.31, 192 1.97 / 3.89, 256 1.99 / 3.46, 320 2.22 / 3.27 -- the transform wants one
+// butterfly per thread, the pixel stage behind it every thread it can get: real-input mode to pixels runs these two plans wider)
+#define MIX_REAL_RENDER_PLANS(X) X(2400, 5, 3, 5, 2, 4, 4, 512) X(2205, 7, 3, 5, 3, 7, 1, 320)
 // four stages: 0.05 s at 96 / 192 / 176.4 kHz, and the 8192-point power of two
 #define MIX_FIXED4_PLANS(X) X(9600, 4, 3, 5, 2, 5, 1, 4, 4, 1024) X(19200, 5, 3, 5, 1, 4, 4, 4, 4, 1024) \
                             X(17640, 5, 3, 7, 2, 4, 3, 7, 1, 1024) X(8192, 4, 1, 4, 2, 4, 4, 4, 4, 512)
@@ -537,11 +637,13 @@ static bool make_plan(uint32_t P, Plan &plan)
 
 }  // namespace mix
 
-hipError_t mixed_init(sgx_ctx *c, void **out)
+// Tables of a P-point plan.  real: P is the WINDOW of real-input mode -- the split table pairs Z[k] with Z[P - k], k = 1 .. P / 2, and
+// the untangling twiddles w_2P^k come with it.  hipErrorInvalidValue: no plan for P (the caller of the real-input half goes without).
+static hipError_t build_tables(uint32_t P, bool real, mix::MixTables **out)
 {
     using namespace mix;
     auto *t = new MixTables();
-    const uint32_t P = c->P, M = c->W - 1;
+    const uint32_t M = real ? P / 2 : P / 2 - 1;
     Plan plan;
     if (!make_plan(P, plan)) { delete t; return hipErrorInvalidValue; }
     t->n_stages = (uint32_t)plan.stages.size();
@@ -629,9 +731,35 @@ hipError_t mixed_init(sgx_ctx *c, void **out)
     if (e == hipSuccess) e = hipMemcpy(t->d_split, split.data(), (size_t)M * sizeof(uint32_t), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&t->d_tw), std::max<size_t>(tw.size(), 1) * sizeof(float2));
     if (e == hipSuccess && !tw.empty()) e = hipMemcpy(t->d_tw, tw.data(), tw.size() * sizeof(float2), hipMemcpyHostToDevice);
+    if (e == hipSuccess && real) {
+        std::vector<float2> twr(std::max<uint32_t>(M, 1));
+        for (uint32_t j = 0; j < M; ++j) {
+            const uint32_t k = j + 1;   // w_2P^k, k <= P / 2: the first quadrant of the circle, its end exact
+            const double ang = -M_PI * (double)k / (double)P;
+            twr[j] = 2 * k == P ? make_float2(0.0f, -1.0f) : make_float2((float)cos(ang), (float)sin(ang));
+        }
+        e = hipMalloc(reinterpret_cast<void **>(&t->d_twr), twr.size() * sizeof(float2));
+        if (e == hipSuccess) e = hipMemcpy(t->d_twr, twr.data(), twr.size() * sizeof(float2), hipMemcpyHostToDevice);
+    }
     if (e != hipSuccess) {
         mixed_destroy(t);
         return e;
+    }
+    *out = t;
+    return hipSuccess;
+}
+
+hipError_t mixed_init(sgx_ctx *c, void **out)
+{
+    mix::MixTables *t = nullptr;
+    hipError_t e = build_tables(c->P, false, &t);
+    if (e != hipSuccess) return e;
+    if (c->C == 1 && c->W >= 8) {   // a mono stream: the W-point plan of real-input mode, where W has one
+        e = build_tables(c->W, true, &t->half);
+        if (e != hipSuccess && e != hipErrorInvalidValue) {
+            mixed_destroy(t);
+            return e;
+        }
     }
     *out = t;
     return hipSuccess;
@@ -643,14 +771,43 @@ void mixed_destroy(void *tables)
 {
     auto *t = static_cast<mix::MixTables *>(tables);
     if (!t) return;
+    if (t->half) mixed_destroy(t->half);
     if (t->d_split) (void)hipFree(t->d_split);
     if (t->d_tw) (void)hipFree(t->d_tw);
+    if (t->d_twr) (void)hipFree(t->d_twr);
     delete t;
+}
+
+// a mono stream whose frames each get their own transform (the default; SGX_FLAG_COMPLEX_MONO: as (s, s) through the 2W-point plan)
+bool mixed_real_serves(const sgx_ctx *c, const void *tables, uint32_t channels)
+{
+    const auto *t = static_cast<const mix::MixTables *>(tables);
+    return t && t->half && channels == 1 && (c->cfg.flags & SGX_FLAG_INDEPENDENT_FRAMES) && !(c->cfg.flags & SGX_FLAG_COMPLEX_MONO);
+}
+
+// real-input mode from PCM to pixels: a compile-time W-point plan, the palette conditions of the fused pixel stage, W / 2 bin pairs in
+// registers (ten per thread at most); the launch sizes its LDS for the column and its samples
+static bool real_fuses_render(const sgx_ctx *c, const mix::MixTables *t)
+{
+    const auto *h = t->half;
+    if (!h || !h->fixed || c->pal.stereo || c->pal.segments || c->pal.n != 256 || !c->d_pal_seed || !wg4096_seed_is_within_one(c)) return false;
+    unsigned nt = 0;
+#define X(Pn, A0, B0, A1, B1, A2, B2, N) if (h->fixed == Pn) nt = N;
+    MIX_FIXED_PLANS(X)
+    MIX_REAL_RENDER_PLANS(X)
+#undef X
+#define X(Pn, A0, B0, A1, B1, A2, B2, A3, B3, N) if (h->fixed == Pn) nt = N;
+    MIX_FIXED4_PLANS(X)
+#undef X
+    return nt && c->W / 2 <= nt * 10u && ((size_t)c->M + 1 + c->tab.samples.size()) * sizeof(float2) <= 160 * 1024;
 }
 
 bool mixed_can_fuse_render(const sgx_ctx *c, const void *tables)
 {
     const auto *t = static_cast<const mix::MixTables *>(tables);
+    // (a mono stream that real-input mode cannot take to pixels goes the two-kernel route on real-input ROWS, not through the 2W-point
+    // plan as an (s, s) frame: the pixels of a context are those of its rows)
+    if (mixed_real_serves(c, tables, c->C)) return real_fuses_render(c, t);
     if (!t || !t->fixed || c->pal.stereo || c->pal.segments || c->pal.n != 256 || !c->d_pal_seed || !wg4096_seed_is_within_one(c)) return false;
     // the column and its interpolated samples on the transform's LDS image; ten bins per thread in registers at most
     unsigned nt = 0;
@@ -684,6 +841,9 @@ static hipError_t launch_mixed(const sgx_ctx *c, const void *tables, const float
     using namespace mix;
     if (n_frames == 0) return hipSuccess;
     const auto *t = static_cast<const MixTables *>(tables);
+    // a mono stream, every frame its own transform (the default): real-input mode on the W-point plan, where there is one
+    const bool real = mixed_real_serves(c, tables, channels) && (!d_rgba || real_fuses_render(c, t));
+    if (real) t = t->half;
     Params p{};
     if (d_rgba) {
         p.render = 1;
@@ -701,7 +861,9 @@ static hipError_t launch_mixed(const sgx_ctx *c, const void *tables, const float
     p.tw = t->d_tw;
     p.split = t->d_split;
     p.W = c->W;
-    p.P = c->P;
+    p.P = real ? c->W : c->P;
+    p.real = real ? 1u : 0u;
+    p.twr = t->d_twr;
     p.H = c->H;
     p.C = channels;
     p.pairs = pairs;
@@ -723,7 +885,9 @@ static hipError_t launch_mixed(const sgx_ctx *c, const void *tables, const float
     p.total_frames = total_frames;
     // (l, r) of a channel pair as one 8-byte word: even channel count and an 8-byte aligned stream
     p.vec2 = (channels >= 2 && channels % 2 == 0 && reinterpret_cast<uintptr_t>(d_pcm) % 8 == 0) ? 1u : 0u;
-    const size_t lds = (size_t)t->lds_points * sizeof(float2);
+    if (real) p.vec2 = (c->W % 2 == 0 && c->H % 2 == 0 && reinterpret_cast<uintptr_t>(d_pcm) % 8 == 0) ? 1u : 0u;   // sample PAIRS of one channel
+    size_t lds = (size_t)t->lds_points * sizeof(float2);
+    if (real && d_rgba) lds = std::max(lds, ((size_t)c->M + 1 + c->tab.samples.size()) * sizeof(float2));   // the column and its samples
     const unsigned threads = t->threads;
     hipError_t attr_err = hipSuccess;
     auto go = [&](auto kernel, unsigned nt, dim3 grid) {
@@ -734,13 +898,27 @@ static hipError_t launch_mixed(const sgx_ctx *c, const void *tables, const float
         hipLaunchKernelGGL(kernel, grid, dim3(nt), lds, c->stream, p);
     };
     auto launch = [&](dim3 grid) {
-        switch (t->fixed) {
+        if (real && d_rgba)
+            switch (t->fixed) {
 #define X(Pn, A0, B0, A1, B1, A2, B2, N) \
-    case Pn: go(stft_mixed_fixed_kernel<Fixed3<Pn, A0, B0, A1, B1, A2, B2, N>, A0, B0, A1, B1, A2, B2>, N, grid); break;
+    case Pn: go(stft_mixed_fixed_kernel<Fixed3<Pn, A0, B0, A1, B1, A2, B2, N>, A0, B0, A1, B1, A2, B2, true>, N, grid); return;
+                MIX_REAL_RENDER_PLANS(X)
+#undef X
+            default: break;
+            }
+        switch (t->fixed) {
+#define X(Pn, A0, B0, A1, B1, A2, B2, N)                                                                                      \
+    case Pn:                                                                                                                  \
+        if (real) go(stft_mixed_fixed_kernel<Fixed3<Pn, A0, B0, A1, B1, A2, B2, N>, A0, B0, A1, B1, A2, B2, true>, N, grid);   \
+        else go(stft_mixed_fixed_kernel<Fixed3<Pn, A0, B0, A1, B1, A2, B2, N>, A0, B0, A1, B1, A2, B2, false>, N, grid);      \
+        break;
             MIX_FIXED_PLANS(X)
 #undef X
-#define X(Pn, A0, B0, A1, B1, A2, B2, A3, B3, N) \
-    case Pn: go(stft_mixed_fixed4_kernel<Fixed4<Pn, A0, B0, A1, B1, A2, B2, A3, B3, N>, A0, B0, A1, B1, A2, B2, A3, B3>, N, grid); break;
+#define X(Pn, A0, B0, A1, B1, A2, B2, A3, B3, N)                                                                                               \
+    case Pn:                                                                                                                                   \
+        if (real) go(stft_mixed_fixed4_kernel<Fixed4<Pn, A0, B0, A1, B1, A2, B2, A3, B3, N>, A0, B0, A1, B1, A2, B2, A3, B3, true>, N, grid);   \
+        else go(stft_mixed_fixed4_kernel<Fixed4<Pn, A0, B0, A1, B1, A2, B2, A3, B3, N>, A0, B0, A1, B1, A2, B2, A3, B3, false>, N, grid);      \
+        break;
             MIX_FIXED4_PLANS(X)
 #undef X
         default: go(stft_mixed_kernel, threads, grid); break;

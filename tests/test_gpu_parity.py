@@ -690,7 +690,7 @@ def test_chirp_z_through_the_composite_stages(torch_cuda, mags_err, Wt, Ht, ch):
 
 @pytest.mark.parametrize("sr,Wexp,fixed", [(8000, 400, True), (16000, 800, True), (32000, 1600, True), (44100, 2205, True), (48000, 2400, True),
                                            (88200, 4410, True), (96000, 4800, True), (176400, 8820, True), (192000, 9600, True),
-                                           (24000, 1200, False), (64000, 3200, False)])
+                                           (24000, 1200, True), (12000, 600, False), (64000, 3200, False)])
 def test_duration_sized_windows_of_the_usual_sample_rates(torch_cuda, mags_err, sr, Wexp, fixed):
     # FastFourierTransform::new(sample_rate, 0.05) (gpu_spectrogram.rs:323): the lengths the usual device rates produce run
     # instantiations of the mixed-radix kernel whose plan is a compile-time constant (sgx_info.render_path bit 2), every
@@ -994,6 +994,40 @@ def test_real_input_kernel_at_other_hops(torch_cuda, mags_err, Ht):
     px = eng.render_batch(dev)
     assert torch.equal(px[:, 0], eng.render_mags(torch.from_numpy(got[:, 0]).cuda().contiguous()))
     assert torch.equal(eng.render_batch(dev, first_frame=5, max_frames=7), px[5:12])
+
+
+@pytest.mark.parametrize("Wt,Ht,off", [(2400, 93, 0), (2400, 256, 1), (2205, 85, 0), (2205, 512, 0), (1200, 100, 0), (300, 7, 1), (4800, 1024, 0),
+                                       (9600, 3000, 0), (1000, 250, 0), (1024, 256, 0), (4096, 512, 2), (441, 100, 0), (12, 2, 0), (9, 3, 0), (15, 4, 1)])
+def test_real_input_mode_of_the_mixed_radix_kernel(torch_cuda, mags_err, Wt, Ht, off):
+    # every window the mixed-radix kernel serves (2W = 2^a 3^b 5^c 7^d), a mono stream in the default mode: the W-point transform of
+    # z[m] = x[2m] + i x[2m+1] and the untangling epilogue (stft_mixed.hip: untangle_store) -- compile-time plans (2400, 2205, 4800,
+    # 9600 points ...) and the run-time plan, odd W (the last sample is half a pair), odd hops and a stream that is not 8-byte aligned
+    # (scalar loads); W 2400 leaves the 4800-point kernel for it.  Against the float64 truth per frame, own peak.
+    torch = torch_cuda
+    frames = 11
+    n = Wt + (frames - 1) * Ht + min(3, Ht - 1)
+    pcm = oracle.white_noise(n + off, seed=900 + Wt + Ht)
+    pcm[(n + off) // 2:] *= np.float32(1e-3)
+    dev = to_dev(torch, pcm)[off:]
+    pcm = pcm[off:]
+    Mt = Wt - 1
+    eng = engine(window_samples=Wt, hop_samples=Ht, channels=1, interp=1, gradient="inferno")
+    assert eng.info.stft_kernel in (6, 9) and eng.info.render_path & 8
+    got = eng.stft_batch(dev).cpu().numpy()
+    truth = np.stack([oracle.np_truth_frame(np.stack([pcm[t * Ht:t * Ht + Wt]] * 2, 1), Wt) for t in range(frames)])
+    assert got.shape == (frames, 1, Mt, 2)
+    assert np.array_equal(got[..., 0], got[..., 1])
+    assert mags_err(got[:, 0], truth) <= 1.0
+    cplx_eng = engine(window_samples=Wt, hop_samples=Ht, channels=1, complex_mono=True)
+    assert not cplx_eng.info.render_path & 8
+    cplx = cplx_eng.stft_batch(dev).cpu().numpy()
+    assert mags_err(got, cplx.astype(np.float64)) <= 2.0                 # the same frames as (s, s) through the 2W-point plan
+    for first, cnt in ((1, 1), (3, 6), (10, 1), (8, 100)):
+        assert np.array_equal(eng.stft_batch(dev, first_frame=first, max_frames=cnt).cpu().numpy(), got[first:first + cnt])
+    assert torch.equal(eng.stft_batch_f16(dev), torch.from_numpy(got).cuda().to(torch.float16))
+    px = eng.render_batch(dev)
+    assert torch.equal(px[:, 0], eng.render_mags(torch.from_numpy(got[:, 0]).cuda().contiguous()))
+    assert torch.equal(eng.render_batch(dev, first_frame=5, max_frames=4), px[5:9])
 
 
 def _pair_error(x, ref, first_frame=0):
