@@ -552,8 +552,9 @@ struct ChirpTables {
 #define MIX_FIXED_PLANS(X) X(4800, 5, 4, 5, 3, 4, 4, 512) X(4410, 7, 3, 5, 3, 7, 2, 512) X(3200, 5, 4, 5, 2, 4, 4, 512) \
                            X(1600, 5, 4, 5, 1, 4, 4, 512) X(800, 5, 2, 5, 1, 4, 4, 256) X(8820, 7, 3, 7, 3, 5, 4, 512) \
                            X(2048, 4, 2, 4, 4, 4, 4, 256) X(1024, 4, 1, 4, 4, 4, 4, 256) \
-                           X(2400, 5, 3, 5, 2, 4, 4, 256) X(2205, 7, 3, 5, 3, 7, 1, 192)
-// (the last two: the W-point transforms of real-input mode at 48 and 44.1 kHz; every plan is instantiated for both modes.  Same-device
+                           X(2400, 5, 3, 5, 2, 4, 4, 256) X(2205, 7, 3, 5, 3, 7, 1, 192) \
+                           X(4096, 4, 4, 4, 4, 4, 4, 256) X(512, 4, 1, 4, 2, 4, 4, 128)
+// (2400, 2205, 4096, 512: the W-point transforms of real-input mode at 48 and 44.1 kHz and at W 4096 / 512; every plan is instantiated for both modes.  Same-device
 // A/B, mono, 262 144 frames at hop 93, rows / PCM -> pixels: 2400 points at 192 threads 2.07 / 3.86 ms, 256 2.03 / 3.25, 320 2.17 / 3.07,
 // 512 2.23 / 2.77; 2205 points at 160 2.02 / 4.31, 192 1.97 / 3.89, 256 1.99 / 3.46, 320 2.22 / 3.27 -- the transform wants one
 // butterfly per thread, the pixel stage behind it every thread it can get: real-input mode to pixels runs these two plans wider)
@@ -687,7 +688,10 @@ static hipError_t build_tables(uint32_t P, bool real, mix::MixTables **out)
         return std::max(std::min(cap, (widest + 63) / 64 * 64), 64u);
     };
     uint32_t best_d = 0;
-    if (r_last % 2 == 0 && (size_t)(P + P / r_last) * sizeof(float2) <= kLds && resident_of(P + P / r_last) == resident_of(P)) best_d = r_last;
+    // (round 4: "no resident workgroup" counts up to four -- the registers hold no more than four 256-thread workgroups of the run-time
+    // geometry or 512-thread ones of a compile-time plan anyway.  Same-device A/B: 4000 points +15 %, 3600 +-0, 3888 -4 %, and the
+    // 4096-point plan of real-input mode at W 4096 becomes the compile-time one: 41 -> 68 M frames/s.  gpurun_out/r4_km_pad.log)
+    if (r_last % 2 == 0 && (size_t)(P + P / r_last) * sizeof(float2) <= kLds && resident_of(P + P / r_last) >= std::min(resident_of(P), 4u)) best_d = r_last;
     t->pad_every = best_d;
     t->lds_points = best_d ? P + P / best_d : P;
     auto padpos = [&](uint32_t i) { return i + (t->pad_every ? i / t->pad_every : 0u); };

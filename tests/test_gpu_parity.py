@@ -997,7 +997,7 @@ def test_real_input_kernel_at_other_hops(torch_cuda, mags_err, Ht):
 
 
 @pytest.mark.parametrize("Wt,Ht,off", [(2400, 93, 0), (2400, 256, 1), (2205, 85, 0), (2205, 512, 0), (1200, 100, 0), (300, 7, 1), (4800, 1024, 0),
-                                       (9600, 3000, 0), (1000, 250, 0), (1024, 256, 0), (4096, 512, 2), (441, 100, 0), (12, 2, 0), (9, 3, 0), (15, 4, 1)])
+                                       (9600, 3000, 0), (1000, 250, 0), (1024, 256, 0), (4096, 512, 2), (441, 100, 0), (12, 2, 0), (9, 3, 0), (15, 4, 1), (512, 64, 0), (2000, 500, 0), (1944, 97, 0)])
 def test_real_input_mode_of_the_mixed_radix_kernel(torch_cuda, mags_err, Wt, Ht, off):
     # every window the mixed-radix kernel serves (2W = 2^a 3^b 5^c 7^d), a mono stream in the default mode: the W-point transform of
     # z[m] = x[2m] + i x[2m+1] and the untangling epilogue (stft_mixed.hip: untangle_store) -- compile-time plans (2400, 2205, 4800,

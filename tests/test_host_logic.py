@@ -134,8 +134,11 @@ def test_mixed_radix_plan_and_block_index_arithmetic_for_every_supported_length(
     # host: every stage of every supported length (2W <= 20480 with prime factors 2, 3, 5, 7) is checked here,
     # and that the kernel has a stage for every (RA, RB) the plan can ask for.
     have = {(7, 4), (7, 3), (7, 2), (5, 5), (5, 4), (5, 3), (5, 2), (4, 4), (4, 3), (4, 2), (3, 3), (3, 2), (7, 1), (5, 1), (4, 1), (3, 1), (2, 1)}
+    # real-input mode (a mono stream, every frame its own transform) runs the W-point plan: 2400 and 2205 points at 48 and 44.1 kHz,
+    # odd lengths included -- so every length from 8 on is checked, not only the even 2W
+    assert [a * b for a, b in mixed_radix_plan(2400)] == [15, 10, 16] and [a * b for a, b in mixed_radix_plan(2205)] == [21, 15, 7]
     lengths = 0
-    for P in range(8, 20481, 2):
+    for P in range(8, 20481):
         plan = mixed_radix_plan(P)
         if plan is None:
             continue
@@ -155,7 +158,7 @@ def test_mixed_radix_plan_and_block_index_arithmetic_for_every_supported_length(
         j = np.arange(P // (plan[0][0] * plan[0][1]), dtype=np.float32)
         got = ((j + np.float32(0.5)) * (np.float32(1.0) / np.float32(r_last))).astype(np.uint32)
         assert np.array_equal(got, (np.arange(len(j)) // r_last).astype(np.uint32)), (P, r_last)
-    assert lengths > 300
+    assert lengths > 400
 
 
 def test_default_color_schemes_follow_the_reference_list():
