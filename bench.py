@@ -756,7 +756,7 @@ def app_point_leg(args, torch, device):
     name = KERNEL_NAMES.get(eng.info.stft_kernel, ("?", "?"))
     # the same point for a mono device (audio_input_list_model.rs:67-69 duplicates the sample into (s, s)): two frames per transform
     del rgba, pcm
-    mono = SpectrogramEngine(48000.0, period=0.05, hop_samples=H_APP, channels=1, device=device)                       # default: every frame its own (s, s) transform
+    mono = SpectrogramEngine(48000.0, period=0.05, hop_samples=H_APP, channels=1, device=device)                       # default: every frame its own transform
     monop = SpectrogramEngine(48000.0, period=0.05, hop_samples=H_APP, channels=1, device=device, paired_frames=True)   # opt-in: two frames per transform
     pcm1 = mono.white_noise((Fa - 1) * H_APP + W_APP)
     out1 = torch.empty((Fa, 1, W_APP - 1, 2), dtype=torch.float32, device=mono.device)
@@ -764,6 +764,7 @@ def app_point_leg(args, torch, device):
     m1 = measure_leg(torch, lambda: mono.stft_batch(pcm1, out=out1), args.leg_sustain_s)
     m1p = measure_leg(torch, lambda: monop.stft_batch(pcm1, out=out1), args.leg_sustain_s)
     mean1, mean1p = m1["mean_ms"], m1p["mean_ms"]
+    mono_real = bool(mono.info.render_path & 8)
     bytes1 = H_APP * 4 + (W_APP - 1) * 8
     ach1, ach1p = Fa * bytes1 / (mean1 * 1e-3) / 1e9, Fa * bytes1 / (mean1p * 1e-3) / 1e9
     del out1, pcm1
@@ -775,7 +776,7 @@ def app_point_leg(args, torch, device):
         "rows_f32": {"frames_per_s": Fa / (mean * 1e-3), **leg_times(m),
                      "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                                   "bytes_per_frame": ALGO_BYTES_APP, "frames_per_launch": Fa}},
-        "mono_rows_f32": {"frames_per_s": Fa / (mean1 * 1e-3), **leg_times(m1), "mono_mode": "every frame its own (s, s) transform (default)",
+        "mono_rows_f32": {"frames_per_s": Fa / (mean1 * 1e-3), **leg_times(m1), "mono_mode": "every frame its own transform (default): real-input mode of the mixed-radix kernel, 2400 points" if mono_real else "every frame its own (s, s) transform (default)",
                           "roofline": {"bound": "hbm", "achieved": ach1, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach1 / HBM_PEAK_GBS,
                                        "bytes_per_frame": bytes1, "frames_per_launch": Fa}},
         "mono_rows_f32_paired_frames": {"frames_per_s": Fa / (mean1p * 1e-3), **leg_times(m1p), "mono_mode": "two frames per transform (SGX_FLAG_PAIRED_FRAMES)",

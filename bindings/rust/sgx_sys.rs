@@ -46,4 +46,4 @@ pub const HIP_MEMCPY_DEVICE_TO_HOST: c_int = 2;
 // own transform, the reference's dataflow (at W 2048 and an even hop as a real-input transform, elsewhere the (s, s) transform).
 pub const SGX_FLAG_PAIRED_FRAMES: u32 = 1024;   // opt-in: two frames per transform (half the work; tolerance against the pair's peak)
 pub const SGX_FLAG_INDEPENDENT_FRAMES: u32 = 16; // never pair: the default since round 4
-pub const SGX_FLAG_COMPLEX_MONO: u32 = 512;     // A/B: the literal (s, s) transform per frame at W 2048
+pub const SGX_FLAG_COMPLEX_MONO: u32 = 512;     // A/B: the literal (s, s) transform per frame where a real-input kernel would run

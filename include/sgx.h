@@ -90,8 +90,10 @@ typedef struct sgx_config {
  * (audio_input_list_model.rs:67-69, fft.rs:47-99).  DEFAULT here, at every window and hop: exactly that dataflow, one transform per
  * frame -- every frame within north_star's tolerance of its OWN peak on any input.  At W 2048 and an even hop (8-byte aligned stream)
  * it is computed as the 4096-point spectrum of a REAL frame, a 2048-point complex transform + one butterfly per bin
- * (stft4096_real.hip; at H 256, the BASELINE shape, with the window sliding in registers): the cost of half a transform.  Elsewhere
- * it is the (s, s) transform itself.
+ * (stft4096_real.hip; at H 256, the BASELINE shape, with the window sliding in registers): the cost of half a transform.  The
+ * mixed-radix kernel does the same at every window it serves (stft_mixed.hip, real-input mode: the application's 2400 and 2205, every
+ * 2-3-5-7-smooth length, W 512 / 1024 / 4096; any hop and alignment).  Elsewhere (W 2048 at odd hops, W 8192, chirp-z lengths, small
+ * powers of two) it is the (s, s) transform itself.
  * SGX_FLAG_PAIRED_FRAMES (opt-in): two frames (2j, 2j+1) per transform in its real and imaginary part -- half the work of the (s, s)
  * transform, but the quieter frame of a pair carries the louder one's float32 rounding floor: the tolerance then holds against the
  * PAIR's peak only (measured: up to 4.7 x the own-peak tolerance across a 60 dB step inside one hop, unbounded next to digital
@@ -99,8 +101,8 @@ typedef struct sgx_config {
 #define SGX_FLAG_PAIRED_FRAMES 1024u /* mono: two frames per transform (the default of rounds 1-3) */
 #define SGX_FLAG_INDEPENDENT_FRAMES 16u /* mono: never pair.  The default since round 4; kept for callers that set it, and it wins over
                                            SGX_FLAG_PAIRED_FRAMES where both are given */
-#define SGX_FLAG_COMPLEX_MONO 512u /* mono at W 2048: the literal (s, s) 4096-point complex transform per frame -- fft.rs:47-57 --
-                                      instead of the real-input kernel (A/B; implies no pairing) */
+#define SGX_FLAG_COMPLEX_MONO 512u /* mono: the literal (s, s) 2W-point complex transform per frame -- fft.rs:47-57 -- wherever a
+                                      real-input kernel would run (A/B; implies no pairing) */
 #define SGX_FLAG_LUT_WALK 64u      /* fused pixel kernel: walk the dB thresholds from the log2 seed even where the host has shown that one compare pair settles the LUT index (A/B, and the test of the fallback) */
 #define SGX_FLAG_LEGACY_16K 32u    /* W = 8192: the first 16384-point kernel (whole transform in LDS, one workgroup per CU) instead of the four-residue one (A/B) */
 #define SGX_FLAG_RESIDUE_16K 128u  /* W = 8192: the second 16384-point kernel (four 4096-point residues of the OUTPUT, two passes of a 512-thread workgroup) instead of the time-decimated one (A/B) */
