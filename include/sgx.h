@@ -92,8 +92,8 @@ typedef struct sgx_config {
  * it is computed as the 4096-point spectrum of a REAL frame, a 2048-point complex transform + one butterfly per bin
  * (stft4096_real.hip; at H 256, the BASELINE shape, with the window sliding in registers): the cost of half a transform.  The
  * mixed-radix kernel does the same at every window it serves (stft_mixed.hip, real-input mode: the application's 2400 and 2205, every
- * 2-3-5-7-smooth length, W 512 / 1024 / 4096; any hop and alignment).  Elsewhere (W 2048 at odd hops, W 8192, chirp-z lengths, small
- * powers of two) it is the (s, s) transform itself.
+ * 2-3-5-7-smooth length, W 512 / 1024 / 4096; any hop and alignment), the chirp-z kernel too from W 86 on (1102 at 22.05 kHz).
+ * Elsewhere (W 2048 at odd hops, W 8192, the small windows of the generic kernels) it is the (s, s) transform itself.
  * SGX_FLAG_PAIRED_FRAMES (opt-in): two frames (2j, 2j+1) per transform in its real and imaginary part -- half the work of the (s, s)
  * transform, but the quieter frame of a pair carries the louder one's float32 rounding floor: the tolerance then holds against the
  * PAIR's peak only (measured: up to 4.7 x the own-peak tolerance across a 60 dB step inside one hop, unbounded next to digital
@@ -129,8 +129,8 @@ typedef struct sgx_info {
                                  stft_kernel 4 (chirp-z) for W = 86 .. 5461, e.g. 1102 at 22.05 kHz;
                                  bit 3 = a mono stream runs a real-input kernel, the W-point transform of sample pairs (unless
                                  SGX_FLAG_PAIRED_FRAMES / SGX_FLAG_COMPLEX_MONO): at W 2048 with an even hop (needs an 8-byte aligned
-                                 stream, else the (s, s) kernel takes it), and at every window the mixed-radix kernel serves
-                                 (stft_kernel 6 and 9, any hop and alignment) */
+                                 stream, else the (s, s) kernel takes it), and at every window the mixed-radix kernel or the chirp-z
+                                 stages serve (stft_kernel 6, 9 and 4 with bit 2; any hop and alignment) */
     uint64_t mags_bytes_per_frame; /* pairs * M * 2 * 4 */
     uint64_t rgba_bytes_per_frame; /* pairs * R * 4     */
 } sgx_info;

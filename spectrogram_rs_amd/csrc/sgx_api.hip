@@ -466,6 +466,7 @@ int sgx_query(const sgx_ctx *c, sgx_info *out)
     if (c->stft_kernel == 2 && c->d_real && !(c->cfg.flags & SGX_FLAG_COMPLEX_MONO) && (c->cfg.flags & SGX_FLAG_INDEPENDENT_FRAMES)) out->render_path |= 8u;
     if ((c->stft_kernel == 6 || c->stft_kernel == 9) && sgx::mixed_real_serves(c, c->d_mix, c->C)) out->render_path |= 8u;
     if (c->stft_kernel == 4 && c->d_chz) out->render_path |= 4u;
+    if (c->stft_kernel == 4 && sgx::chirpz_real_serves(c, c->d_chz, c->C)) out->render_path |= 8u;
     if ((c->stft_kernel == 6 || c->stft_kernel == 9) && !(c->cfg.flags & SGX_FLAG_NO_FUSED_RENDER) && sgx::mixed_can_fuse_render(c, c->d_mix)) out->render_path |= 3u;
     out->mags_bytes_per_frame = (uint64_t)c->pairs * c->M * 2 * sizeof(float);
     out->rgba_bytes_per_frame = (uint64_t)c->pairs * c->R * 4;

@@ -211,6 +211,7 @@ bool mixed_real_serves(const sgx_ctx *c, const void *tables, uint32_t channels);
 bool chirpz_supported(uint32_t W);
 hipError_t chirpz_init(sgx_ctx *c, void **out);
 void chirpz_destroy(void *tables);
+bool chirpz_real_serves(const sgx_ctx *c, const void *tables, uint32_t channels);   // real-input mode, as mixed_real_serves
 hipError_t launch_stft_chirpz(const sgx_ctx *c, const void *tables, const float *d_pcm, uint32_t channels, uint32_t pairs,
                               size_t first_frame, size_t n_frames, size_t total_frames, float *d_mags);
 bool mixed_can_fuse_render(const sgx_ctx *c, const void *tables);   // one kernel from PCM to pixels at this length, palette and row table

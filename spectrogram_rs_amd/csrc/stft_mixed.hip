@@ -154,7 +154,7 @@ __device__ __forceinline__ void stage(float2 *s, const Params &p, const float2 *
                             x2 = make_float2(src.a[2 * nc], whole ? src.a[2 * nc + 1] : 0.0f);
                             w2 = make_float2(p.window[2 * nc], whole ? p.window[2 * nc + 1] : 0.0f);
                         }
-                        if (n < g.W()) x[q] = make_float2(x2.x * w2.x, x2.y * w2.y);
+                        if (n < g.W()) x[q] = p.chirp ? cmul(make_float2(x2.x * w2.x, x2.y * w2.y), p.chirp[nc]) : make_float2(x2.x * w2.x, x2.y * w2.y);
                         continue;
                     }
                     const float w = p.window[nc];
@@ -290,8 +290,17 @@ __device__ __forceinline__ void split_store(const Params &p, const float2 *s, ui
 // (the same identity as stft4096_real.hip; W even: k = W/2 is its own partner and both formulas give the same magnitude).
 __device__ __forceinline__ float2 untangle(const Params &p, const float2 *s, uint32_t k1)
 {
-    const uint32_t w = p.split[k1];
-    const float2 a = s[w & 0xffffu], b = s[w >> 16], t = p.twr[k1];
+    float2 a, b;
+    if (p.chirp) {   // chirp-z: natural order, one point of padding in 16; Z[k] = c[k] y[k] (P = W here)
+        const uint32_t k = k1 + 1, kp = p.P - k;
+        a = cmul(s[k + (k >> 4)], p.chirp[k]);
+        b = cmul(s[kp + (kp >> 4)], p.chirp[kp]);
+    } else {
+        const uint32_t w = p.split[k1];
+        a = s[w & 0xffffu];
+        b = s[w >> 16];
+    }
+    const float2 t = p.twr[k1];
     const float sre = a.x + b.x, sim = a.y - b.y;     // 2 E
     const float dre = a.x - b.x, dim = a.y + b.y;     // 2 i O
     const float tx = t.x * dim + t.y * dre, ty = t.y * dim - t.x * dre;   // w (dim, -dre) = 2 w O
@@ -487,7 +496,7 @@ __global__ void __launch_bounds__(F::NT, F::NT == 256 ? 4 : (F::NT == 512 ? 8 : 
 // radix-4 ladder): forward stages (the first one reads z[n] hann[n] c[n] from the stream, rows past W are zero), pointwise
 // product with B^ = FFT_L(conj chirp) / L stored at the image's own positions, the stages inverted in reverse order (natural
 // order back at position n + n / 16), split with the second chirp factor.
-template <typename F, int R0A, int R0B, int R1A, int R1B, int R2A, int R2B>
+template <typename F, int R0A, int R0B, int R1A, int R1B, int R2A, int R2B, bool REAL>
 __global__ void __launch_bounds__(F::NT, F::NT >= 256 ? 4 : 2) chirpz3_kernel(Params p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -501,7 +510,7 @@ __global__ void __launch_bounds__(F::NT, F::NT >= 256 ? 4 : 2) chirpz3_kernel(Pa
     using G0 = FixGeo<F::M0, F::P / F::R0, F::pp(F::M0), F::pp(F::P), 0, F::PAD, F::NT, false>;
     using G1 = FixGeo<F::M1, F::P / F::R1, F::pp(F::M1), F::pp(F::M0), 0, F::PAD, F::NT, false>;
     using G2 = FixGeo<1, F::P / F::R2, 1, F::pp(F::M1), 0, F::PAD, F::NT, false>;
-    stage<R0A, R0B>(s, p, p.tw, G0f{p.W}, src, tid);
+    stage<R0A, R0B, G0f, REAL>(s, p, p.tw, G0f{REAL ? (p.W + 1) / 2 : p.W}, src, tid);   // (real-input mode: ceil(W / 2) sample pairs)
     stage<R1A, R1B>(s, p, p.tw + F::TW1, G1{}, src, tid);
     stage<R2A, R2B>(s, p, p.tw, G2{}, src, tid);
     for (uint32_t i = tid; i < F::pp(F::P); i += F::NT) s[i] = cmul(s[i], p.bhat[i]);
@@ -509,10 +518,11 @@ __global__ void __launch_bounds__(F::NT, F::NT >= 256 ? 4 : 2) chirpz3_kernel(Pa
     stage_inv<R2A, R2B>(s, p.tw, G2{}, tid);
     stage_inv<R1A, R1B>(s, p.tw + F::TW1, G1{}, tid);
     stage_inv<R0A, R0B>(s, p.tw, G0{}, tid);
-    split_store(p, s, pair, row_a, row_b, tid, F::NT);
+    if constexpr (REAL) untangle_store(p, s, row_a, tid, F::NT);
+    else split_store(p, s, pair, row_a, row_b, tid, F::NT);
 }
 
-template <typename F, int R0A, int R0B, int R1A, int R1B, int R2A, int R2B, int R3A, int R3B>
+template <typename F, int R0A, int R0B, int R1A, int R1B, int R2A, int R2B, int R3A, int R3B, bool REAL>
 __global__ void __launch_bounds__(F::NT, 4) chirpz4_kernel(Params p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -527,7 +537,7 @@ __global__ void __launch_bounds__(F::NT, 4) chirpz4_kernel(Params p)
     using G1 = FixGeo<F::M1, F::P / F::R1, F::pp(F::M1), F::pp(F::M0), 0, F::PAD, F::NT, false>;
     using G2 = FixGeo<F::M2, F::P / F::R2, F::pp(F::M2), F::pp(F::M1), 0, F::PAD, F::NT, false>;
     using G3 = FixGeo<1, F::P / F::R3, 1, F::pp(F::M2), 0, F::PAD, F::NT, false>;
-    stage<R0A, R0B>(s, p, p.tw, G0f{p.W}, src, tid);
+    stage<R0A, R0B, G0f, REAL>(s, p, p.tw, G0f{REAL ? (p.W + 1) / 2 : p.W}, src, tid);
     stage<R1A, R1B>(s, p, p.tw + F::TW1, G1{}, src, tid);
     stage<R2A, R2B>(s, p, p.tw + F::TW2, G2{}, src, tid);
     stage<R3A, R3B>(s, p, p.tw, G3{}, src, tid);
@@ -537,7 +547,8 @@ __global__ void __launch_bounds__(F::NT, 4) chirpz4_kernel(Params p)
     stage_inv<R2A, R2B>(s, p.tw + F::TW2, G2{}, tid);
     stage_inv<R1A, R1B>(s, p.tw + F::TW1, G1{}, tid);
     stage_inv<R0A, R0B>(s, p.tw, G0{}, tid);
-    split_store(p, s, pair, row_a, row_b, tid, F::NT);
+    if constexpr (REAL) untangle_store(p, s, row_a, tid, F::NT);
+    else split_store(p, s, pair, row_a, row_b, tid, F::NT);
 }
 
 // L, the stages, threads (W 86 .. 5461; shorter windows keep the radix-4 ladder of stft_bluestein.hip)
@@ -547,6 +558,10 @@ __global__ void __launch_bounds__(F::NT, 4) chirpz4_kernel(Params p)
 struct ChirpTables {
     float2 *d_chirp = nullptr, *d_bhat = nullptr, *d_tw = nullptr;
     uint32_t L = 0, lds_points = 0;
+    // real-input mode (a mono stream, every frame its own transform): the chirp-z transform of W points over ceil(W / 2) sample pairs
+    // -- a convolution of half the length -- and the untangling twiddles w_2W^k
+    ChirpTables *half = nullptr;
+    float2 *d_twr = nullptr;
 };
 
 // P, the three stages (RA, RB), threads.  0.05 s at 48 / 44.1 / 32 / 16 / 8 / 88.2 kHz.  512 threads where a stage has more than
@@ -992,6 +1007,14 @@ static uint32_t chirp_length(uint32_t W)
     return L;
 }
 
+// P points out of nz non-zero inputs: any power of two >= P + nz - 1 that has a plan
+static uint32_t conv_length(uint32_t P, uint32_t nz)
+{
+    uint32_t L = 512;
+    while (L < P + nz - 1) L <<= 1;
+    return L;
+}
+
 }  // namespace mix
 
 bool chirpz_supported(uint32_t W)
@@ -1001,10 +1024,12 @@ bool chirpz_supported(uint32_t W)
     return L == 512 || L == 1024 || L == 2048 || L == 4096 || L == 8192 || L == 16384;
 }
 
-hipError_t chirpz_init(sgx_ctx *c, void **out)
+// Tables of the chirp-z transform of P points out of nz non-zero inputs (2W and W for an (l, r) frame; real: W and ceil(W / 2) sample
+// pairs, with the untangling twiddles w_2P^k).  hipErrorInvalidValue: no plan for the convolution length.
+static hipError_t build_chirp(uint32_t P, uint32_t nz, bool real, mix::ChirpTables **out)
 {
     using namespace mix;
-    const uint32_t W = c->W, P = c->P, L = chirp_length(W);
+    const uint32_t L = real ? conv_length(P, nz) : chirp_length(nz);
     std::vector<uint32_t> radix;
 #define X(Ln, A0, B0, A1, B1, A2, B2, N) if (L == Ln) radix = {A0 * B0, A1 * B1, A2 * B2};
     CHIRP_PLANS3(X)
@@ -1045,10 +1070,10 @@ hipError_t chirpz_init(sgx_ctx *c, void **out)
         cr[n] = cos(ang); ci[n] = sin(ang);
         chirp[n] = make_float2((float)cr[n], (float)ci[n]);
     }
-    // b[m] = conj(c[|m|]) for m in [-(W-1), P-1], wrapped modulo L
+    // b[m] = conj(c[|m|]) for m in [-(nz-1), P-1], wrapped modulo L
     std::vector<double> br(L, 0.0), bi(L, 0.0);
     for (uint32_t m = 0; m < P; ++m) { br[m] = cr[m]; bi[m] = -ci[m]; }
-    for (uint32_t m = 1; m < W; ++m) { br[L - m] = cr[m]; bi[L - m] = -ci[m]; }
+    for (uint32_t m = 1; m < nz; ++m) { br[L - m] = cr[m]; bi[L - m] = -ci[m]; }
     fft_host(br, bi);
     for (uint32_t K = 0; K < L; ++K) {   // bin K = k1 + r1 (k2 + r2 (...)) ends at k1 m1 + k2 m2 + ...
         uint32_t k = K, at = 0;
@@ -1066,6 +1091,15 @@ hipError_t chirpz_init(sgx_ctx *c, void **out)
     hipError_t e = up(&t->d_chirp, chirp);
     if (e == hipSuccess) e = up(&t->d_bhat, bhat);
     if (e == hipSuccess) e = up(&t->d_tw, tw);
+    if (e == hipSuccess && real) {
+        std::vector<float2> twr(std::max<uint32_t>(P / 2, 1));
+        for (uint32_t j = 0; j < P / 2; ++j) {
+            const uint32_t k = j + 1;   // w_2P^k, k <= P / 2
+            const double ang = -M_PI * (double)k / (double)P;
+            twr[j] = 2 * k == P ? make_float2(0.0f, -1.0f) : make_float2((float)cos(ang), (float)sin(ang));
+        }
+        e = up(&t->d_twr, twr);
+    }
     if (e != hipSuccess) {
         chirpz_destroy(t);
         return e;
@@ -1074,10 +1108,34 @@ hipError_t chirpz_init(sgx_ctx *c, void **out)
     return hipSuccess;
 }
 
+hipError_t chirpz_init(sgx_ctx *c, void **out)
+{
+    mix::ChirpTables *t = nullptr;
+    hipError_t e = build_chirp(c->P, c->W, false, &t);
+    if (e != hipSuccess) return e;
+    if (c->C == 1) {   // a mono stream: real-input mode
+        e = build_chirp(c->W, (c->W + 1) / 2, true, &t->half);
+        if (e != hipSuccess && e != hipErrorInvalidValue) {
+            chirpz_destroy(t);
+            return e;
+        }
+    }
+    *out = t;
+    return hipSuccess;
+}
+
+bool chirpz_real_serves(const sgx_ctx *c, const void *tables, uint32_t channels)
+{
+    const auto *t = static_cast<const mix::ChirpTables *>(tables);
+    return t && t->half && channels == 1 && (c->cfg.flags & SGX_FLAG_INDEPENDENT_FRAMES) && !(c->cfg.flags & SGX_FLAG_COMPLEX_MONO);
+}
+
 void chirpz_destroy(void *tables)
 {
     auto *t = static_cast<mix::ChirpTables *>(tables);
     if (!t) return;
+    if (t->half) chirpz_destroy(t->half);
+    if (t->d_twr) (void)hipFree(t->d_twr);
     if (t->d_chirp) (void)hipFree(t->d_chirp);
     if (t->d_bhat) (void)hipFree(t->d_bhat);
     if (t->d_tw) (void)hipFree(t->d_tw);
@@ -1090,14 +1148,18 @@ hipError_t launch_stft_chirpz(const sgx_ctx *c, const void *tables, const float 
     using namespace mix;
     if (n_frames == 0) return hipSuccess;
     const auto *t = static_cast<const ChirpTables *>(tables);
+    const bool real = chirpz_real_serves(c, tables, channels);   // a mono stream, every frame its own transform (the default)
+    if (real) t = t->half;
     Params p{};
     p.pcm = d_pcm;
     p.window = c->d_window;
     p.tw = t->d_tw;
     p.chirp = t->d_chirp;
     p.bhat = t->d_bhat;
+    p.twr = t->d_twr;
+    p.real = real ? 1u : 0u;
     p.W = c->W;
-    p.P = c->P;
+    p.P = real ? c->W : c->P;
     p.H = c->H;
     p.C = channels;
     p.pairs = pairs;
@@ -1106,6 +1168,7 @@ hipError_t launch_stft_chirpz(const sgx_ctx *c, const void *tables, const float 
     p.n_frames = n_frames;
     p.total_frames = total_frames;
     p.vec2 = (channels >= 2 && channels % 2 == 0 && reinterpret_cast<uintptr_t>(d_pcm) % 8 == 0) ? 1u : 0u;
+    if (real) p.vec2 = (c->W % 2 == 0 && c->H % 2 == 0 && reinterpret_cast<uintptr_t>(d_pcm) % 8 == 0) ? 1u : 0u;   // sample PAIRS of one channel
     const size_t lds = (size_t)t->lds_points * sizeof(float2);
     hipError_t attr_err = hipSuccess;
     auto go = [&](auto kernel, unsigned nt, dim3 grid) {
@@ -1117,12 +1180,18 @@ hipError_t launch_stft_chirpz(const sgx_ctx *c, const void *tables, const float 
     };
     auto launch = [&](dim3 grid) {
         switch (t->L) {
-#define X(Ln, A0, B0, A1, B1, A2, B2, N) \
-    case Ln: go(chirpz3_kernel<Fixed3<Ln, A0, B0, A1, B1, A2, B2, N>, A0, B0, A1, B1, A2, B2>, N, grid); break;
+#define X(Ln, A0, B0, A1, B1, A2, B2, N)                                                                             \
+    case Ln:                                                                                                         \
+        if (real) go(chirpz3_kernel<Fixed3<Ln, A0, B0, A1, B1, A2, B2, N>, A0, B0, A1, B1, A2, B2, true>, N, grid);   \
+        else go(chirpz3_kernel<Fixed3<Ln, A0, B0, A1, B1, A2, B2, N>, A0, B0, A1, B1, A2, B2, false>, N, grid);      \
+        break;
             CHIRP_PLANS3(X)
 #undef X
-#define X(Ln, A0, B0, A1, B1, A2, B2, A3, B3, N) \
-    case Ln: go(chirpz4_kernel<Fixed4<Ln, A0, B0, A1, B1, A2, B2, A3, B3, N>, A0, B0, A1, B1, A2, B2, A3, B3>, N, grid); break;
+#define X(Ln, A0, B0, A1, B1, A2, B2, A3, B3, N)                                                                                      \
+    case Ln:                                                                                                                          \
+        if (real) go(chirpz4_kernel<Fixed4<Ln, A0, B0, A1, B1, A2, B2, A3, B3, N>, A0, B0, A1, B1, A2, B2, A3, B3, true>, N, grid);    \
+        else go(chirpz4_kernel<Fixed4<Ln, A0, B0, A1, B1, A2, B2, A3, B3, N>, A0, B0, A1, B1, A2, B2, A3, B3, false>, N, grid);       \
+        break;
             CHIRP_PLANS4(X)
 #undef X
         default: attr_err = hipErrorInvalidValue; break;

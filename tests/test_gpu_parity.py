@@ -997,12 +997,15 @@ def test_real_input_kernel_at_other_hops(torch_cuda, mags_err, Ht):
 
 
 @pytest.mark.parametrize("Wt,Ht,off", [(2400, 93, 0), (2400, 256, 1), (2205, 85, 0), (2205, 512, 0), (1200, 100, 0), (300, 7, 1), (4800, 1024, 0),
-                                       (9600, 3000, 0), (1000, 250, 0), (1024, 256, 0), (4096, 512, 2), (441, 100, 0), (12, 2, 0), (9, 3, 0), (15, 4, 1), (512, 64, 0), (2000, 500, 0), (1944, 97, 0)])
+                                       (9600, 3000, 0), (1000, 250, 0), (1024, 256, 0), (4096, 512, 2), (441, 100, 0), (12, 2, 0), (9, 3, 0), (15, 4, 1), (512, 64, 0), (2000, 500, 0), (1944, 97, 0),
+                                       (1102, 43, 0), (551, 100, 1), (3001, 300, 0), (171, 20, 0), (5461, 500, 0), (87, 9, 0), (1852, 170, 0)])
 def test_real_input_mode_of_the_mixed_radix_kernel(torch_cuda, mags_err, Wt, Ht, off):
     # every window the mixed-radix kernel serves (2W = 2^a 3^b 5^c 7^d), a mono stream in the default mode: the W-point transform of
     # z[m] = x[2m] + i x[2m+1] and the untangling epilogue (stft_mixed.hip: untangle_store) -- compile-time plans (2400, 2205, 4800,
     # 9600 points ...) and the run-time plan, odd W (the last sample is half a pair), odd hops and a stream that is not 8-byte aligned
-    # (scalar loads); W 2400 leaves the 4800-point kernel for it.  Against the float64 truth per frame, own peak.
+    # (scalar loads); W 2400 leaves the 4800-point kernel for it.  Against the float64 truth per frame, own peak.  The last seven: lengths
+    # with a prime factor above 7 -- the chirp-z kernel (stft_kernel 4) in the same mode: a W-point chirp-z transform of ceil(W / 2) sample
+    # pairs, a convolution of half the length, and the same untangling epilogue.
     torch = torch_cuda
     frames = 11
     n = Wt + (frames - 1) * Ht + min(3, Ht - 1)
@@ -1012,7 +1015,7 @@ def test_real_input_mode_of_the_mixed_radix_kernel(torch_cuda, mags_err, Wt, Ht,
     pcm = pcm[off:]
     Mt = Wt - 1
     eng = engine(window_samples=Wt, hop_samples=Ht, channels=1, interp=1, gradient="inferno")
-    assert eng.info.stft_kernel in (6, 9) and eng.info.render_path & 8
+    assert eng.info.stft_kernel in (4, 6, 9) and eng.info.render_path & 8
     got = eng.stft_batch(dev).cpu().numpy()
     truth = np.stack([oracle.np_truth_frame(np.stack([pcm[t * Ht:t * Ht + Wt]] * 2, 1), Wt) for t in range(frames)])
     assert got.shape == (frames, 1, Mt, 2)
