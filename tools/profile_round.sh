@@ -3,6 +3,7 @@
 # bench line, rocprofv3 kernel trace + stats of the same command, the two HBM PMC passes, the SQ counter passes
 repo=$(cd "$(dirname "$0")/.." && pwd)
 cd $repo
+rm -f gpurun_out/pr_csrc_sha16.txt
 timeout -k 10 400 python bench.py > gpurun_out/pr_bench.json 2> gpurun_out/pr_bench.err || exit 1
 (cd /tmp && export TMPDIR=/tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $repo/gpurun_out/pr_trace -- python3 $repo/bench.py --cpu-frames 0 > $repo/gpurun_out/pr_trace.log 2>&1) || exit 1
 python3 tools/summarize_prof.py gpurun_out/pr_trace > gpurun_out/pr_kernel_trace.txt
@@ -13,4 +14,5 @@ python3 tools/pmc_summary.py gpurun_out/pr_sq1_bench gpurun_out/pr_sq2_bench > g
 # the two summaries bench.py quotes (stamped with the kernel sources' hash): profiles/<round>_hbm_traffic.json, <round>_pixel_pipes.json
 python3 tools/pmc_round.py ${ROUND:-r04} gpurun_out/pr_fetch_bench gpurun_out/pr_fetch_micro gpurun_out/pr_write_bench gpurun_out/pr_write_micro \
     gpurun_out/pr_sq1_bench gpurun_out/pr_sq2_bench > gpurun_out/pr_round.txt || exit 1
+python3 -c "from bench import csrc_sha16; print(csrc_sha16())" > gpurun_out/pr_csrc_sha16.txt   # what tools/profiles_from_round.py checks the tree against
 echo profile round done

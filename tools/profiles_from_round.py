@@ -13,6 +13,16 @@ import sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 rnd = sys.argv[1] if len(sys.argv) > 1 else "r03"
 g = os.path.join(root, "gpurun_out")
+# the counters were measured on the kernel sources whose hash profile_round.sh wrote beside them: the stamp pmc_round.py puts on the
+# summaries (the tree's hash NOW) must be that one, or the summaries would claim a build they were not measured on
+sys.path.insert(0, root)
+from bench import csrc_sha16  # noqa: E402
+try:
+    measured = open(os.path.join(g, "pr_csrc_sha16.txt")).read().strip()
+except OSError:
+    sys.exit("gpurun_out/pr_csrc_sha16.txt is missing: run tools/profile_round.sh on a GPU box first")
+if measured != csrc_sha16():
+    sys.exit(f"the profile round in gpurun_out/ was measured on kernel sources {measured}, the tree is at {csrc_sha16()}: run tools/profile_round.sh again")
 dirs = [os.path.join(g, d) for d in ("pr_fetch_bench", "pr_fetch_micro", "pr_write_bench", "pr_write_micro", "pr_sq1_bench", "pr_sq2_bench")]
 subprocess.run([sys.executable, os.path.join(root, "tools", "pmc_round.py"), rnd, *dirs], check=True, stdout=open(os.path.join(g, "pr_round.txt"), "w"))
 for d, n in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
