@@ -14,5 +14,6 @@ python3 tools/pmc_summary.py gpurun_out/pr_sq1_bench gpurun_out/pr_sq2_bench > g
 # the two summaries bench.py quotes (stamped with the kernel sources' hash): profiles/<round>_hbm_traffic.json, <round>_pixel_pipes.json
 python3 tools/pmc_round.py ${ROUND:-r04} gpurun_out/pr_fetch_bench gpurun_out/pr_fetch_micro gpurun_out/pr_write_bench gpurun_out/pr_write_micro \
     gpurun_out/pr_sq1_bench gpurun_out/pr_sq2_bench > gpurun_out/pr_round.txt || exit 1
+(cd gpurun_out && find pr_* -name '*.csv' | sort) > gpurun_out/pr_files.txt   # this run's files: gpurun MERGES into the caller's gpurun_out/, older runs' stay there
 python3 -c "from bench import csrc_sha16; print(csrc_sha16())" > gpurun_out/pr_csrc_sha16.txt   # what tools/profiles_from_round.py checks the tree against
 echo profile round done

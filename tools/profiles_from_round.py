@@ -23,6 +23,17 @@ except OSError:
     sys.exit("gpurun_out/pr_csrc_sha16.txt is missing: run tools/profile_round.sh on a GPU box first")
 if measured != csrc_sha16():
     sys.exit(f"the profile round in gpurun_out/ was measured on kernel sources {measured}, the tree is at {csrc_sha16()}: run tools/profile_round.sh again")
+# gpurun merges a call's gpurun_out/ into the local one: counter files of EARLIER profile rounds (other builds, other devices) are still
+# there and would be averaged in.  Keep this run's only (pr_files.txt, written on the box, where nothing older exists).
+try:
+    keep = {os.path.normpath(l.strip()) for l in open(os.path.join(g, "pr_files.txt")) if l.strip()}
+except OSError:
+    sys.exit("gpurun_out/pr_files.txt is missing: run tools/profile_round.sh on a GPU box first")
+stale = [p for p in glob.glob(os.path.join(g, "pr_*", "**", "*.csv"), recursive=True) if os.path.normpath(os.path.relpath(p, g)) not in keep]
+for p in stale:
+    os.remove(p)
+if stale:
+    print(f"removed {len(stale)} counter / trace files of earlier profile rounds from gpurun_out/")
 dirs = [os.path.join(g, d) for d in ("pr_fetch_bench", "pr_fetch_micro", "pr_write_bench", "pr_write_micro", "pr_sq1_bench", "pr_sq2_bench")]
 subprocess.run([sys.executable, os.path.join(root, "tools", "pmc_round.py"), rnd, *dirs], check=True, stdout=open(os.path.join(g, "pr_round.txt"), "w"))
 for d, n in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
