@@ -2,12 +2,17 @@
 / interpolation / LUT rule, every draw checked against the CPU oracle (magnitudes within the stated tolerance,
 pixel bytes bit-exact on identical magnitudes) and against the library's own invariants (one-kernel == two-kernel
 pixel path, any sub-range == the same frames of the full run).  Run with -m gpu on an MI355X."""
+import os
+
 import numpy as np
 import pytest
 
 import oracle
 
 pytestmark = pytest.mark.gpu
+
+# SGX_FUZZ_OFFSET=k: the same sweeps over OTHER draws (seed + k) -- for a longer hunt than the suite's own draws, by hand
+OFFSET = int(os.environ.get("SGX_FUZZ_OFFSET", "0"))
 
 
 def draw(rng):
@@ -42,6 +47,7 @@ def draw(rng):
 def test_random_configuration(seed, mags_err, gradients):
     import torch
     from spectrogram_rs_amd import SpectrogramEngine
+    seed += OFFSET
     rng = np.random.default_rng(1000 + seed)
     c = draw(rng)
     W, H, ch, n = c["W"], c["H"], c["channels"], c["n"]
