@@ -88,12 +88,12 @@ typedef struct sgx_config {
 #define SGX_FLAG_PACKED_KERNEL 8u  /* W = 2048: workgroup-per-transform kernel with packed (re, im) arithmetic instead of scalar (A/B) */
 /* Mono streams.  The reference duplicates a mono sample into (s, s) and transforms every frame on its own
  * (audio_input_list_model.rs:67-69, fft.rs:47-99).  DEFAULT here, at every window and hop: exactly that dataflow, one transform per
- * frame -- every frame within north_star's tolerance of its OWN peak on any input.  At W 2048 and an even hop (8-byte aligned stream)
+ * frame -- every frame within north_star's tolerance of its OWN peak on any input.  At W 2048 (any hop, any alignment of the stream)
  * it is computed as the 4096-point spectrum of a REAL frame, a 2048-point complex transform + one butterfly per bin
  * (stft4096_real.hip; at H 256, the BASELINE shape, with the window sliding in registers): the cost of half a transform.  The
  * mixed-radix kernel does the same at every window it serves (stft_mixed.hip, real-input mode: the application's 2400 and 2205, every
  * 2-3-5-7-smooth length, W 512 / 1024 / 4096; any hop and alignment), the chirp-z kernel too from W 86 on (1102 at 22.05 kHz).
- * Elsewhere (W 2048 at odd hops, W 8192, the small windows of the generic kernels) it is the (s, s) transform itself.
+ * Elsewhere (W 8192, the small windows of the generic kernels) it is the (s, s) transform itself.
  * SGX_FLAG_PAIRED_FRAMES (opt-in): two frames (2j, 2j+1) per transform in its real and imaginary part -- half the work of the (s, s)
  * transform, but the quieter frame of a pair carries the louder one's float32 rounding floor: the tolerance then holds against the
  * PAIR's peak only (measured: up to 4.7 x the own-peak tolerance across a 60 dB step inside one hop, unbounded next to digital
@@ -128,8 +128,7 @@ typedef struct sgx_info {
                                  0.05 s windows of the usual sample rates (8 kHz to 192 kHz) and the powers of two from 512 on;
                                  stft_kernel 4 (chirp-z) for W = 86 .. 5461, e.g. 1102 at 22.05 kHz;
                                  bit 3 = a mono stream runs a real-input kernel, the W-point transform of sample pairs (unless
-                                 SGX_FLAG_PAIRED_FRAMES / SGX_FLAG_COMPLEX_MONO): at W 2048 with an even hop (needs an 8-byte aligned
-                                 stream, else the (s, s) kernel takes it), and at every window the mixed-radix kernel or the chirp-z
+                                 SGX_FLAG_PAIRED_FRAMES / SGX_FLAG_COMPLEX_MONO): at W 2048, and at every window the mixed-radix kernel or the chirp-z
                                  stages serve (stft_kernel 6, 9 and 4 with bit 2; any hop and alignment) */
     uint64_t mags_bytes_per_frame; /* pairs * M * 2 * 4 */
     uint64_t rgba_bytes_per_frame; /* pairs * R * 4     */

@@ -389,7 +389,7 @@ int sgx_create(const sgx_config *cfg, sgx_ctx **out_ctx)
         if (e != hipSuccess) return bail(SGX_ERR_HIP, std::string("sgx_create: tuned kernel tables: ") + hipGetErrorString(e));
         e = sgx::wg4096_init(c, &c->d_fast_wg);
         if (e != hipSuccess) return bail(SGX_ERR_HIP, std::string("sgx_create: tuned kernel tables: ") + hipGetErrorString(e));
-        if (c->C == 1 && c->H % 2 == 0) {
+        if (c->C == 1) {
             e = sgx::real4096_init(c, &c->d_real);
             if (e != hipSuccess) return bail(SGX_ERR_HIP, std::string("sgx_create: real-input kernel tables: ") + hipGetErrorString(e));
         }

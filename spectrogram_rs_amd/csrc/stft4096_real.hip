@@ -1,4 +1,4 @@
-// stft4096_real.hip -- K1R: a mono stream at W = 2048 (H = 256: the tuned form; any even hop) with EVERY frame its own transform, at the
+// stft4096_real.hip -- K1R: a mono stream at W = 2048 (H = 256: the tuned form; any other hop too) with EVERY frame its own transform, at the
 // price of half a transform.
 //
 // The reference duplicates a mono sample into (s, s) and runs one 4096-point complex transform per frame
@@ -99,7 +99,7 @@ __device__ __forceinline__ void fft8_half_zero(const float (&zr)[4], const float
 constexpr int kRowsF32 = 0, kRowsF16 = 1, kPixels = 2;   // what a launch writes: float rows, half-pair rows, RGBA columns (fused pixel path)
 
 // PIX (kPixels only): the pixel code of the instantiation, wg::kPixCubic / kPixCosine / kPixGeneric (stft4096_wg.hpp)
-// SLIDE: H = 256, the window slides in registers (above).  Else: any EVEN hop (a frame starts on a column): the eight columns of the
+// SLIDE: H = 256, the window slides in registers (above).  Else: any hop (a frame starts on any sample): the eight columns of the
 // next frame pair are requested where the sliding form requests its one, straight into R -- dead since pass 1 -- and every sample is
 // fetched 2048 / H times, through L2.
 template <int MODE, int PIX, bool SLIDE>
@@ -149,23 +149,24 @@ __global__ void __launch_bounds__(256, 4) stft4096_real_kernel(Params p)
     // Columns from `col0` of the stream on, as a raw buffer (uniform base + one 32-bit lane offset); its record count is what the
     // stream still holds from there, so a column past the end reads as zero: a pair's second frame that the stream does not hold, or
     // the rows requested ahead at the end of a run, need no branch (their results are never stored).
-    auto columns_from = [&](unsigned long long col0) {
-        const unsigned long long first = 2 * col0;                           // sample index
+    // (the loads below are 8-byte words at 4-byte aligned addresses when the hop is odd or the stream starts on an odd sample: buffer
+    // loads of more than one dword need dword alignment only)
+    auto samples_from = [&](unsigned long long first) {                      // first: sample index
         const unsigned long long left = first < p.stream_samples ? (p.stream_samples - first) * 4 : 0;
         const unsigned long long addr = (unsigned long long)(p.pcm + (first < p.stream_samples ? first : 0));
         const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)addr), hi = __builtin_amdgcn_readfirstlane((uint32_t)(addr >> 32));
         const int records = __builtin_amdgcn_readfirstlane((int)(left < 0x7fffffffull ? left : 0x7fffffffull));
         return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((unsigned long long)hi << 32) | lo), 0, records, 0x00020000);
     };
+    auto columns_from = [&](unsigned long long col0) { return samples_from(2 * col0); };
     auto column = [&](__amdgpu_buffer_rsrc_t r, int byte_offset) {
         const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, tid * 8, byte_offset, 0);
         return make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
     };
     float2 R[8];        // R[j] = c[128 fa + tid + 128 j]: rows a = j / 2 of frame A (even j) and frame B (odd j)
     float2 L;           // the next R[7] = c[128 fa + 1152 + tid]   (SLIDE)
-    const unsigned long long hc = p.H / 2;    // columns per hop (128 when SLIDE)
-    auto load_pair = [&](unsigned long long fa_) {   // !SLIDE: all eight columns of the pair (fa_, fa_ + 1)
-        const __amdgpu_buffer_rsrc_t r0 = columns_from(fa_ * hc), r1 = columns_from((fa_ + 1) * hc);
+    auto load_pair = [&](unsigned long long fa_) {   // !SLIDE: all eight columns of the pair (fa_, fa_ + 1); any hop
+        const __amdgpu_buffer_rsrc_t r0 = samples_from(fa_ * p.H), r1 = samples_from((fa_ + 1) * p.H);
 #pragma unroll
         for (int a = 0; a < 4; ++a) { R[2 * a] = column(r0, 2048 * a); R[2 * a + 1] = column(r1, 2048 * a); }
     };
@@ -424,11 +425,11 @@ void real4096_destroy(void *tables)
     delete t;
 }
 
-// the streams this kernel serves: one channel, W = 2048, an EVEN hop and an 8-byte aligned stream (every frame starts on an 8-byte
-// column; H = 256 slides its window in registers)
+// the streams this kernel serves: one channel, W = 2048 (H = 256 slides its window in registers)
 bool real4096_serves(const sgx_ctx *c, const float *d_pcm, uint32_t channels)
 {
-    return channels == 1 && c->d_real && c->W == (uint32_t)wgr::kW && c->H % 2 == 0 && (reinterpret_cast<uintptr_t>(d_pcm) & 7u) == 0;
+    (void)d_pcm;   // any hop, any (4-byte) alignment of the stream: see samples_from
+    return channels == 1 && c->d_real && c->W == (uint32_t)wgr::kW;
 }
 
 namespace wg {

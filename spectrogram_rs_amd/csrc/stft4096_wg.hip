@@ -537,9 +537,9 @@ hipError_t launch_wg(const sgx_ctx *c, const void *tables, const float *d_pcm, u
             p.seed_pm1 = wg4096_seed_is_within_one(c) ? 1u : 0u;
             p.single_rows = t->single_rows;
         }
-        // A one-channel stream (include/sgx.h, "Mono streams"): by default, at an even hop, every frame its own real-input transform
-        // (stft4096_real.hip); SGX_FLAG_PAIRED_FRAMES, odd hops and streams that are not 8-byte aligned: two frames per
-        // transform; SGX_FLAG_INDEPENDENT_FRAMES there and SGX_FLAG_COMPLEX_MONO: every frame as its own (s, s) transform
+        // A one-channel stream (include/sgx.h, "Mono streams"): by default every frame its own real-input transform
+        // (stft4096_real.hip); SGX_FLAG_PAIRED_FRAMES: two frames per transform; SGX_FLAG_COMPLEX_MONO: every frame as its own (s, s)
+        // transform
         const uint32_t fl = c->cfg.flags;      // (sgx_create: INDEPENDENT is set unless PAIRED was asked for)
         const bool own_transform = (fl & (SGX_FLAG_INDEPENDENT_FRAMES | SGX_FLAG_COMPLEX_MONO)) != 0;
         if (channels == 1 && own_transform && !(fl & SGX_FLAG_COMPLEX_MONO) && real4096_serves(c, d_pcm, channels))
