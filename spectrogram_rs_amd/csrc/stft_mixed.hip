@@ -82,6 +82,8 @@ struct Params {
     float inv_m[kMaxStages];
 };
 
+typedef float v2f_a4 __attribute__((ext_vector_type(2), aligned(4)));   // an 8-byte word at a 4-byte aligned address
+
 struct Source {   // where the first stage finds (l + i r) * hann (fft.rs:53-63); zeros from W on (fft.rs:65-69)
     const float *a, *b;
     uint32_t cl, cr;
@@ -146,8 +148,10 @@ __device__ __forceinline__ void stage(float2 *s, const Params &p, const float2 *
                     const uint32_t n = q * m + j, nc = n < g.W() ? n : g.W() - 1;
                     if (real) {   // uniform
                         float2 x2, w2;
-                        if (p.vec2) {
-                            x2 = *reinterpret_cast<const float2 *>(src.a + 2 * nc);
+                        if (p.vec2) {   // an even W: whole pairs.  The samples' 8-byte words are 4-byte aligned at odd hops / stream offsets:
+                                        // loads of two dwords need dword alignment only (v2f_a4 tells the compiler as much)
+                            const v2f_a4 xv = *reinterpret_cast<const v2f_a4 *>(src.a + 2 * nc);
+                            x2 = make_float2(xv.x, xv.y);
                             w2 = *reinterpret_cast<const float2 *>(p.window + 2 * nc);
                         } else {   // an odd W ends on half a pair
                             const bool whole = 2 * nc + 1 < p.W;
@@ -907,7 +911,7 @@ static hipError_t launch_mixed(const sgx_ctx *c, const void *tables, const float
     p.total_frames = total_frames;
     // (l, r) of a channel pair as one 8-byte word: even channel count and an 8-byte aligned stream
     p.vec2 = (channels >= 2 && channels % 2 == 0 && reinterpret_cast<uintptr_t>(d_pcm) % 8 == 0) ? 1u : 0u;
-    if (real) p.vec2 = (c->W % 2 == 0 && c->H % 2 == 0 && reinterpret_cast<uintptr_t>(d_pcm) % 8 == 0) ? 1u : 0u;   // sample PAIRS of one channel
+    if (real) p.vec2 = c->W % 2 == 0 ? 1u : 0u;   // sample PAIRS of one channel as 8-byte words (any hop, any alignment: see stage())
     size_t lds = (size_t)t->lds_points * sizeof(float2);
     if (real && d_rgba) lds = std::max(lds, ((size_t)c->M + 1 + c->tab.samples.size()) * sizeof(float2));   // the column and its samples
     const unsigned threads = t->threads;
@@ -1168,7 +1172,7 @@ hipError_t launch_stft_chirpz(const sgx_ctx *c, const void *tables, const float 
     p.n_frames = n_frames;
     p.total_frames = total_frames;
     p.vec2 = (channels >= 2 && channels % 2 == 0 && reinterpret_cast<uintptr_t>(d_pcm) % 8 == 0) ? 1u : 0u;
-    if (real) p.vec2 = (c->W % 2 == 0 && c->H % 2 == 0 && reinterpret_cast<uintptr_t>(d_pcm) % 8 == 0) ? 1u : 0u;   // sample PAIRS of one channel
+    if (real) p.vec2 = c->W % 2 == 0 ? 1u : 0u;   // sample PAIRS of one channel as 8-byte words
     const size_t lds = (size_t)t->lds_points * sizeof(float2);
     hipError_t attr_err = hipSuccess;
     auto go = [&](auto kernel, unsigned nt, dim3 grid) {
