@@ -25,6 +25,10 @@
 // The lengths the usual device rates produce (and the powers of two without a tuned kernel) run instantiations whose
 // whole plan is a compile-time constant (stft_mixed_fixed_kernel / stft_mixed_fixed4_kernel, MIX_FIXED_PLANS): the same
 // stage() over FixGeo instead of DynGeo; half the registers, workgroups of 512 / 1024 threads, +24 % to +64 %.
+//
+// Round 4: REAL-INPUT MODE -- a mono stream in the default mode (every frame its own transform; include/sgx.h, "Mono streams") runs the
+// W-point plan on z[m] = x[2m] + i x[2m+1] and an untangling epilogue (untangle_store / pixel_epilogue_real) instead of the 2W-point plan
+// on (s, s): half the transform per frame.  The chirp-z kernels below (lengths with a prime factor above 7) take the same mode.
 #include <algorithm>
 #include <vector>
 
