@@ -474,6 +474,58 @@ __global__ void __launch_bounds__(F::NT, F::NT <= 256 ? 4 : 8) stft_mixed_fixed_
     }
 }
 
+// Real-input mode from PCM to pixels, TWO frames per workgroup (the two application plans, MIX_REAL2_RENDER_PLANS): each half of the
+// workgroup transforms one frame on its own W-point image; then the pixel stage runs ONCE, with every thread, over both columns -- .x / .y
+// of a bin, as for a frame pair -- where a mono column alone would carry the same value in both components and do every sum twice.
+// (waves per SIMD the LDS lets stay resident -- two images, or the column with ~2300 samples behind it -- so that the register budget is
+// no tighter than the occupancy the kernel can have anyway)
+template <typename F>
+constexpr unsigned real2_waves_per_simd()
+{
+    constexpr size_t lds = (size_t)(2 * F::pp(F::P) > F::P + 2304 ? 2 * F::pp(F::P) : F::P + 2304) * sizeof(float2);
+    constexpr size_t wgs = 160 * 1024 / lds < 1 ? 1 : 160 * 1024 / lds;
+    constexpr size_t waves = wgs * (2 * F::NT / 64) / 4;
+    return waves < 1 ? 1u : (waves > 8 ? 8u : (unsigned)waves);
+}
+
+template <typename F, int R0A, int R0B, int R1A, int R1B, int R2A, int R2B>
+__global__ void __launch_bounds__(2 * F::NT, real2_waves_per_simd<F>()) stft_mixed_real2_render_kernel(Params p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2 *s = reinterpret_cast<float2 *>(smem_raw);
+    constexpr uint32_t NT = F::NT, IMG = F::pp(F::P), M = F::P - 1, K = F::P / 2, kPer = (K + NT - 1) / NT;
+    const uint32_t tid = threadIdx.x, half = tid >= NT ? 1u : 0u, ltid = tid - half * NT;
+    float2 *img = s + half * IMG;
+    const unsigned long long fa = 2ull * blockIdx.x, f = fa + half;              // rows fa, fa + 1 of this launch
+    const unsigned long long fc = f < p.n_frames ? f : p.n_frames - 1;            // no second frame: the last one again, never stored
+    Source src;
+    src.a = src.b = p.pcm + (size_t)((p.first_frame + fc) * p.H);
+    src.cl = src.cr = 0;
+    src.data_b = true;
+    using G0 = FixGeo<F::M0, F::P / F::R0, F::pp(F::M0), F::pp(F::P), F::W, F::PAD, NT, true>;
+    stage<R0A, R0B, G0, 1>(img, p, p.tw, G0{}, src, ltid);
+    stage<R1A, R1B>(img, p, p.tw + F::TW1, FixGeo<F::M1, F::P / F::R1, F::pp(F::M1), F::pp(F::M0), F::W, F::PAD, NT, false>{}, src, ltid);
+    stage<R2A, R2B>(img, p, p.tw, FixGeo<1, F::P / F::R2, 1, F::pp(F::M1), F::W, F::PAD, NT, false>{}, src, ltid);
+    float2 mg[kPer];
+#pragma unroll
+    for (uint32_t i = 0; i < kPer; ++i) {
+        const uint32_t k1 = ltid + NT * i;
+        mg[i] = k1 < K ? untangle(p, img, k1) : make_float2(0.0f, 0.0f);
+    }
+    __syncthreads();
+    float *col = reinterpret_cast<float *>(s);   // column element j: (frame fa, frame fa + 1) = col[2 j], col[2 j + 1]
+#pragma unroll
+    for (uint32_t i = 0; i < kPer; ++i) {
+        const uint32_t k1 = ltid + NT * i;
+        if (k1 < K) {
+            col[2 * k1 + half] = mg[i].x;
+            col[2 * (M - 1 - k1) + half] = mg[i].y;
+        }
+    }
+    __syncthreads();
+    pixel_passes<2 * NT>(p, s, s + M + 1, M, true, 0u, (long long)fa, (long long)fa + 1, tid);
+}
+
 template <typename F, int R0A, int R0B, int R1A, int R1B, int R2A, int R2B, int R3A, int R3B, bool REAL>
 __global__ void __launch_bounds__(F::NT, F::NT == 256 ? 4 : (F::NT == 512 ? 8 : 4)) stft_mixed_fixed4_kernel(Params p)
 {
@@ -585,6 +637,12 @@ struct ChirpTables {
 // 512 2.23 / 2.77; 2205 points at 160 2.02 / 4.31, 192 1.97 / 3.89, 256 1.99 / 3.46, 320 2.22 / 3.27 -- the transform wants one
 // butterfly per thread, the pixel stage behind it every thread it can get: real-input mode to pixels runs these two plans wider)
 #define MIX_REAL_RENDER_PLANS(X) X(2400, 5, 3, 5, 2, 4, 4, 512) X(2205, 7, 3, 5, 3, 7, 1, 320)
+// ... and, unless SGX_KM_REAL1 (A/B), every three-stage plan with TWO frames per workgroup (threads per FRAME here):
+// stft_mixed_real2_render_kernel
+#define MIX_REAL2_RENDER_PLANS(X) X(2400, 5, 3, 5, 2, 4, 4, 256) X(2205, 7, 3, 5, 3, 7, 1, 192) X(4800, 5, 4, 5, 3, 4, 4, 512) \
+                                  X(4410, 7, 3, 5, 3, 7, 2, 512) X(4096, 4, 4, 4, 4, 4, 4, 256) X(1024, 4, 1, 4, 4, 4, 4, 256) \
+                                  X(512, 4, 1, 4, 2, 4, 4, 128) X(1600, 5, 4, 5, 1, 4, 4, 256) X(800, 5, 2, 5, 1, 4, 4, 128) \
+                                  X(3200, 5, 4, 5, 2, 4, 4, 256) X(8820, 7, 3, 7, 3, 5, 4, 512)
 // four stages: 0.05 s at 96 / 192 / 176.4 kHz, and the 8192-point power of two
 #define MIX_FIXED4_PLANS(X) X(9600, 4, 3, 5, 2, 5, 1, 4, 4, 1024) X(19200, 5, 3, 5, 1, 4, 4, 4, 4, 1024) \
                             X(17640, 5, 3, 7, 2, 4, 3, 7, 1, 1024) X(8192, 4, 1, 4, 2, 4, 4, 4, 4, 512)
@@ -918,6 +976,13 @@ static hipError_t launch_mixed(const sgx_ctx *c, const void *tables, const float
     if (real) p.vec2 = c->W % 2 == 0 ? 1u : 0u;   // sample PAIRS of one channel as 8-byte words (any hop, any alignment: see stage())
     size_t lds = (size_t)t->lds_points * sizeof(float2);
     if (real && d_rgba) lds = std::max(lds, ((size_t)c->M + 1 + c->tab.samples.size()) * sizeof(float2));   // the column and its samples
+    bool two_frames = false;   // real-input mode to pixels at the two application plans: two frames (two images) per workgroup
+#ifndef SGX_KM_REAL1
+#define X(Pn, A0, B0, A1, B1, A2, B2, N) if (real && d_rgba && t->fixed == Pn) two_frames = true;
+    MIX_REAL2_RENDER_PLANS(X)
+#undef X
+#endif
+    if (two_frames) lds = std::max(lds, 2 * (size_t)t->lds_points * sizeof(float2));
     const unsigned threads = t->threads;
     hipError_t attr_err = hipSuccess;
     auto go = [&](auto kernel, unsigned nt, dim3 grid) {
@@ -928,6 +993,16 @@ static hipError_t launch_mixed(const sgx_ctx *c, const void *tables, const float
         hipLaunchKernelGGL(kernel, grid, dim3(nt), lds, c->stream, p);
     };
     auto launch = [&](dim3 grid) {
+        if (two_frames)
+            switch (t->fixed) {
+#define X(Pn, A0, B0, A1, B1, A2, B2, N)                                                                                                  \
+    case Pn:                                                                                                                              \
+        go(stft_mixed_real2_render_kernel<Fixed3<Pn, A0, B0, A1, B1, A2, B2, N>, A0, B0, A1, B1, A2, B2>, 2 * N, dim3((grid.x + 1) / 2, 1)); \
+        return;
+                MIX_REAL2_RENDER_PLANS(X)
+#undef X
+            default: break;
+            }
         if (real && d_rgba)
             switch (t->fixed) {
 #define X(Pn, A0, B0, A1, B1, A2, B2, N) \
