@@ -756,7 +756,7 @@ def app_point_leg(args, torch, device):
     name = KERNEL_NAMES.get(eng.info.stft_kernel, ("?", "?"))
     # the same point for a mono device (audio_input_list_model.rs:67-69 duplicates the sample into (s, s)): two frames per transform
     del rgba, pcm
-    mono = SpectrogramEngine(48000.0, period=0.05, hop_samples=H_APP, channels=1, device=device)                       # default: every frame its own transform
+    mono = SpectrogramEngine(48000.0, period=0.05, hop_samples=H_APP, channels=1, device=device, interp=0, gradient="viridis")   # default: every frame its own transform
     monop = SpectrogramEngine(48000.0, period=0.05, hop_samples=H_APP, channels=1, device=device, paired_frames=True)   # opt-in: two frames per transform
     pcm1 = mono.white_noise((Fa - 1) * H_APP + W_APP)
     out1 = torch.empty((Fa, 1, W_APP - 1, 2), dtype=torch.float32, device=mono.device)
@@ -765,6 +765,15 @@ def app_point_leg(args, torch, device):
     m1p = measure_leg(torch, lambda: monop.stft_batch(pcm1, out=out1), args.leg_sustain_s)
     mean1, mean1p = m1["mean_ms"], m1p["mean_ms"]
     mono_real = bool(mono.info.render_path & 8)
+    del out1
+    rgba1 = torch.empty((Fa, 1, R, 4), dtype=torch.uint8, device=mono.device)
+    rgba1.zero_()
+    m1x = measure_leg(torch, lambda: mono.render_batch(pcm1, out=rgba1), args.leg_sustain_s)
+    bytes1x = H_APP * 4 + R * 4
+    ach1x = Fa * bytes1x / (m1x["mean_ms"] * 1e-3) / 1e9
+    mono_fused = bool(mono.info.render_path & 1)
+    del rgba1
+    out1 = None
     bytes1 = H_APP * 4 + (W_APP - 1) * 8
     ach1, ach1p = Fa * bytes1 / (mean1 * 1e-3) / 1e9, Fa * bytes1 / (mean1p * 1e-3) / 1e9
     del out1, pcm1
@@ -782,6 +791,10 @@ def app_point_leg(args, torch, device):
         "mono_rows_f32_paired_frames": {"frames_per_s": Fa / (mean1p * 1e-3), **leg_times(m1p), "mono_mode": "two frames per transform (SGX_FLAG_PAIRED_FRAMES)",
                                         "roofline": {"bound": "hbm", "achieved": ach1p, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach1p / HBM_PEAK_GBS,
                                                      "bytes_per_frame": bytes1, "frames_per_launch": Fa}},
+        "mono_pcm_to_rgba": {"frames_per_s": Fa / (m1x["mean_ms"] * 1e-3), **leg_times(m1x), "fused_kernel": mono_fused,
+                             "mono_mode": "default (real-input mode, two frames per workgroup)" if mono_real else "default ((s, s) transform)",
+                             "roofline": {"bound": "hbm", "achieved": ach1x, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach1x / HBM_PEAK_GBS,
+                                          "bytes_per_frame": bytes1x, "frames_per_launch": Fa}},
         "pcm_to_rgba": {"frames_per_s": Fa / (meanp * 1e-3), **leg_times(mp), "fused_kernel": bool(eng.info.render_path & 1),
                         "roofline": {"bound": "hbm", "achieved": achp, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achp / HBM_PEAK_GBS,
                                      "bytes_per_frame": ALGO_BYTES_APP_PIXEL, "frames_per_launch": Fa}},
