@@ -59,6 +59,12 @@ if __name__ == "__main__" and "--chirp" in sys.argv:
         run(f"KB {2 * Wt} (chirp-z)", Wt, max(Wt // 10, 1), 2, frames=6)
     sys.exit(0)
 
+if __name__ == "__main__" and "--real" in sys.argv:   # the real-input modes of round 4 beside the (s, s) transform they replace
+    for Wt, Ht in ((2400, 93), (2205, 86), (4096, 256), (1102, 43), (2048, 255)):
+        run(f"W {Wt} mono default (real-input mode)", Wt, Ht, 1)
+        run(f"W {Wt} mono, the (s, s) transform per frame", Wt, Ht, 1, complex_mono=True)
+    sys.exit(0)
+
 if __name__ == "__main__":
     run("K1R mono (default: every frame its own real-input transform)", 2048, 256, 1)
     run("K1 mono (frame pairs)", 2048, 256, 1, paired_frames=True)
