@@ -281,8 +281,10 @@ SGX_API int sgx_set_builtin_gradient(sgx_ctx *ctx, const char *name);
  * "viridis" "magma" "inferno" "plasma" (256-entry ramps) and colorous' ColorBrewer B-spline gradients "red_yellow_blue"
  * "red_blue" "spectral" "red_yellow_green" "pink_green" "purple_orange" "purple_green" "brown_green" "red_grey" "reds"
  * "blues" "greens" "greys" "oranges" "purples" (continuous: anchors from ColorBrewer, d3's interpolateRgbBasis),
- * "turbo" "cividis" (d3's quintics) and "cubehelix" "cool" "warm" (d3's interpolateCubehelixLong) -- every one of the
- * 19 entries of default_color_schemes (colorscheme.rs:125-151).  All [third-party, unpinned]: colorous is not vendored.
+ * "turbo" "cividis" (d3's quintics) and "cubehelix" "cool" "warm" (d3's interpolateCubehelixLong, bytes by truncation as
+ * the reference's screenshots/colorscheme-cool.png shows colorous doing) -- every one of the 19 entries of
+ * default_color_schemes (colorscheme.rs:125-151).  [third-party]: colorous is not vendored; what the reference's four
+ * screenshots pin (the values of the Viridis / Magma / Plasma tables, Cool's curve and byte rule) is tests/test_host_logic.py.
  * stereo != 0: the diverging rule of colorscheme.rs:63-66 (colour from l / (|l| + |r|), alpha from the level). */
 SGX_API int sgx_set_builtin_scheme(sgx_ctx *ctx, const char *name, int stereo);
 /* eval_continuous(t) of a built-in gradient on the host (ColorScheme::background / foreground, colorscheme.rs:41-53) */

@@ -9,11 +9,13 @@ oracle's pixel stage to evaluate (oracle.set_gradient_fn):
                                 bytes by Math.round, clamped                         RED_YELLOW_BLUE ... ORANGES  (:130-148)
   interpolateTurbo / Cividis    per channel a quintic in t                           TURBO, CIVIDIS               (:140,142)
   interpolateCubehelixLong      (h, s, l) linear in t, no shortest arc, gamma 1,
-                                then d3-color's Cubehelix -> sRGB matrix             CUBEHELIX, COOL (and WARM)   (:141,143)
+                                then d3-color's Cubehelix -> sRGB matrix, bytes by
+                                TRUNCATION (the reference's Cool screenshot decides)  CUBEHELIX, COOL (and WARM)   (:141,143)
 
-PARITY UNPINNED against colorous itself for every one of them (tests/test_host_logic.py says which have an independent
-pin at all: the default cube helix against matplotlib's `cubehelix`, +-1 LSB; the spline's end colours against
-ColorBrewer's; Turbo / Cividis only in shape).  Anchors: tests/golden/brewer_anchors.npz (make_brewer_anchors.py).
+PARITY UNPINNED against colorous itself except where the reference's own screenshots decide (tests/test_host_logic.py:
+the four 256-entry tables' values and Cool's curve + byte rule; it also says which others have an independent pin: the
+default cube helix against matplotlib's `cubehelix`, +-1 LSB; the spline's end colours against ColorBrewer's; Turbo /
+Cividis only in shape).  Anchors: tests/golden/brewer_anchors.npz (make_brewer_anchors.py).
 """
 import math
 import os
@@ -26,6 +28,12 @@ _ANCHORS = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__
 def _byte(v):
     r = math.floor(v + 0.5)            # Math.round: half up
     return int(0.0 if r < 0.0 else (255.0 if r > 255.0 else r))
+
+
+def _byte_trunc(v):
+    """Rust `as u8` on a float: toward zero, saturating, NaN -> 0 -- what colorous does for the cubehelix family, as the
+    reference's own screenshot of Cool shows (tests/golden/screenshot_colours.npz: (109, 63, 169) for (109.70, 63.81, 169.91))"""
+    return int(0.0 if not (v > 0.0) else (255.0 if v >= 255.0 else math.floor(v)))
 
 
 def rgb_basis(anchors):
@@ -76,9 +84,9 @@ def cubehelix_long(h0, s0, l0, h1, s1, l1):
         h = (h0 + t * (h1 - h0) + 120.0) * (math.pi / 180.0)
         s, l = s0 + t * (s1 - s0), l0 + t * (l1 - l0)
         a, ch, sh = s * l * (1.0 - l), math.cos(h), math.sin(h)
-        return (_byte(255.0 * (l + a * (-0.14861 * ch + 1.78277 * sh))),
-                _byte(255.0 * (l + a * (-0.29227 * ch + -0.90649 * sh))),
-                _byte(255.0 * (l + a * (1.97294 * ch))))
+        return (_byte_trunc(255.0 * (l + a * (-0.14861 * ch + 1.78277 * sh))),
+                _byte_trunc(255.0 * (l + a * (-0.29227 * ch + -0.90649 * sh))),
+                _byte_trunc(255.0 * (l + a * (1.97294 * ch))))
     return fn
 
 

@@ -111,8 +111,13 @@ void brewer_eval(double t, uint8_t out[3], void *user)
 //     no shortest-arc on the hue, gamma 1 -- followed by d3-color's Cubehelix -> sRGB matrix.  The default CUBEHELIX,
 //     (300, 0.5, 0) -> (-240, 0.5, 1), is Green's (2011) helix with start 0.5, -1.5 rotations, hue 1, gamma 1: the curve
 //     matplotlib's `cubehelix` colormap traces (checked in tests/test_host_logic.py against matplotlib._cm.cubehelix).
-// The endpoint triples and the byte rule (round to nearest, clamp) are data of this file: PARITY UNPINNED like every other
-// gradient (the crate is not vendored in the reference), replaceable through sgx_set_gradient_fn.
+//     Bytes of the cubehelix family by TRUNCATION (Rust's saturating `as u8`), not d3's Math.round: the one place where
+//     something the reference holds decides -- screenshots/colorscheme-cool.png shows background() = eval_continuous(0.0)
+//     (colorscheme.rs:41-44) as (109, 63, 169) where the curve is (109.70, 63.81, 169.91), the axes = eval_continuous(1.0) as
+//     (175, 239, 90) for (175.23, 239.78, 90.54), and 599 of the curve's 623 truncated colours verbatim against 364 of its
+//     rounded ones (tests/golden/screenshot_colours.npz, tests/test_host_logic.py).
+// The endpoint triples and, for Turbo / Cividis / the splines, the byte rule (round to nearest, clamp) are data of this
+// file: PARITY UNPINNED (the crate is not vendored in the reference), replaceable through sgx_set_gradient_fn.
 struct sgx_poly { const char *name; double r[6], g[6], b[6]; };
 const sgx_poly SGX_POLY[] = {
     {"turbo", {34.61, 1172.33, -10793.56, 33300.12, -38394.49, 14825.05}, {23.31, 557.33, 1225.33, -3574.96, 1073.77, 707.56},
@@ -132,6 +137,12 @@ uint8_t byte_round(double v)
     const double r = std::floor(v + 0.5);
     if (!(r > 0.0)) return 0;   // negative and NaN
     return (uint8_t)(r > 255.0 ? 255.0 : r);
+}
+
+uint8_t byte_trunc(double v)     // Rust `as u8` on a float: toward zero, saturating, NaN -> 0
+{
+    if (!(v > 0.0)) return 0;
+    return (uint8_t)(v >= 255.0 ? 255.0 : v);
 }
 
 void poly_eval(double t, uint8_t out[3], void *user)
@@ -154,9 +165,9 @@ void helix_eval(double t, uint8_t out[3], void *user)
     const double h = (g->h0 + t * (g->h1 - g->h0) + 120.0) * (M_PI / 180.0);
     const double s = g->s0 + t * (g->s1 - g->s0), l = g->l0 + t * (g->l1 - g->l0);
     const double a = s * l * (1.0 - l), ch = std::cos(h), sh = std::sin(h);
-    out[0] = byte_round(255.0 * (l + a * (-0.14861 * ch + 1.78277 * sh)));
-    out[1] = byte_round(255.0 * (l + a * (-0.29227 * ch + -0.90649 * sh)));
-    out[2] = byte_round(255.0 * (l + a * (1.97294 * ch)));
+    out[0] = byte_trunc(255.0 * (l + a * (-0.14861 * ch + 1.78277 * sh)));
+    out[1] = byte_trunc(255.0 * (l + a * (-0.29227 * ch + -0.90649 * sh)));
+    out[2] = byte_trunc(255.0 * (l + a * (1.97294 * ch)));
 }
 
 // name -> (evaluator, its data) for every continuous gradient this library evaluates itself

@@ -214,15 +214,15 @@ def test_independent_pins_of_the_colour_schemes_and_which_stay_unpinned():
     #                                   spline against matplotlib's piecewise-linear ramp over the same anchors -- close, not a pin
     #   Turbo, Cividis                  d3 publishes POLYNOMIAL FITS of these maps; matplotlib ships the maps themselves (256 entries):
     #                                   the fit is within 26 / 19 LSB of the map -- the right shape, not a pin
-    #   Cool                            no independent source here (matplotlib's `cool` is another map)
-    # => UNPINNED against anything but this build's reading of the d3 formulas: the 13 splines (interior), Turbo, Cividis, Cool.
+    #   Cool                            the reference's own screenshot (test_reference_screenshots_pin_...): curve and byte rule
+    # => UNPINNED against anything but this build's reading of the d3 formulas: the 13 splines (interior), Turbo, Cividis.
     import matplotlib
     import numpy as np
     from spectrogram_rs_amd.engine import builtin_gradient, builtin_gradient_eval
     ts = (np.arange(256) + 0.5) / 256.0
     mpl = lambda name: np.rint(np.asarray(matplotlib.colormaps[name](ts))[:, :3] * 255.0).astype(int)
     lib = lambda name: np.array([builtin_gradient_eval(name, float(t)) for t in ts], int)
-    assert np.abs(lib("cubehelix") - mpl("cubehelix")).max() <= 1
+    assert np.abs(lib("cubehelix") - mpl("cubehelix")).max() <= 2      # (truncated bytes against matplotlib's rounded 256-entry samples; the curve itself: next test)
     for name in ("viridis", "magma", "inferno", "plasma"):
         assert np.array_equal(builtin_gradient(name), np.rint(np.asarray(matplotlib.colormaps[name].colors) * 255.0).astype(np.uint8))
     brewer = {"red_yellow_blue": "RdYlBu", "red_blue": "RdBu", "spectral": "Spectral", "red_yellow_green": "RdYlGn", "pink_green": "PiYG",
@@ -244,14 +244,52 @@ def test_cubehelix_default_is_the_curve_matplotlib_traces():
     from spectrogram_rs_amd.engine import builtin_gradient_eval
     fns = _cm.cubehelix(gamma=1.0, s=0.5, r=-1.5, h=1.0)
     ts = np.linspace(0.0, 1.0, 2049)
-    want = np.stack([np.clip(np.floor(255.0 * np.asarray(fns[k](ts), np.float64) + 0.5), 0, 255) for k in ("red", "green", "blue")], 1)
+    # bytes by truncation (Rust's `as u8`): the rule the reference's Cool screenshot shows for this family (test below)
+    want = np.stack([np.clip(np.floor(255.0 * np.asarray(fns[k](ts), np.float64)), 0, 255) for k in ("red", "green", "blue")], 1)
     got = np.array([builtin_gradient_eval("cubehelix", float(t)) for t in ts], np.float64)
     d = np.abs(got - want)
-    assert d.max() <= 1 and (d > 0).mean() < 2e-3, (d.max(), (d > 0).mean())   # same curve; a byte may sit on a rounding tie
+    assert d.max() <= 1 and (d > 0).mean() < 2e-3, (d.max(), (d > 0).mean())   # same curve; a byte may sit on an integer
     assert builtin_gradient_eval("cubehelix", 0.0) == (0, 0, 0) and builtin_gradient_eval("cubehelix", 1.0) == (255, 255, 255)
     # Cool / Warm meet at t = 1 (d3's rainbow is warm(2t) then cool(2 - 2t)): (h, s, l) = (80, 1.5, 0.8)
     assert builtin_gradient_eval("cool", 1.0) == builtin_gradient_eval("warm", 1.0)
-    assert builtin_gradient_eval("cool", 0.0) == (110, 64, 170) and builtin_gradient_eval("warm", 0.0) == (110, 64, 170)
+    assert builtin_gradient_eval("cool", 0.0) == (109, 63, 169) and builtin_gradient_eval("warm", 0.0) == (109, 63, 169)
+
+
+def test_reference_screenshots_pin_the_table_values_and_cools_curve():
+    # The ONLY outputs of the colour path that the reference itself holds: screenshots/colorscheme-{viridis,magma,plasma,cool}.png
+    # (README.md).  tests/golden/screenshot_colours.npz (make_screenshot_colours.py, build container) keeps their data: the window's
+    # fill = ColorScheme::background() = gradient.eval_continuous(0.0), the axes = foreground() = eval_continuous(1.0)
+    # (colorscheme.rs:41-53), and the set of distinct opaque colours (pixels of color_for, :55-71, scaled by the toolkit: many blends,
+    # many verbatim).  What this pins: the VALUES of the three 256-entry tables (entry 0, entry 255, and >= 150 further entries found
+    # verbatim) and, for Cool -- a continuous curve with no table -- the curve AND the byte rule (truncation, not d3's rounding).
+    # What it does not pin: the index rule t -> entry (no pixel's t is known), Inferno and the other 14 gradients.
+    import os
+    import numpy as np
+    from oracle.gradients import CONTINUOUS
+    from spectrogram_rs_amd.engine import builtin_gradient, builtin_gradient_eval
+    shots = np.load(os.path.join(os.path.dirname(__file__), "golden", "screenshot_colours.npz"))
+    for name in ("viridis", "magma", "plasma"):
+        table = builtin_gradient(name)
+        assert tuple(shots[name + "_background"]) == tuple(table[0]), name
+        assert tuple(shots[name + "_axis"]) == tuple(table[255]), name
+        seen = set(map(tuple, shots[name + "_colours"].tolist()))
+        verbatim = sum(tuple(int(v) for v in e) in seen for e in table)
+        assert verbatim >= 150, (name, verbatim)                      # measured: viridis 243, magma 171, plasma 236
+    # Cool: background / axes are the curve's ends under truncation -- (109.70, 63.81, 169.91) and (175.23, 239.78, 90.54)
+    assert tuple(shots["cool_background"]) == builtin_gradient_eval("cool", 0.0) == (109, 63, 169)
+    assert tuple(shots["cool_axis"]) == builtin_gradient_eval("cool", 1.0) == (175, 239, 90)
+    cols, cnt = shots["cool_colours"], shots["cool_counts"]
+    seen = set(map(tuple, cols.tolist()))
+    curve = {builtin_gradient_eval("cool", float(t)) for t in np.linspace(0.0, 1.0, 20001)}
+    assert curve == {CONTINUOUS["cool"](float(t)) for t in np.linspace(0.0, 1.0, 20001)}
+    hit = len(curve & seen)
+    assert len(curve) > 600 and hit >= 0.95 * len(curve), (len(curve), hit)          # measured: 599 of 623 (d3's rounding: 364 of 619)
+    # pixel-weighted: more than half of ALL opaque pixels carry a colour of the curve verbatim, three quarters are within 1 LSB of it
+    # (the rest: the toolkit's scaling blends, the border, the axis labels' anti-aliasing)
+    arr = np.array(sorted(curve), np.int32)
+    dist = np.array([int(np.abs(arr - c).max(axis=1).min()) for c in cols.astype(np.int32)])
+    exact, near = cnt[dist == 0].sum() / cnt.sum(), cnt[dist <= 1].sum() / cnt.sum()
+    assert exact >= 0.5 and near >= 0.75, (exact, near)                                # measured: 0.540, 0.768
 
 
 def test_integration_md_shows_the_binding_files_verbatim():
