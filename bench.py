@@ -882,6 +882,8 @@ def config5_leg(args, torch, dist, eng, rank, world, backend, barrier, max_over_
     warm = min(1024, chunk)        # (the sample buffer and the rings hold `chunk` frames: never more per round)
     stream_columns([min(warm, c) for c in counts], warm, produce, lambda g0, p: None, like=like, dst=0)
     acc.zero_()
+    if os.environ.get("BENCH_FAIL_RANK") == str(rank):            # fault injection (tests/test_gpu_config5.py): a rank that dies inside the leg
+        os._exit(7)
     t_over, arrived = run(produce, consume)                       # the run that counts: render + gather, overlapped
     t_comp, _ = run(produce, None, send=False)                    # render only
     t_xfer, _ = run(None, lambda g0, p: None)                     # gather only (re-sends the ring's last contents)

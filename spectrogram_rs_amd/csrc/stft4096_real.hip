@@ -69,7 +69,10 @@ __device__ __forceinline__ float2 cmulf(float2 a, float2 b)
 }
 
 // a raw buffer descriptor over one output row (uniform base); `present` false: zero records, every store through it is dropped by
-// the range check -- a frame outside the requested range costs no branch in the store section
+// the range check -- a frame outside the requested range costs no branch in the store section.  (gfx950 checks lane offset + SCALAR
+// offset against the record count -- tools/bufrange.hip, profiles/r05_bufrange.txt: a store with records 0 and soffset 2048 writes
+// nothing, a load whose soffset alone passes the records reads 0 -- and test_rows_past_the_requested_count_are_never_written holds
+// every two-frames-per-iteration kernel to it with sentinel rows behind and in front of the caller's range.)
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t out_rsrc(char *base, long long byte, bool present)
 {
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)byte);

@@ -1,0 +1,64 @@
+"""BASELINE configs[4] on hardware, inside the suite the driver runs: bench.py's config-5 leg -- PCM generated on the device chunk by
+chunk, the fused PCM -> RGBA kernel, the two-slot ring, the gather of pixel columns to rank 0, sgx_checksum_add over every piece --
+run as TWO FRESH rank processes on the one MI355X of the box (BENCH_BACKEND=gloo BENCH_SINGLE_DEVICE=1: every rank on cuda:0, pieces
+staged through the host; RCCL refuses two ranks on one device).  The ranks are ordinary children of a bare `python bench.py --gpus 2`
+(subprocess; this pytest process has touched the GPU and is never replaced).  What the first 8-GPU run then adds is RCCL alone.
+
+Frame t depends only on samples [tH, tH + W) (reference: src/fourier/audio_transform.rs:34-42), so the sharded bytes must be the
+single process's bytes: the root's checksum over all gathered columns equals the one computed here in-process."""
+import importlib.util
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+TOTAL, CHUNK = 300_003, 32_768          # rank 0: 150 002 frames, rank 1: 150 001 -> 5 rounds each, uneven tails (18 930 / 18 929)
+
+
+def run_bench(extra_env, timeout=900):
+    env = dict(os.environ, BENCH_BACKEND="gloo", BENCH_SINGLE_DEVICE="1", **extra_env)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "BENCH_LAUNCH_ONLY"):
+        env.pop(k, None)
+    argv = ["--gpus", "2", "--steps", "2", "--warmup", "1", "--frames", "65536", "--placements", "1", "--sustain-s", "0",
+            "--config5-frames", str(TOTAL), "--config5-chunk", str(CHUNK), "--leg-timeout", "120"]
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def single_process_checksum(total, chunk):
+    spec = importlib.util.spec_from_file_location("config5_single", os.path.join(ROOT, "tools", "config5_single.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.single_process_checksum(total, chunk)
+
+
+def test_config5_leg_two_ranks_on_one_gpu_equals_the_single_process():
+    p = run_bench({})
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-4000:])
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert "error" not in line, line.get("error")
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0
+    c5 = line["config5"]
+    assert c5["backend"] == "gloo" and c5["ranks_seen"] == [0, 1]
+    assert c5["frames_total"] == TOTAL and c5["frames_per_gpu"] == [150_002, 150_001]
+    assert c5["chunk_columns"] == CHUNK and c5["rounds"] == 5
+    assert c5["gathered_bytes"] == 150_001 * 4096                      # rank 1's columns, every one, once
+    assert c5["sharded_equals_single_gpu_on_first_chunk_of_every_rank"] is True
+    # another chunk size on purpose: the checksum carries global word indices, so it cannot depend on how the stream was cut
+    assert c5["checksum_all_columns"] == single_process_checksum(TOTAL, 50_000)
+    assert c5["frames_per_s"] > 0 and c5["overlapped_s"] > 0
+
+
+def test_config5_leg_a_rank_dying_inside_the_leg_fails_the_run():
+    p = run_bench({"BENCH_FAIL_RANK": "1"})
+    assert p.returncode != 0, p.stdout[-2000:]
+    for ln in p.stdout.splitlines():
+        if ln.startswith("{"):                 # rank 0 may still report: then the line says what happened
+            assert "error" in json.loads(ln)

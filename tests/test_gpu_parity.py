@@ -873,30 +873,81 @@ def test_pixel_path_configuration_space(torch_cuda, gradients, cfg):
     assert np.array_equal(fused.bin_edges(), oracle.bin_edges(cfg["rows"], cfg["f_min"], cfg["f_max"]))
 
 
-def test_non_finite_and_extreme_samples(torch_cuda, gradients):
+@pytest.mark.parametrize("paired", [False, True])
+def test_non_finite_and_extreme_samples(torch_cuda, gradients, paired):
     # NaN / inf / huge samples must not fault or poison neighbouring frames; colours follow Rust's
     # saturating casts (NaN -> index 0); frames without bad samples are unaffected
     torch = torch_cuda
     x = oracle.white_noise(W + 40 * H, seed=5) * np.float32(0.1)
     bad = x.copy()
-    bad[W + 20 * H + 5] = np.nan          # touches frames 13..28 (every frame whose window covers it)
+    bad[W + 20 * H + 5] = np.nan          # touches frames 21..28 (every frame whose window covers it)
     bad[100] = np.float32(3e38)           # frame 0 only (sample 100 < H): overflows to inf in the FFT
-    eng = engine(window_samples=W, hop_samples=H, channels=1, gradient="viridis")
+    eng = engine(window_samples=W, hop_samples=H, channels=1, gradient="viridis", paired_frames=paired)
+    assert bool(eng.info.render_path & 8) == (not paired)
     good_m = eng.stft_batch(to_dev(torch, x)).cpu().numpy()
     bad_m = eng.stft_batch(to_dev(torch, bad)).cpu().numpy()
     touched = np.zeros(41, bool)
     touched[0] = True
     n_idx = W + 20 * H + 5
     touched[[t for t in range(41) if t * H <= n_idx < t * H + W]] = True
-    # a mono transform carries frames 2j and 2j+1 (real / imaginary part): a non-finite sample also
-    # reaches the partner frame of the same transform -- exactly as a non-finite LEFT sample reaches the
-    # RIGHT channel of its frame in the reference's own (l + i r) packing (fft.rs:57,87-88)
-    touched = touched | np.array([touched[min(t ^ 1, 40)] for t in range(41)])
+    if paired:
+        # SGX_FLAG_PAIRED_FRAMES: a transform carries frames 2j and 2j+1 (real / imaginary part): a non-finite sample also
+        # reaches the partner frame of the same transform -- exactly as a non-finite LEFT sample reaches the
+        # RIGHT channel of its frame in the reference's own (l + i r) packing (fft.rs:57,87-88)
+        touched = touched | np.array([touched[min(t ^ 1, 40)] for t in range(41)])
+    # default: every frame its own transform -- a bad sample reaches EXACTLY the frames whose window covers it (frame 1 shares a
+    # workgroup iteration with frame 0, frame 20 with frame 21, frame 29 with frame 28: all three stay bit-identical)
     assert np.array_equal(bad_m[~touched], good_m[~touched])
-    assert not np.isfinite(bad_m[touched]).all()
+    assert all(not np.isfinite(bad_m[t]).all() for t in np.flatnonzero(touched))
+    if not paired:
+        assert not touched[1] and not touched[20] and not touched[29] and touched[21] and touched[28]
     rg = eng.render_batch(to_dev(torch, bad)).cpu().numpy()[:, 0]
     ref = oracle.render_columns(bad_m[:, 0], SR, gradients["viridis"])
     assert np.array_equal(rg, ref)
+
+
+SENTINEL_CASES = [
+    # (window, hop, channels, flags): every kernel that holds two frames per workgroup iteration and drops the second of an odd launch
+    (2048, 256, 1, {}),                          # K1R, sliding window
+    (2048, 100, 1, {}),                          # K1R, any hop
+    (2048, 256, 1, {"paired_frames": True}),     # K1, mono frame pairs
+    (2048, 256, 2, {}),                          # K1, (l, r)
+    (2400, 93, 1, {}),                           # mixed radix, real-input mode (two frames per workgroup to pixels)
+    (2400, 93, 1, {"paired_frames": True}),      # K48 frame pairs
+    (2205, 86, 1, {}),                           # mixed radix, odd window
+    (1102, 43, 1, {}),                           # chirp-z, real-input mode
+    (8192, 512, 1, {}),                          # K16 on a duplicated plane
+]
+
+
+@pytest.mark.parametrize("case", SENTINEL_CASES, ids=lambda c: "W%d-H%d-C%d%s" % (c[0], c[1], c[2], "-" + "-".join(c[3]) if c[3] else ""))
+def test_rows_past_the_requested_count_are_never_written(torch_cuda, case):
+    # an odd launch computes the absent second frame of its last pair and must drop it -- nothing may land in the caller's
+    # buffer at or past row n.  The caller's buffer here is LARGER than the call needs, its tail filled with a sentinel; every output
+    # kind (float rows, half rows, RGBA columns), odd and even counts, also behind a first_frame.
+    torch = torch_cuda
+    Wc, Hc, ch, kw = case
+    eng = engine(window_samples=Wc, hop_samples=Hc, channels=ch, gradient="viridis", **kw)
+    Mc = Wc - 1
+    pcm = to_dev(torch, oracle.white_noise((Wc + 40 * Hc) * ch, seed=23) * np.float32(0.3))
+    extra = 3
+    for first, n in ((0, 1), (0, 5), (3, 7), (0, 8), (2, 33)):
+        want_f = eng.stft_batch(pcm, first_frame=first, max_frames=n)
+        buf = torch.full((n + extra, eng.pairs, Mc, 2), float("nan"), dtype=torch.float32, device="cuda")
+        eng.stft_batch(pcm, first_frame=first, max_frames=n, out=buf)
+        assert torch.equal(buf[:n], want_f) and bool(torch.isnan(buf[n:]).all()), ("f32 rows", first, n)
+        want_h = eng.stft_batch_f16(pcm, first_frame=first, max_frames=n)
+        bufh = torch.full((n + extra, eng.pairs, Mc, 2), float("nan"), dtype=torch.float16, device="cuda")
+        eng.stft_batch_f16(pcm, first_frame=first, max_frames=n, out=bufh)
+        assert torch.equal(bufh[:n], want_h) and bool(torch.isnan(bufh[n:]).all()), ("f16 rows", first, n)
+        want_p = eng.render_batch(pcm, first_frame=first, max_frames=n)
+        bufp = torch.full((n + extra, eng.pairs, R, 4), 0xA5, dtype=torch.uint8, device="cuda")
+        eng.render_batch(pcm, first_frame=first, max_frames=n, out=bufp)
+        assert torch.equal(bufp[:n], want_p) and bool((bufp[n:] == 0xA5).all()), ("rgba columns", first, n)
+        # and in FRONT of the buffer: a call whose output starts inside a larger allocation leaves the rows before it alone
+        big = torch.full((2 + n + extra, eng.pairs, Mc, 2), float("nan"), dtype=torch.float32, device="cuda")
+        eng.stft_batch(pcm, first_frame=first, max_frames=n, out=big[2:])
+        assert torch.equal(big[2:2 + n], want_f) and bool(torch.isnan(big[:2]).all()) and bool(torch.isnan(big[2 + n:]).all())
 
 
 def test_frame_pairing_dynamic_range_and_independent_frames(torch_cuda, mags_err):
