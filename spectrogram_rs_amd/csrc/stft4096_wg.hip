@@ -40,11 +40,20 @@ __device__ __forceinline__ float2 cmulf(float2 a, float2 b)
     return make_float2(fmaf(a.x, b.x, -(a.y * b.y)), fmaf(a.x, b.y, a.y * b.x));
 }
 
+#if SGX_STAMPS
+// diagnostic build only (tools/k1_phases.py): per-phase wave cycles (s_memtime), summed over all waves and iterations
+__device__ unsigned long long g_phase_cycles[20];
+#define SGX_STAMP(i) { const unsigned long long now_ = __builtin_readcyclecounter(); st_acc[i] += now_ - st_last; st_last = now_; }
+#else
+#define SGX_STAMP(i)
+#endif
+
 // PIX: kPixNone = rows (float or half pairs); else the fused pixel path with that pixel code (stft4096_wg.hpp)
 template <bool MONO, int PAIRING, bool C2, int PIX>
 __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
 {
-    constexpr bool RENDER = PIX != kPixNone;
+    constexpr bool RENDER = PIX != kPixNone && PIX != kPixRowsF16;
+    constexpr bool F16 = PIX == kPixRowsF16;    // rows as (l, r) half pairs (compile-time: the row stores are straight-line code)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float2 *buf = reinterpret_cast<float2 *>(smem_raw);
     float2 *tw2 = buf + kBufComplex;
@@ -84,6 +93,7 @@ __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
     // Software pipeline: the samples of transform j+1 are requested while transform j is still in
     // its FFT passes, i.e. BEFORE j's magnitude stores.  vmcnt retires in issue order, so a load
     // issued after 16-32 stores would have to wait for all of them to reach memory first.
+    constexpr bool kSlide2 = !MONO && C2 && PAIRING == kPairAdjacentRow;   // an (l, r) stream at H = 256: sliding register window
     float sa[(MONO && PAIRING == kPairAdjacentRow) ? 9 : 8], sb[8];
     float ld0 = 0.0f, ld1 = 0.0f;   // sliding window: the two rows requested for the next transform
     bool pending = false;
@@ -132,13 +142,21 @@ __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
         } else {
             const float *s0 = p.pcm + (p.first_frame + job) * p.H * p.C;
             if (C2) {
-                // (a sliding register window like the mono one was tried here: stereo input is not traffic-bound and
-                // the extra live registers cost more than the saved row loads)
                 const __amdgpu_buffer_rsrc_t r0 = pcm_rsrc(s0);
+                if (kSlide2 && sequential) {
+                    // H = 256 = one row of (l, r) columns: the next frame's rows 0 .. 6 are this frame's rows 1 .. 7 -- the window slides in
+                    // registers and ONE 8-byte load per thread fetches the new row 7 (round 1 tried this at the register cap and lost 8 %;
+                    // the kernel has 15 registers to spare now, and what the seven saved loads relieve is the CU's vector-memory path,
+                    // which the row stores share: profiles/r05_k1_stereo.txt)
+                    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r0, tid * 8, 2048 * 7, 0);
+                    ld0 = __uint_as_float(v.x); ld1 = __uint_as_float(v.y);
+                    pending = true;
+                } else {
 #pragma unroll
-                for (int a = 0; a < 8; ++a) {
-                    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r0, tid * 8, 2048 * a, 0);
-                    sa[a] = __uint_as_float(v.x); sb[a] = __uint_as_float(v.y);
+                    for (int a = 0; a < 8; ++a) {
+                        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r0, tid * 8, 2048 * a, 0);
+                        sa[a] = __uint_as_float(v.x); sb[a] = __uint_as_float(v.y);
+                    }
                 }
             } else {
                 // one channel, every frame its own (s, s) transform (SGX_FLAG_INDEPENDENT_FRAMES; audio_input_list_model.rs:67-69).
@@ -150,10 +168,22 @@ __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
         }
     };
     if (job_begin < job_end) fetch(job_begin, false);
-    if (MONO && PAIRING == kPairAdjacentRow && kSlideWindow) {
-        // the first window is waited for HERE, so that the loop header carries no pending load of the entry path
+    {
+        // The first window is waited for HERE (an empty asm that reads it), so that the loop header carries no pending load of the entry
+        // path.  Merged with the back edge -- where the same registers are followed by the transform's row stores -- a pending entry load
+        // made the compiler wait at the top of EVERY iteration with vmcnt(6) .. vmcnt(0): for every row store just issued to be
+        // acknowledged by memory, once per transform (round 5: the (l, r) and (s, s) streams, 5.5 -> 4.6 ms per 1e6 frames; the sliding
+        // mono window has had this wait since round 1).
         asm volatile("" ::"v"(sa[0]), "v"(sa[1]), "v"(sa[2]), "v"(sa[3]), "v"(sa[4]), "v"(sa[5]), "v"(sa[6]), "v"(sa[7]),
                      "v"(sa[(MONO && PAIRING == kPairAdjacentRow) ? 8 : 7]));
+        if ((MONO && PAIRING != kPairAdjacentRow) || (!MONO && C2))
+            asm volatile("" ::"v"(sb[0]), "v"(sb[1]), "v"(sb[2]), "v"(sb[3]), "v"(sb[4]), "v"(sb[5]), "v"(sb[6]), "v"(sb[7]));
+        // (the resident constants too: a pass-1 twiddle still pending at the loop entry became a vmcnt(14) .. vmcnt(0) at its first use
+        // inside the loop -- in every iteration, where the only vector-memory operations in flight are the previous transform's stores)
+#pragma unroll
+        for (int q = 1; q < 16; ++q) asm volatile("" ::"v"(tw1[q].x), "v"(tw1[q].y));
+#pragma unroll
+        for (int a = 0; a < 8; ++a) asm volatile("" ::"v"(win[a]));
     }
 
     // Wave priorities.  The four waves of a SIMD belong to four workgroups in four different phases; left to the
@@ -164,7 +194,12 @@ __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
     // stream overlaps the other workgroups' arithmetic better: +6 % (mono), and with the intermediate steps 1 and 2 for
     // the second pass +12 % for stereo input (same-device A/B; the steps cost mono 1 %).  The fused pixel path holds
     // priority 1 through its sample pass and 3 from its row pass on: +12 % over no priorities.
+#if SGX_STAMPS
+    unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_last = __builtin_readcyclecounter();
+#endif
     for (unsigned long long job = job_begin; job < job_end; ++job) {
+        SGX_STAMP(15)   // back edge: loop control
         if (MONO && PAIRING == kPairAdjacentRow && kSlideWindow && pending) {
             // this transform = the previous one moved on by two rows.  vmcnt counts in issue order: the two row
             // loads are complete once no more than `issued_since` younger instructions are outstanding.
@@ -173,7 +208,9 @@ __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
             // `v_mov v0, v97` in FRONT of the waits of the two short paths: a read of a register whose load was still
             // pending (gfx9 has no interlock for it).  tools/isa_check_prefetch.py (run by the Makefile) fails the build
             // if anything touches the two registers between request and wait again.
-            asm volatile("s_cmp_ge_u32 %2, 14\n\t"
+            asm volatile("s_cmp_ge_u32 %2, 16\n\t"
+                         "s_cbranch_scc1 4f\n\t"
+                         "s_cmp_ge_u32 %2, 14\n\t"
                          "s_cbranch_scc1 1f\n\t"
                          "s_cmp_ge_u32 %2, 7\n\t"
                          "s_cbranch_scc1 2f\n\t"
@@ -183,7 +220,10 @@ __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
                          "s_waitcnt vmcnt(7)\n\t"
                          "s_branch 3f\n"
                          "1:\n\t"
-                         "s_waitcnt vmcnt(14)\n"
+                         "s_waitcnt vmcnt(14)\n\t"
+                         "s_branch 3f\n"
+                         "4:\n\t"
+                         "s_waitcnt vmcnt(16)\n"
                          "3:"
                          : "+v"(ld0), "+v"(ld1)
                          : "s"(__builtin_amdgcn_readfirstlane(issued_since))
@@ -192,6 +232,13 @@ __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
             for (int a = 0; a < 7; ++a) sa[a] = sa[a + 2];
             sa[7] = ld0;
             sa[(MONO && PAIRING == kPairAdjacentRow) ? 8 : 7] = ld1;
+        }
+        if (kSlide2 && pending) {
+            // (ld0 / ld1 were waited for behind the previous transform's stores, at the end of its iteration)
+#pragma unroll
+            for (int a = 0; a < 7; ++a) { sa[a] = sa[a + 1]; sb[a] = sb[a + 1]; }
+            sa[7] = ld0;
+            sb[7] = ld1;
         }
         // ---- Hann (fft.rs:53-63) on the prefetched samples
         float er[8], ei[8];
@@ -219,8 +266,10 @@ __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
         pretwiddle8_w16(orr, oi);
         fft8(er, ei);
         fft8(orr, oi);
+        SGX_STAMP(0)    // prefetch wait + Hann + pass-1 arithmetic
 
         lds_barrier();  // the previous transform's partner reads are complete
+        SGX_STAMP(1)    // barrier 0
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int pos = FFT8_OUT[j];
@@ -230,7 +279,9 @@ __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
             buf[(2 * j + 1) * kS1 + tid] = cmulf(vo, tw1[2 * j + 1]);
         }
         __builtin_amdgcn_s_setprio(0);  // (wave priorities: see the note at the head of the loop)
+        SGX_STAMP(2)    // twiddles + image-1 writes (to completion: the stamp drains lgkmcnt)
         lds_barrier();
+        SGX_STAMP(3)    // barrier 1
 
         // ---- pass 2: thread (q1, t0): 16-point FFT over t1, then twiddle w_256^{t0 q2}
         float xr[16], xi[16];
@@ -241,7 +292,9 @@ __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
         }
         fft16(xr, xi);
         if (!MONO) __builtin_amdgcn_s_setprio(1);
+        SGX_STAMP(4)    // image-1 reads + FFT16
         lds_barrier();  // everyone has read image 1
+        SGX_STAMP(5)    // barrier 2
 #pragma unroll
         for (int q2 = 0; q2 < 16; ++q2) {
             const int pos = FFT16_OUT[q2];
@@ -249,7 +302,9 @@ __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
             buf[t0_2 * kS2 + q1_2 + 16 * q2] = q2 == 0 ? v : cmulf(v, tw2[q2 * 16 + t0_2]);
         }
         if (!MONO) __builtin_amdgcn_s_setprio(2);
+        SGX_STAMP(6)    // twiddles (LDS reads) + image-2 writes
         lds_barrier();
+        SGX_STAMP(7)    // barrier 3
 
         // ---- pass 3: thread u = q1 + 16 q2: 16-point FFT over t0 -> bins k = u + 256 q3
 #pragma unroll
@@ -261,59 +316,88 @@ __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
         if (job + 1 < job_end) fetch(job + 1, true);  // ahead of this transform's stores (see above)
         if (RENDER) __builtin_amdgcn_s_setprio(1);  // the pixel passes are long: 3 only from the row pass (the pixel stores) on
         else __builtin_amdgcn_s_setprio(3);
+        SGX_STAMP(8)    // image-2 reads + FFT16 + the next transform's sample requests
         lds_barrier();  // everyone has read image 2
+        SGX_STAMP(9)    // barrier 4
         // partner exchange: publish q3 = 8..15 (the bins P-k of the kept half)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int pos = FFT16_OUT[8 + j];
             buf[j * 256 + col] = make_float2(xr[pos], xi[pos]);
         }
+        SGX_STAMP(10)   // partner writes
         lds_barrier();
+        SGX_STAMP(11)   // barrier 5
 
         // ---- split + magnitude (fft.rs:81-98)
         float ml[8], mr[8];
+        // (l, r) rows: every segment is stored as soon as it is computed -- eight stores spread over the split instead of one burst of eight
+        // behind it (a wave stalls at the issue of a store while the CU's vector-memory path drains the previous ones: 1 083 cycles per
+        // transform for the burst, profiles/r05_k1_stereo.txt; same device 5.10 -> 4.87 ms per 1e6 frames together with the sliding window)
+        constexpr bool kInterleave = !MONO && !RENDER;
+        float2 pb[8] = {};
+        if (kInterleave) {
+#pragma unroll
+            for (int q3 = 0; q3 < 8; ++q3) pb[q3] = buf[(7 - q3) * 256 + pcol];
+        }
+#if SGX_ABL_STORES == 1   // timing only: every row lands in the first 64 rows
+        const long long f0_il = f0 & 63;
+#else
+        const long long f0_il = f0;
+#endif
+        const __amdgpu_buffer_rsrc_t r_il = row_rsrc(reinterpret_cast<char *>(p.mags), (long long)(((size_t)f0_il * p.pairs + p.pair) * ((size_t)kM * (F16 ? 4 : 8))) - (F16 ? 4 : 8));
 #pragma unroll
         for (int q3 = 0; q3 < 8; ++q3) {
             const int pos = FFT16_OUT[q3];
             // F[P-k]: thread 256-u holds it as q3' = 15 - q3 (row 7 - q3); thread 0 as q3' = 16 - q3
-            const float2 b = buf[(7 - q3) * 256 + pcol];
+            const float2 b = kInterleave ? pb[q3] : buf[(7 - q3) * 256 + pcol];
             const float ar = xr[pos], ai = xi[pos];
             const float pr = ar + b.x, pi = ai - b.y;   // a + conj(b) = 2 L^
             const float qr = ar - b.x, qi = ai + b.y;   // a - conj(b) = 2i R^
             ml[q3] = __builtin_amdgcn_sqrtf(fmaf(pr, pr, pi * pi));  // already scaled by 1 / W (see `win`)
             mr[q3] = __builtin_amdgcn_sqrtf(fmaf(qr, qr, qi * qi));
+            if (kInterleave) {
+                // k = 0 (DC) is not part of the output (fft.rs:81): thread 0's first store carries a lane offset beyond the descriptor's records
+                if (F16) {
+                    const __half2 h = __floats2half2_rn(ml[q3], mr[q3]);
+                    __builtin_amdgcn_raw_buffer_store_b32(*reinterpret_cast<const uint32_t *>(&h), r_il, ((q3 == 0 && col == 0) ? (int)0x80000000 : col * 4) + 1024 * (q3 & 3), 4096 * (q3 >> 2), 0);
+                } else {
+#if SGX_ABL_STORES == 3     // timing only: every value computed and live, (practically) no store executed
+                    if (ml[q3] == 12345.678f)
+#endif
+                    __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(ml[q3]), __float_as_uint(mr[q3])}, r_il, ((q3 == 0 && col == 0) ? (int)0x80000000 : col * 8) + 2048 * (q3 & 1), 4096 * (q3 >> 1), kAuxNt);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
 
-        // every stored row is 8 store instructions in every wave (the lane of bin 0 is masked, not skipped; the
-        // wait below assumes 7, one to spare); the fused pixel path issues table loads and pixel stores of its
-        // own: counted as "unknown" = 0
+        SGX_STAMP(12)   // partner reads + split arithmetic ((l, r) rows: and the row stores, one per segment)
+        // every row is 8 store instructions in every wave, whether the row is stored or not (an absent row's descriptor holds zero
+        // records, the lane of bin 0 carries an offset beyond the records); the fused pixel path issues table loads and pixel stores
+        // of its own
         // (the fused pixel path: every wave issues at least n_samples / 256 table loads in the sample pass and R / 256 pixel stores per
         // stored column in the row pass AFTER the two row loads were requested -- a lower bound is all the wait needs; with "unknown = 0"
         // the head of the next transform waited for the pixel stores just issued to be acknowledged by memory)
         issued_since = RENDER ? (p.n_samples >> 8) + (p.R >> 8) * ((have_first ? 1u : 0u) + ((MONO && have_second) ? 1u : 0u))
-                              : 7u * ((have_first ? 1u : 0u) + ((MONO && have_second) ? 1u : 0u));
+                              : (MONO ? 16u : 8u);    // rows: eight store instructions per row in every wave, absent rows included (dropped by their descriptor)
         if (!RENDER) {
             // ---- store [F][pairs][M][2]: uniform row base (SGPR) + one 32-bit lane offset
-            if (p.out_f16) {
+            if (F16) {
                 char *base = reinterpret_cast<char *>(p.mags);
                 const long long row0 = (long long)(((size_t)(have_first ? f0 : 0) * p.pairs + p.pair) * (size_t)kM * 4) - 4;
                 if (MONO) {
-                    if (have_first) store_row_f16<true>(base, row0, col, ml, ml);
-                    if (have_second) store_row_f16<true>(base, (long long)((f1 * p.pairs + p.pair) * (size_t)kM * 4) - 4, col, mr, mr);
-                } else {
-                    store_row_f16<false>(base, row0, col, ml, mr);
-                }
+                    store_row_f16<true>(base, row0, col, ml, ml, have_first);
+                    store_row_f16<true>(base, (long long)((f1 * p.pairs + p.pair) * (size_t)kM * 4) - 4, col, mr, mr, have_second);
+                }   // ((l, r) rows: stored inside the split)
             } else {
                 // byte offset of bin k = 0 of the row (bin k lives 8 k bytes on; k = 0 is never stored)
                 char *base = reinterpret_cast<char *>(p.mags);
                 constexpr size_t kPitch = (size_t)kM * 8;
                 const long long row0 = (long long)(((size_t)(have_first ? f0 : 0) * p.pairs + p.pair) * kPitch) - 8;
                 if (MONO) {
-                    if (have_first) store_row<true>(base, row0, col, ml, ml);
-                    if (have_second) store_row<true>(base, (long long)((f1 * p.pairs + p.pair) * kPitch) - 8, col, mr, mr);
-                } else {
-                    store_row<false>(base, row0, col, ml, mr);
-                }
+                    store_row<true>(base, row0, col, ml, ml, have_first);
+                    store_row<true>(base, (long long)((f1 * p.pairs + p.pair) * kPitch) - 8, col, mr, mr, have_second);
+                }   // ((l, r) rows: stored inside the split)
             }
         } else {
             // ---- fused pixel column(s): magnitude_in -> color_for -> put_pixel
@@ -328,6 +412,7 @@ __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
                 if (q3 == 0 && col == 1) m2[0] = make_float2(ml[0], mr[0]);                            // bin 1 again in front
                 if (q3 == 7 && col == 255) m2[kM + 1] = m2[kM + 2] = make_float2(ml[7], mr[7]);      // bin 2047 twice behind
             }
+
             lds_barrier();
             sample_pass<PIX>(p, m2, vbuf, tid);
             lds_barrier();
@@ -337,7 +422,27 @@ __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
             __builtin_amdgcn_s_setprio(3);
             row_pass<MONO, PIX>(p, row_words, vbuf, dst_a, dst_b, have_first, have_second, pal, tid);
         }
+        SGX_STAMP(13)   // row stores issued (fused pixel path: the pixel passes)
+        if (kSlide2) {
+            asm volatile("" : "+v"(ld0), "+v"(ld1));    // the new row, behind the stores: vmcnt(stores issued since)
+        } else if (!(MONO && PAIRING == kPairAdjacentRow && kSlideWindow)) {
+            // The next transform's samples, requested in front of the stores, are waited for HERE, behind them: in straight-line code
+            // that is vmcnt(stores issued since), which the older loads satisfy while the stores are still in flight.  Left pending
+            // across the back edge the compiler merged them with the entry path and waited at the top of every iteration with
+            // vmcnt(5) .. vmcnt(0): for every row store of the transform to be acknowledged by memory.  (The sliding mono window does
+            // the same by hand, above.)
+            asm volatile("" : "+v"(sa[0]), "+v"(sa[1]), "+v"(sa[2]), "+v"(sa[3]), "+v"(sa[4]), "+v"(sa[5]), "+v"(sa[6]), "+v"(sa[7]));
+            if ((MONO && PAIRING != kPairAdjacentRow) || (!MONO && C2))
+                asm volatile("" : "+v"(sb[0]), "+v"(sb[1]), "+v"(sb[2]), "+v"(sb[3]), "+v"(sb[4]), "+v"(sb[5]), "+v"(sb[6]), "+v"(sb[7]));
+        }
     }
+#if SGX_STAMPS
+    if ((tid & 63) == 0) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) atomicAdd(&g_phase_cycles[i], st_acc[i]);
+        atomicAdd(&g_phase_cycles[16], (unsigned long long)(job_end > job_begin ? job_end - job_begin : 0));   // wave-iterations
+    }
+#endif
 }
 
 // Is the kernel's LUT-index seed floor(log2(power + 1e-7) a + b) (pixel_for) within one of the exact threshold count
@@ -365,6 +470,18 @@ bool seed_within_one(const std::vector<float> &lut_thr, double guess_a, double g
 }
 
 }  // namespace wg
+
+#if SGX_STAMPS
+extern "C" __attribute__((visibility("default"))) int sgx_debug_phase_cycles(unsigned long long *h_out, int reset)
+{
+    hipError_t e = hipMemcpyFromSymbol(h_out, HIP_SYMBOL(wg::g_phase_cycles), sizeof(unsigned long long) * 20);
+    if (e == hipSuccess && reset) {
+        unsigned long long zero[20] = {0};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(wg::g_phase_cycles), zero, sizeof(zero));
+    }
+    return e == hipSuccess ? 0 : -1;
+}
+#endif
 
 hipError_t wg4096_init(sgx_ctx *c, void **out)
 {
@@ -562,7 +679,8 @@ hipError_t launch_wg(const sgx_ctx *c, const void *tables, const float *d_pcm, u
         auto launch = [&](auto mono_c, auto pairing_c, auto c2_c) {
             constexpr bool M_ = decltype(mono_c)::value, C2_ = decltype(c2_c)::value;
             constexpr int P_ = decltype(pairing_c)::value;
-            if (!RENDER) hipLaunchKernelGGL((stft4096_wg_kernel<M_, P_, C2_, kPixNone>), grid, block, lds, c->stream, p);
+            if (!RENDER && out_f16) hipLaunchKernelGGL((stft4096_wg_kernel<M_, P_, C2_, kPixRowsF16>), grid, block, lds, c->stream, p);
+            else if (!RENDER) hipLaunchKernelGGL((stft4096_wg_kernel<M_, P_, C2_, kPixNone>), grid, block, lds, c->stream, p);
             else if (pix == kPixCubic) hipLaunchKernelGGL((stft4096_wg_kernel<M_, P_, C2_, RENDER ? kPixCubic : kPixNone>), grid, block, lds, c->stream, p);
             else if (pix == kPixCosine) hipLaunchKernelGGL((stft4096_wg_kernel<M_, P_, C2_, RENDER ? kPixCosine : kPixNone>), grid, block, lds, c->stream, p);
             else hipLaunchKernelGGL((stft4096_wg_kernel<M_, P_, C2_, RENDER ? kPixGeneric : kPixNone>), grid, block, lds, c->stream, p);
@@ -574,6 +692,10 @@ hipError_t launch_wg(const sgx_ctx *c, const void *tables, const float *d_pcm, u
             else launch(T{}, std::integral_constant<int, kPairAdjacent>{}, F{});
         } else if (channels == 1) {   // every mono frame as its own (s, s) transform
             launch(F{}, std::integral_constant<int, kPairAdjacent>{}, F{});
+#ifndef SGX_NO_STEREO_SLIDE
+        } else if (c->H == 256) {
+            launch(F{}, std::integral_constant<int, kPairAdjacentRow>{}, T{});    // (l, r) at H = 256: sliding register window
+#endif
         } else {
             launch(F{}, std::integral_constant<int, kPairAdjacent>{}, T{});
         }

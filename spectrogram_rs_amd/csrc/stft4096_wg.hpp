@@ -89,11 +89,15 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 // A raw buffer descriptor over one output row: base = the row's bin-0 address (uniform), no stride, no bounds
 // in the way (2 GB window).  Stores through it take an SGPR descriptor + one 32-bit lane offset + a scalar
 // segment offset + an immediate: no per-lane 64-bit address arithmetic at all.
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t row_rsrc(char *mags, long long row_byte)
+// `present` false: zero records, every store through the descriptor is dropped by the range check (lane offset + scalar offset against
+// the records: tools/bufrange.hip) -- a row outside the requested range costs no branch, and the stores of an iteration are
+// straight-line code whose count the compiler's vmcnt waits can rely on
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t row_rsrc(char *mags, long long row_byte, bool present = true)
 {
     const uint32_t olo = __builtin_amdgcn_readfirstlane((uint32_t)row_byte);
     const uint32_t ohi = __builtin_amdgcn_readfirstlane((uint32_t)((unsigned long long)row_byte >> 32));
-    return __builtin_amdgcn_make_buffer_rsrc(mags + (long long)(((unsigned long long)ohi << 32) | olo), 0, 0x7fffffff, 0x00020000);
+    const int records = __builtin_amdgcn_readfirstlane(present ? 0x7fffffff : 0);
+    return __builtin_amdgcn_make_buffer_rsrc(mags + (long long)(((unsigned long long)ohi << 32) | olo), 0, records, 0x00020000);
 }
 
 // the same kind of descriptor over the sample stream from a wave-uniform address on (a frame's first sample)
@@ -108,17 +112,31 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t pcm_rsrc(const float *base)
 // Cache policy of the magnitude stores (A/B on one device, 1e6 frames): an (l, r) stream re-reads 7/8 of every frame's
 // samples through L2, and marking the output non-temporal keeps them there: 6.00 -> 5.57 ms.  A mono stream slides its
 // window in registers and re-reads nothing: there the same bit costs 10-40 %, sc1 30 %.
+#if defined(SGX_AUX)
+constexpr int kAuxNt = SGX_AUX;   // (A/B: bit 0 sc0, bit 1 nt, bit 4 sc1)
+#else
 constexpr int kAuxNt = 2;   // the `nt` bit of a buffer store
+#endif
 template <bool DUP>  // DUP: mono, the row holds (m, m); else (va, vb) = (left, right)
-__device__ __forceinline__ void store_row(char *mags, long long row_byte, int col, const float (&va)[8], const float (&vb)[8])
+__device__ __forceinline__ void store_row(char *mags, long long row_byte, int col, const float (&va)[8], const float (&vb)[8], bool present = true)
 {
-    const __amdgpu_buffer_rsrc_t r = row_rsrc(mags, row_byte);
+    const __amdgpu_buffer_rsrc_t r = row_rsrc(mags, row_byte, present);
     const int lane_off = col * 8;
+    // k = 0 (DC) is not part of the output (fft.rs:81): thread 0's first store carries a lane offset beyond the descriptor's 2 GB and is
+    // dropped by the range check (tools/bufrange.hip) -- eight store instructions in straight-line code for every wave, so that the
+    // compiler's count of the stores issued since the prefetch (its vmcnt waits) is exact
+    const int lane_off0 = col != 0 ? lane_off : (int)0x80000000;
 #pragma unroll
     for (int q3 = 0; q3 < 8; ++q3)
-        if (q3 > 0 || col != 0) {  // k = 0 (DC) is not part of the output (fft.rs:81)
+#if SGX_ABL_STORES == 2       // timing only: one store segment of eight
+        if (q3 == 1) {
+#elif SGX_ABL_STORES == 3     // timing only: every value computed and live, (practically) no store executed
+        if (va[q3] == 12345.678f) {
+#else
+        {
+#endif
             const u32x2 d = {__float_as_uint(va[q3]), __float_as_uint(DUP ? va[q3] : vb[q3])};
-            __builtin_amdgcn_raw_buffer_store_b64(d, r, lane_off + 2048 * (q3 & 1), 4096 * (q3 >> 1), DUP ? 0 : kAuxNt);
+            __builtin_amdgcn_raw_buffer_store_b64(d, r, (q3 == 0 ? lane_off0 : lane_off) + 2048 * (q3 & 1), 4096 * (q3 >> 1), DUP ? 0 : kAuxNt);
         }
 }
 
@@ -141,7 +159,8 @@ constexpr int kColSlots = 2050;                                 // slots of the 
 constexpr int kMaxFusedSamples = kBufComplex - kColSlots;       // float2 per sample behind it (2302)
 // which pixel code an instantiation carries: the launch-uniform switches -- the interpolator, the LUT search -- are compile-time,
 // each instantiation holds one path's code and live ranges
-constexpr int kPixNone = 0, kPixCubic = 1, kPixCosine = 2, kPixGeneric = 3;   // kPixGeneric: interpolator at run time, LUT seed + walk (SGX_FLAG_LUT_WALK / proof failed)
+constexpr int kPixNone = 0, kPixCubic = 1, kPixCosine = 2, kPixGeneric = 3, kPixRowsF16 = 4;   // kPixRowsF16: no pixels either -- half-pair rows (stft4096_wg.hip)
+//   // kPixGeneric: interpolator at run time, LUT seed + walk (SGX_FLAG_LUT_WALK / proof failed)
 
 // (The repeats are written by the ONE thread that holds bin 1 / bin 2047, in the one unrolled step where it does -- a test of the
 // bin index in every step of every thread kept sixteen compares' worth of values alive and spilled 14 registers.)
@@ -287,16 +306,16 @@ __device__ __forceinline__ void row_pass(const Params &p, const uint32_t (&row_w
 
 // the same row as IEEE half pairs (round to nearest even): bin k at byte 4 k of rowm4
 template <bool DUP>
-__device__ __forceinline__ void store_row_f16(char *mags, long long row_byte, int col, const float (&va)[8], const float (&vb)[8])
+__device__ __forceinline__ void store_row_f16(char *mags, long long row_byte, int col, const float (&va)[8], const float (&vb)[8], bool present = true)
 {
-    const __amdgpu_buffer_rsrc_t r = row_rsrc(mags, row_byte);
+    const __amdgpu_buffer_rsrc_t r = row_rsrc(mags, row_byte, present);
     const int lane_off = col * 4;
+    const int lane_off0 = col != 0 ? lane_off : (int)0x80000000;   // k = 0 (DC): dropped by the range check (see store_row)
 #pragma unroll
-    for (int q3 = 0; q3 < 8; ++q3)
-        if (q3 > 0 || col != 0) {
-            const __half2 h = __floats2half2_rn(va[q3], DUP ? va[q3] : vb[q3]);
-            __builtin_amdgcn_raw_buffer_store_b32(*reinterpret_cast<const uint32_t *>(&h), r, lane_off + 1024 * (q3 & 3), 4096 * (q3 >> 2), 0);
-        }
+    for (int q3 = 0; q3 < 8; ++q3) {
+        const __half2 h = __floats2half2_rn(va[q3], DUP ? va[q3] : vb[q3]);
+        __builtin_amdgcn_raw_buffer_store_b32(*reinterpret_cast<const uint32_t *>(&h), r, (q3 == 0 ? lane_off0 : lane_off) + 1024 * (q3 & 3), 4096 * (q3 >> 2), 0);
+    }
 }
 
 }  // namespace wg
