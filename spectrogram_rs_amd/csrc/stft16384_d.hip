@@ -113,7 +113,7 @@ __device__ __forceinline__ void store16(u32x4 v, __amdgpu_buffer_rsrc_t r, int v
 {
     (void)aux_is_compile_time_below;
     __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, soff, D_OUT_AUX);
-    asm volatile("s_nop 2");
+    asm volatile("s_nop 2" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));   // (reads the data registers: the scheduler cannot move their rewrite in front of the wait states)
 }
 #ifdef D_ABL_NOSTORE
 #define D_STORE_OK(v) ((v) == 12345.678f)   // ablation builds: (practically) never true, but the value stays live
@@ -142,6 +142,14 @@ __global__ void __launch_bounds__(256) duplicate_mono_kernel(const float *pcm, f
         reinterpret_cast<float2 *>(plane)[i] = make_float2(s, s);
     }
 }
+
+#if SGX_STAMPS
+// diagnostic build only (tools/k16_phases.py): per-phase wave cycles (s_memtime), summed over all waves and iterations
+__device__ unsigned long long g_phase_cycles16[24];
+#define SGX_STAMP(i) { const unsigned long long now_ = __builtin_readcyclecounter(); st_acc[i] += now_ - st_last; st_last = now_; }
+#else
+#define SGX_STAMP(i)
+#endif
 
 template <bool MONO>
 __global__ void __launch_bounds__(1024, 1) stft16384_d_kernel(Params p)
@@ -288,7 +296,15 @@ __global__ void __launch_bounds__(1024, 1) stft16384_d_kernel(Params p)
             }
         }
     };
+#if SGX_STAMPS
+    unsigned long long st_acc[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_last = __builtin_readcyclecounter(), st_iters = 0;
+#endif
     for (unsigned long long job = job_begin; job < job_end; job += job_step) {
+#if SGX_STAMPS
+        ++st_iters;
+#endif
+        SGX_STAMP(19)   // loop control
         long long f0, f1;
         bool have_first = true, have_second = true;
         uint32_t pair = 0;
@@ -318,13 +334,20 @@ __global__ void __launch_bounds__(1024, 1) stft16384_d_kernel(Params p)
         pretwiddle8_w16(orr, oi);
         fft8(er, ei);
         fft8(orr, oi);
+        SGX_STAMP(0)    // job bookkeeping + pass-1 arithmetic (two FFT8)
         lds_barrier();  // the previous transform's partner reads are complete, its staged row is complete
+        SGX_STAMP(1)    // barrier A
         if (prev.valid) flush(prev);
+        SGX_STAMP(2)    // flush: staged row read back, the first 16-byte store issued
         {
             float2 *w1 = buf + tid;   // element (index, r) at 4 index + r = 4 (q kS1 + col) + r = 4 q kS1 + tid
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                if (j == 4) lds_barrier();   // rows 8..15 of the image lie over the staged row: everyone has read it back
+                if (j == 4) {   // rows 8..15 of the image lie over the staged row: everyone has read it back
+                    SGX_STAMP(3)
+                    lds_barrier();
+                    SGX_STAMP(4)
+                }
                 const int pos = FFT8_OUT[j];
                 const float2 ve = make_float2(er[pos], ei[pos]);
                 const float2 vo = make_float2(orr[pos], oi[pos]);
@@ -332,7 +355,9 @@ __global__ void __launch_bounds__(1024, 1) stft16384_d_kernel(Params p)
                 w1[4 * (2 * j + 1) * kS1] = cmulf(vo, tw1[2 * j + 1]);
             }
         }
+        SGX_STAMP(5)    // image-1 writes, second half (3: first half; 4: barrier B)
         lds_barrier();
+        SGX_STAMP(6)    // barrier C
 
         // ---- pass 2: lane (q1, t0, r), col = t0 + 16 t1: FFT16 over t1 -> q2, twiddle w_1024^{q2 (4 t0 + r)}
         float xr[16], xi[16];
@@ -345,6 +370,7 @@ __global__ void __launch_bounds__(1024, 1) stft16384_d_kernel(Params p)
                 xr[t1] = v.x; xi[t1] = v.y;
             }
             fft16(xr, xi);
+            SGX_STAMP(7)    // image-1 reads + FFT16
             // Row q1 of the image belongs to wave q1 alone from here to the end of pass 3: it read all of it above, writes the pass-2
             // results back into it (element (q2, t0, r) at 68 q2 + 4 t0 + r: 16 x 68 = the row's 1088 slots) and reads them again as
             // the pass-3 thread (q1, q2, r) -- LDS instructions of one wave execute in order, so neither the overwrite nor the read-back
@@ -358,6 +384,7 @@ __global__ void __launch_bounds__(1024, 1) stft16384_d_kernel(Params p)
                 w2[68 * q2] = q2 == 0 ? v : cmulf(v, tw[64 * q2]);
             }
         }
+        SGX_STAMP(8)    // pass-2 twiddles + writes (to completion)
 
         // ---- pass 3: lane (q1, q2, r) = (wave, (tid >> 2) & 15, tid & 3), i.e. u = q1 + 16 q2: FFT16 over t0 -> q3
         {
@@ -369,6 +396,7 @@ __global__ void __launch_bounds__(1024, 1) stft16384_d_kernel(Params p)
             }
         }
         fft16(xr, xi);
+        SGX_STAMP(9)    // pass-3 reads + FFT16
         // the next transform's samples: ahead of this transform's stores (vmcnt retires in order), and as early as the registers
         // allow -- here, before the recombination (same-device A/B against "after the publish": +3 %; after the recombination the
         // compiler spills 14 registers)
@@ -407,7 +435,9 @@ __global__ void __launch_bounds__(1024, 1) stft16384_d_kernel(Params p)
             xr[a] = odd ? br : ar; xi[a] = odd ? bi : ai;
             xr[b] = odd ? ar : br; xi[b] = odd ? ai : bi;
         }
+        SGX_STAMP(10)   // prefetch requests + recombination (twiddles, two DPP stages)
         lds_barrier();  // everyone has read image 2
+        SGX_STAMP(11)   // barrier D
         {
             // slot (h, u, L) at 1088 h + 4 (u & 15) + 68 (u >> 4) + L: the lanes of a wave hold u = q1 + 16 q2 for one q1 -- at a stride of
             // 68 complex per q2 they fall into different banks, here and in the partner reads below
@@ -418,7 +448,9 @@ __global__ void __launch_bounds__(1024, 1) stft16384_d_kernel(Params p)
                 wp[1088 * h] = make_float2(xr[pos], xi[pos]);
             }
         }
+        SGX_STAMP(12)   // partner writes
         lds_barrier();
+        SGX_STAMP(13)   // barrier E
 
         // ---- split + magnitude (fft.rs:81-98).  Kept (u, qq) of lane L pairs with slot h = 7 - qq of lane L of quad 256 - u;
         //      quad 0 is its own mirror one row up (h = 8 - qq), and its qq = 0 partners are single values of other lanes of the
@@ -448,9 +480,18 @@ __global__ void __launch_bounds__(1024, 1) stft16384_d_kernel(Params p)
             const int b = kbase + 256 * qq - 1;     // 0-based bin
             if (!dc) stage[stage_slot(b)] = make_float2(ml, mr);
         }
+        SGX_STAMP(14)   // partner reads + split + staging writes
         prev = Pending{f0, f1, pair, have_first, have_second, true};
         if (more) take(nxt.data_second);
+        SGX_STAMP(15)   // wait for the next samples + Hann
     }
+#if SGX_STAMPS
+    if ((tid & 63) == 0) {
+#pragma unroll
+        for (int i = 0; i < 20; ++i) atomicAdd(&g_phase_cycles16[i], st_acc[i]);
+        atomicAdd(&g_phase_cycles16[20], st_iters);
+    }
+#endif
     if (prev.valid) {   // the last transform's row
         lds_barrier();
         flush(prev);
@@ -465,6 +506,18 @@ struct TablesD {
 };
 
 }  // namespace d16k
+
+#if SGX_STAMPS
+extern "C" __attribute__((visibility("default"))) int sgx_debug_phase_cycles16(unsigned long long *h_out, int reset)
+{
+    hipError_t e = hipMemcpyFromSymbol(h_out, HIP_SYMBOL(d16k::g_phase_cycles16), sizeof(unsigned long long) * 24);
+    if (e == hipSuccess && reset) {
+        unsigned long long zero[24] = {0};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(d16k::g_phase_cycles16), zero, sizeof(zero));
+    }
+    return e == hipSuccess ? 0 : -1;
+}
+#endif
 
 bool d16384_supported(const sgx_ctx *c)
 {

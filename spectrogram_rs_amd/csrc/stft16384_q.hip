@@ -141,7 +141,7 @@ __device__ __forceinline__ void st_f4(__amdgpu_buffer_rsrc_t r, int voff, int so
     __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(a), __float_as_uint(b), __float_as_uint(c), __float_as_uint(d)}, r, voff, soff, AUX);
     // (two wait states: with the store's scalar offset in an SGPR the compiler's hazard table allows a vector write of the data
     // registers right behind a 16-byte store; the lane-quad kernel, stft16384_d.hip, had rows corrupted that way)
-    asm volatile("s_nop 2");
+    asm volatile("s_nop 2" ::"v"(a), "v"(b), "v"(c), "v"(d));   // (reads the data: a rewrite of their registers cannot be scheduled in front of the wait states)
 }
 #ifdef Q_ABL_NOSTORE
 #define Q_STORE_OK(v) ((v) == 12345.678f)   // ablation builds: (practically) never true, but the value stays live
