@@ -40,6 +40,10 @@ __device__ __forceinline__ float2 cmulf(float2 a, float2 b)
     return make_float2(fmaf(a.x, b.x, -(a.y * b.y)), fmaf(a.x, b.y, a.y * b.x));
 }
 
+#ifndef SGX_PRIO_A
+#define SGX_PRIO_A 1   // (l, r) / (s, s) transforms: wave priority from the end of pass 2 (A) and from the image-2 writes (B) on; 3 from the split on
+#define SGX_PRIO_B 2
+#endif
 #if SGX_STAMPS
 // diagnostic build only (tools/k1_phases.py): per-phase wave cycles (s_memtime), summed over all waves and iterations
 __device__ unsigned long long g_phase_cycles[20];
@@ -291,7 +295,7 @@ __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
             xr[t1] = v.x; xi[t1] = v.y;
         }
         fft16(xr, xi);
-        if (!MONO) __builtin_amdgcn_s_setprio(1);
+        if (!MONO) __builtin_amdgcn_s_setprio(RENDER ? 2 : SGX_PRIO_A);   // (fused (l, r) pixels: 2 / 2 measured 3 % ahead of 1 / 2, rows the other way round)
         SGX_STAMP(4)    // image-1 reads + FFT16
         lds_barrier();  // everyone has read image 1
         SGX_STAMP(5)    // barrier 2
@@ -301,7 +305,7 @@ __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
             const float2 v = make_float2(xr[pos], xi[pos]);
             buf[t0_2 * kS2 + q1_2 + 16 * q2] = q2 == 0 ? v : cmulf(v, tw2[q2 * 16 + t0_2]);
         }
-        if (!MONO) __builtin_amdgcn_s_setprio(2);
+        if (!MONO) __builtin_amdgcn_s_setprio(SGX_PRIO_B);
         SGX_STAMP(6)    // twiddles (LDS reads) + image-2 writes
         lds_barrier();
         SGX_STAMP(7)    // barrier 3

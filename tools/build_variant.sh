@@ -10,7 +10,7 @@ mkdir -p ../ab build/ab
 FLAGS="-O3 -std=c++17 -fPIC -fvisibility=hidden -ffp-contract=off -fno-slp-vectorize -Wall -Wno-unused-result --offload-arch=gfx950 -munsafe-fp-atomics"
 /opt/rocm/bin/hipcc $FLAGS "$@" -c ${SRC:-stft4096_wg.hip} -o build/ab/$name.o
 /opt/rocm/bin/hipcc $FLAGS "$@" -S --cuda-device-only ${SRC:-stft4096_wg.hip} -o build/ab/$name.s 2>/dev/null
-python3 ../../tools/isa_check_store16.py build/ab/$name.s
+if grep -q buffer_store_dwordx4 build/ab/$name.s; then python3 ../../tools/isa_check_store16.py build/ab/$name.s; fi
 objs=$(ls build/*.o | grep -v ${SRC:-stft4096_wg.hip}.o)
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -o ../ab/$name.so $objs build/ab/$name.o
 echo built ../ab/$name.so
