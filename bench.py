@@ -64,16 +64,12 @@ ALGO_BYTES_APP = H_APP * 2 * 4 + (W_APP - 1) * 2 * 4          # 19 936 B / frame
 ALGO_BYTES_APP_PIXEL = H_APP * 2 * 4 + R * 4                  # 4 840 B / frame
 KERNEL_NAMES = {
     0: ("generic power-of-two (workgroup per frame, LDS radix-4)", "sgx::stft_generic_kernel"),
-    1: ("stft4096 wave-per-transform", "sgx::stft4096_kernel<6, true>"),
     2: ("stft4096 workgroup-per-transform (256 threads x 16 points, radix-16 x3, mono frame pairs), scalar codelets",
         "sgx::wg::stft4096_wg_kernel<true, 0, false, 0>"),
     "real": ("stft4096 real-input: every mono frame its own transform, a 2048-point complex transform of the real frame + one butterfly per bin "
              "(256 threads x 2 frames x 8 points, radix 8 x 16 x 16, sliding half-row window)", "sgx::wgr::stft4096_real_kernel<0, 0, true>"),
-    3: ("stft4096 workgroup-per-transform (256 threads x 16 points, radix-16 x3, mono frame pairs), packed (re, im) codelets",
-        "sgx::wgp::stft4096_wgp_kernel<true, 0, false, false>"),
     5: ("stft16384 as four 4096-point residues (512 threads = 256 lane pairs, DPP decimation)", "sgx::q16k::stft16384_q_kernel<false, true>"),
     6: ("mixed radix at the window's own length (compile-time plan)", "sgx::mix::stft_mixed_fixed_kernel"),
-    7: ("stft16384 workgroup-per-transform (1024 threads, whole transform in LDS)", "sgx::wg16k::stft16384_wg_kernel<false>"),
     8: ("stft16384 as four time-decimated 4096-point transforms in the lanes of a quad (1024 threads per transform, DPP recombination)",
         "sgx::d16k::stft16384_d_kernel<false>"),
     9: ("stft4800 workgroup-per-transform (320 threads, 16 x 20 x 15, resident twiddles, mono frame pairs)", "sgx::w48::stft4800_wg_kernel<0, false>"),
@@ -101,7 +97,6 @@ def parse(argv=None):
     ap.add_argument("--leg-timeout", type=float, default=600.0, help="seconds after which a stalled collective leg is given up (exit 3)")
     ap.add_argument("--cpu-frames", type=int, default=262_144, help="frames of the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--generic", action="store_true", help="force the generic power-of-two kernel")
-    ap.add_argument("--packed", action="store_true", help="the packed (re, im) variant of the 4096-point kernel (A/B)")
     return ap.parse_args(argv)
 
 
@@ -298,7 +293,7 @@ def main_rank(args):
 
     F = args.frames
     eng = SpectrogramEngine(48000.0, window_samples=W, hop_samples=H, channels=1, device=local_rank,
-                            force_generic=args.generic, packed_kernel=args.packed, interp=1, gradient="viridis")
+                            force_generic=args.generic, interp=1, gradient="viridis")
     # weak scaling: one stream of world*F frames; rank g owns the contiguous range frame_range(g)
     # and generates exactly its samples (with the W-H halo) -- no input exchange
     first_frame, n_own = frame_range(rank, world, world * F)

@@ -85,7 +85,6 @@ typedef struct sgx_config {
 
 #define SGX_FLAG_FORCE_GENERIC 1u /* use the generic power-of-two kernel even where a tuned one exists, the chirp-z kernel even where the mixed-radix one applies (testing) */
 #define SGX_FLAG_NO_FUSED_RENDER 4u /* sgx_render_batch: run STFT and pixel stage as two kernels even where the fused one applies (A/B) */
-#define SGX_FLAG_PACKED_KERNEL 8u  /* W = 2048: workgroup-per-transform kernel with packed (re, im) arithmetic instead of scalar (A/B) */
 /* Mono streams.  The reference duplicates a mono sample into (s, s) and transforms every frame on its own
  * (audio_input_list_model.rs:67-69, fft.rs:47-99).  DEFAULT here, at every window and hop: exactly that dataflow, one transform per
  * frame -- every frame within north_star's tolerance of its OWN peak on any input.  At W 2048 (any hop, any alignment of the stream)
@@ -104,10 +103,8 @@ typedef struct sgx_config {
 #define SGX_FLAG_COMPLEX_MONO 512u /* mono: the literal (s, s) 2W-point complex transform per frame -- fft.rs:47-57 -- wherever a
                                       real-input kernel would run (A/B; implies no pairing) */
 #define SGX_FLAG_LUT_WALK 64u      /* fused pixel kernel: walk the dB thresholds from the log2 seed even where the host has shown that one compare pair settles the LUT index (A/B, and the test of the fallback) */
-#define SGX_FLAG_LEGACY_16K 32u    /* W = 8192: the first 16384-point kernel (whole transform in LDS, one workgroup per CU) instead of the four-residue one (A/B) */
 #define SGX_FLAG_RESIDUE_16K 128u  /* W = 8192: the second 16384-point kernel (four 4096-point residues of the OUTPUT, two passes of a 512-thread workgroup) instead of the time-decimated one (A/B) */
 #define SGX_FLAG_MIXED_GENERIC 256u /* W = 2400: the composite-radix kernel (any 2-3-5-7-smooth length) instead of the tuned 4800-point one (A/B) */
-#define SGX_FLAG_WAVE_KERNEL 2u   /* W = 2048: use the wave-per-transform kernel instead of the workgroup-per-transform one (A/B) */
 
 typedef struct sgx_info {
     uint32_t struct_size;
@@ -120,7 +117,7 @@ typedef struct sgx_info {
     uint32_t rows;            /* R */
     uint32_t sample_rate_u32; /* SampleRate(sample_rate as u32)      simple_spectrogram.rs:138 */
     uint32_t total_samples_per_column; /* sum over rows of magnitude_in's sample count */
-    uint32_t stft_kernel;     /* 0 = generic power-of-two, 1 = 4096-point wave-per-transform, 2 = 4096-point workgroup-per-transform (default), 3 = the same with packed (re, im) arithmetic, 4 = Bluestein chirp-z (any 2W), 5 = 16384-point as four 4096-point residues of the output (SGX_FLAG_RESIDUE_16K), 6 = mixed radix (2W = 2^a 3^b 5^c 7^d <= 20480, e.g. the application's 4800, 4410 and 19200), 7 = 16384-point, whole transform in LDS (SGX_FLAG_LEGACY_16K), 8 = 16384-point as four time-decimated 4096-point transforms in the lanes of a quad, one 1024-thread workgroup per transform (default for W = 8192), 9 = 4800-point workgroup-per-transform, 16 x 20 x 15 (default for W = 2400, the application's window at 48 kHz; streams of more than two channels run 6) */
+    uint32_t stft_kernel;     /* 0 = generic power-of-two, 2 = 4096-point workgroup-per-transform (default at W 2048), 4 = Bluestein chirp-z (any 2W), 5 = 16384-point as four 4096-point residues of the output (SGX_FLAG_RESIDUE_16K), 6 = mixed radix (2W = 2^a 3^b 5^c 7^d <= 20480, e.g. the application's 4800, 4410 and 19200), 8 = 16384-point as four time-decimated 4096-point transforms in the lanes of a quad, one 1024-thread workgroup per transform (default for W = 8192), 9 = 4800-point workgroup-per-transform, 16 x 20 x 15 (default for W = 2400, the application's window at 48 kHz; streams of more than two channels run 6) */
     uint32_t render_path;     /* sgx_render_batch as configured NOW (palette included): bit 0 = one fused PCM-to-pixel kernel (the
                                  4096-point kernel, or a compile-time plan of the mixed-radix kernel whose LDS image holds the column),
                                  bit 1 = its LUT index is seed + one compare pair (else seed + walk); neither = two kernels;
@@ -328,6 +325,29 @@ SGX_API int sgx_live_tick_view(sgx_live *live, sgx_view *view, size_t max_frames
  * at the BOTTOM (GL).  The palette texture is ColorScheme::lookup_table(32) of the context's current colour scheme,
  * min_db / max_db the context's. */
 SGX_API int sgx_view_draw(sgx_view *view, uint32_t width, uint32_t height, float *d_rgba_f32);
+
+/* ---- the CPU pixel path's image ring --------------------------------------------------------------
+ * SimpleSpectrogram keeps a row-major width x height RGBA Pixbuf (simple_spectrogram.rs:89-94; 1024 x 1024), writes every new
+ * frame as one pixel column at x = offset, image row height - 1 - py (:140-161), advances offset = (px + 1) % width (:164) and
+ * composes the scrolling picture from the sub-images [offset, width) and [0, offset) (:181-209).  sgx_image is that Pixbuf on
+ * the device: [height][width][4] bytes, rowstride 4 * width, height = the context's rows.  Destroy images before sgx_destroy(ctx)
+ * (an image that outlives its context answers SGX_ERR_INVALID_ARG). */
+typedef struct sgx_image sgx_image;
+SGX_API int sgx_image_create(sgx_ctx *ctx, uint32_t width /* 1024 */, sgx_image **out);
+SGX_API void sgx_image_destroy(sgx_image *image);
+/* The pixel loop's put_pixel + offset update for n columns at once (:140-164): d_rgba [n][rows][4] -- a DEVICE pointer, e.g. what
+ * sgx_render_batch wrote -- column i lands at x = (offset + i) % width, offset advances by n (mod width); with n > width the ring
+ * laps itself and the later columns win, as written one by one.  The new offset is returned. */
+SGX_API int sgx_image_write_columns(sgx_image *image, const uint8_t *d_rgba, size_t n_columns, uint32_t *offset_out);
+SGX_API uint32_t sgx_image_offset(const sgx_image *image);
+/* One GUI tick of SimpleSpectrogram::snapshot (:136-165: `for frequency_sample in fft.process()` -> put_pixel): every complete frame
+ * of the live ring, at most max_frames, becomes a pixel column of the image, device to device. */
+SGX_API int sgx_live_tick_image(sgx_live *live, sgx_image *image, size_t max_frames, size_t *n_frames);
+/* d_out [height][width][4]: the buffer as it lies (scrolled = 0), or the composed picture -- columns [offset, width) followed by
+ * [0, offset) (:181-209; scrolled != 0). */
+SGX_API int sgx_image_read(sgx_image *image, int scrolled, uint8_t *d_out);
+/* the device buffer itself ([height][width][4], valid until sgx_image_destroy; ordered on the context's stream) */
+SGX_API const uint8_t *sgx_image_pixels(const sgx_image *image);
 
 /* ---- synthetic input + verification helpers (bench / multi-GPU harness, not reference API) -- */
 

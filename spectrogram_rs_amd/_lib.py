@@ -21,11 +21,8 @@ SGX_ERR_NO_DEVICE = -5
 INTERP_CUBIC, INTERP_COSINE = 0, 1
 LUT_FLOOR_N, LUT_ROUND_NM1 = 0, 1
 FLAG_FORCE_GENERIC = 1
-FLAG_WAVE_KERNEL = 2
 FLAG_NO_FUSED_RENDER = 4
-FLAG_PACKED_KERNEL = 8
 FLAG_INDEPENDENT_FRAMES = 16
-FLAG_LEGACY_16K = 32
 FLAG_LUT_WALK = 64
 FLAG_RESIDUE_16K = 128
 FLAG_MIXED_GENERIC = 256
@@ -123,6 +120,13 @@ SIGNATURES = [
     ("sgx_view_offset", C.c_uint32, [C.c_void_p]),
     ("sgx_live_tick_view", C.c_int, [C.c_void_p, C.c_void_p, _sz, C.POINTER(_sz)]),
     ("sgx_view_draw", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, _vp]),
+    ("sgx_image_create", C.c_int, [_ctx, C.c_uint32, C.POINTER(C.c_void_p)]),
+    ("sgx_image_destroy", None, [C.c_void_p]),
+    ("sgx_image_write_columns", C.c_int, [C.c_void_p, _vp, _sz, C.POINTER(C.c_uint32)]),
+    ("sgx_image_offset", C.c_uint32, [C.c_void_p]),
+    ("sgx_live_tick_image", C.c_int, [C.c_void_p, C.c_void_p, _sz, C.POINTER(_sz)]),
+    ("sgx_image_read", C.c_int, [C.c_void_p, C.c_int, _vp]),
+    ("sgx_image_pixels", C.c_void_p, [C.c_void_p]),
     ("sgx_checksum", C.c_int, [_ctx, _vp, _sz, C.c_uint64, C.POINTER(C.c_uint64)]),
     ("sgx_checksum_add", C.c_int, [_ctx, _vp, _sz, C.c_uint64, _vp]),
 ]

@@ -16,11 +16,7 @@ namespace {
 
 thread_local std::string g_create_error;
 
-#ifdef SGX_WITH_VARIANTS
-const char *kVersion = "sgx 0.3 (hip gfx950) +variants";
-#else
-const char *kVersion = "sgx 0.3 (hip gfx950)";
-#endif
+const char *kVersion = "sgx 0.4 (hip gfx950)";
 
 int fail(sgx_ctx *c, int code, const std::string &msg)
 {
@@ -240,16 +236,12 @@ hipError_t run_stft(const sgx_ctx *c, const float *d_pcm, uint32_t channels, uin
     if (c->stft_kernel == 8)   // (a mono stream whose frames are not paired: as an (s, s) plane through the two-channel kernel; the 8192-point
                                // plan of the mixed-radix kernel's real-input mode measured no faster: 31.4 against 32.6 M frames/s, round 4)
         return sgx::launch_stft_d16384(c, c->d_d16k, d_pcm, channels, pairs, first, n, total, d_mags);
-    if (c->stft_kernel == 7 && (channels != 1 || !(c->cfg.flags & SGX_FLAG_INDEPENDENT_FRAMES)))
-        return sgx::launch_stft_wg16384(c, c->d_fast_16k, d_pcm, channels, pairs, first, n, total, d_mags);
     // (a mono stream, every frame its own transform: real-input mode of the mixed-radix kernel, 2400 points instead of 4800 on (s, s))
     if (c->stft_kernel == 9 && channels <= 2 && !sgx::mixed_real_serves(c, c->d_mix, channels)) return sgx::launch_stft_w4800(c, c->d_w4800, d_pcm, channels, first, n, total, d_mags, false);
     if (c->stft_kernel == 6 || c->stft_kernel == 9) return sgx::launch_stft_mixed(c, c->d_mix, d_pcm, channels, pairs, first, n, total, d_mags);
     if (c->stft_kernel == 4 && c->d_chz) return sgx::launch_stft_chirpz(c, c->d_chz, d_pcm, channels, pairs, first, n, total, d_mags);
     if (c->stft_kernel == 4) return sgx::launch_stft_bluestein(c, c->d_blu, d_pcm, channels, pairs, first, n, total, d_mags);
-    if (c->stft_kernel == 3) return sgx::launch_stft_wgp4096(c, c->d_fast_wg, d_pcm, channels, pairs, first, n, total, d_mags);
     if (c->stft_kernel == 2) return sgx::launch_stft_wg4096(c, c->d_fast_wg, d_pcm, channels, pairs, first, n, total, d_mags);
-    if (c->stft_kernel == 1) return sgx::launch_stft_fast4096(c, d_pcm, channels, pairs, first, n, total, d_mags);
     return sgx::launch_stft_generic(c, d_pcm, channels, pairs, first, n, total, d_mags);
 }
 
@@ -368,11 +360,9 @@ int sgx_create(const sgx_config *cfg, sgx_ctx **out_ctx)
     if (rc != SGX_OK) { std::string m = c->err; return bail(rc, m); }
 
     c->stft_kernel = 0;
-#ifndef SGX_WITH_VARIANTS
-    if (cfg->flags & (SGX_FLAG_WAVE_KERNEL | SGX_FLAG_PACKED_KERNEL | SGX_FLAG_LEGACY_16K))
-        return bail(SGX_ERR_UNSUPPORTED, "sgx_create: SGX_FLAG_WAVE_KERNEL / SGX_FLAG_PACKED_KERNEL / SGX_FLAG_LEGACY_16K select superseded A/B kernels "
-                                         "that this build leaves out (make -C spectrogram_rs_amd/csrc VARIANTS=1)");
-#endif
+    if (cfg->flags & (2u | 8u | 32u))   // the flag bits of the A/B kernels of rounds 1-3 (wave-per-transform, packed arithmetic, first 16384-point design)
+        return bail(SGX_ERR_UNSUPPORTED, "sgx_create: flag bits 2, 8 and 32 selected superseded A/B kernels that were removed in round 5 "
+                                         "(their measurements: profiles/r01_*, r02_*, r03_k16_ablation.txt)");
     // powers of two from W = 512 on that have no tuned kernel ride the composite-radix stages too (compile-time plans 4 x 16 x 16,
     // 8 x 16 x 16, 4 x 8 x 16 x 16): same-device A/B against the radix-4 ladder of the generic kernel, mono / stereo:
     // W 512 +29 % / +44 %, W 1024 +48 % / +90 %, W 4096 +83 % / +117 %; W 256: -14 %, W 128: -53 % (run-time geometry)
@@ -396,19 +386,13 @@ int sgx_create(const sgx_config *cfg, sgx_ctx **out_ctx)
         }
         c->stft_kernel = 4;
     } else if (!(cfg->flags & SGX_FLAG_FORCE_GENERIC) && sgx::fast4096_supported(c)) {
-        e = sgx::fast4096_init(c);
-        if (e != hipSuccess) return bail(SGX_ERR_HIP, std::string("sgx_create: tuned kernel tables: ") + hipGetErrorString(e));
         e = sgx::wg4096_init(c, &c->d_fast_wg);
         if (e != hipSuccess) return bail(SGX_ERR_HIP, std::string("sgx_create: tuned kernel tables: ") + hipGetErrorString(e));
         if (c->C == 1) {
             e = sgx::real4096_init(c, &c->d_real);
             if (e != hipSuccess) return bail(SGX_ERR_HIP, std::string("sgx_create: real-input kernel tables: ") + hipGetErrorString(e));
         }
-        c->stft_kernel = (cfg->flags & SGX_FLAG_WAVE_KERNEL) ? 1 : ((cfg->flags & SGX_FLAG_PACKED_KERNEL) ? 3 : 2);
-    } else if (!(cfg->flags & SGX_FLAG_FORCE_GENERIC) && (cfg->flags & SGX_FLAG_LEGACY_16K) && sgx::wg16384_supported(c)) {
-        e = sgx::wg16384_init(c, &c->d_fast_16k);
-        if (e != hipSuccess) return bail(SGX_ERR_HIP, std::string("sgx_create: 16384-point kernel tables: ") + hipGetErrorString(e));
-        c->stft_kernel = 7;
+        c->stft_kernel = 2;
     } else if (!(cfg->flags & (SGX_FLAG_FORCE_GENERIC | SGX_FLAG_RESIDUE_16K)) && sgx::d16384_supported(c)) {
         e = sgx::d16384_init(c, &c->d_d16k);
         if (e != hipSuccess) return bail(SGX_ERR_HIP, std::string("sgx_create: 16384-point kernel tables: ") + hipGetErrorString(e));
@@ -427,8 +411,8 @@ void sgx_destroy(sgx_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    sgx::detach_views(c);   // views that outlive their context keep their own buffers and answer SGX_ERR_INVALID_ARG from now on
-    sgx::fast4096_destroy(c);
+    sgx::detach_views(c);
+    sgx::detach_images(c);   // views that outlive their context keep their own buffers and answer SGX_ERR_INVALID_ARG from now on
     sgx::wg4096_destroy(c->d_fast_wg);
     c->d_fast_wg = nullptr;
     sgx::real4096_destroy(c->d_real);
@@ -440,8 +424,6 @@ void sgx_destroy(sgx_ctx *c)
     c->d_mix = nullptr;
     sgx::chirpz_destroy(c->d_chz);
     c->d_chz = nullptr;
-    sgx::wg16384_destroy(c->d_fast_16k);
-    c->d_fast_16k = nullptr;
     sgx::q16384_destroy(c->d_q16k);
     c->d_q16k = nullptr;
     sgx::d16384_destroy(c->d_d16k);
@@ -471,7 +453,7 @@ int sgx_query(const sgx_ctx *c, sgx_info *out)
     out->total_samples_per_column = (uint32_t)c->tab.samples.size();
     out->stft_kernel = (uint32_t)c->stft_kernel;
     out->render_path = 0;
-    if ((c->stft_kernel == 2 || c->stft_kernel == 3) && !(c->cfg.flags & SGX_FLAG_NO_FUSED_RENDER) && sgx::wg4096_can_fuse_render(c, c->d_fast_wg))
+    if (c->stft_kernel == 2 && !(c->cfg.flags & SGX_FLAG_NO_FUSED_RENDER) && sgx::wg4096_can_fuse_render(c, c->d_fast_wg))
         out->render_path = 1u | (sgx::wg4096_seed_is_within_one(c) ? 2u : 0u);
     if ((c->stft_kernel == 6 || c->stft_kernel == 9) && sgx::mixed_fixed_plan(c->d_mix)) out->render_path |= 4u;
     if (c->stft_kernel == 2 && c->d_real && !(c->cfg.flags & SGX_FLAG_COMPLEX_MONO) && (c->cfg.flags & SGX_FLAG_INDEPENDENT_FRAMES)) out->render_path |= 8u;
@@ -599,11 +581,9 @@ int sgx_render_batch(sgx_ctx *c, const float *d_pcm, size_t n_samples, size_t fi
     if (n > max_frames) n = max_frames;
     if (!d_pcm || !d_rgba) return fail(c, SGX_ERR_INVALID_ARG, "sgx_render_batch: null buffer");
     SGX_HIP(c, hipSetDevice(c->device));
-    if ((c->stft_kernel == 2 || c->stft_kernel == 3) && !(c->cfg.flags & SGX_FLAG_NO_FUSED_RENDER) && sgx::wg4096_can_fuse_render(c, c->d_fast_wg)) {
+    if (c->stft_kernel == 2 && !(c->cfg.flags & SGX_FLAG_NO_FUSED_RENDER) && sgx::wg4096_can_fuse_render(c, c->d_fast_wg)) {
         // one kernel from PCM to pixels: magnitudes never leave LDS (5 120 B of HBM traffic per frame)
-        hipError_t e = c->stft_kernel == 3
-                           ? sgx::launch_render_wgp4096(c, c->d_fast_wg, d_pcm, c->C, c->pairs, first_frame, n, total, d_rgba)
-                           : sgx::launch_render_wg4096(c, c->d_fast_wg, d_pcm, c->C, c->pairs, first_frame, n, total, d_rgba);
+        hipError_t e = sgx::launch_render_wg4096(c, c->d_fast_wg, d_pcm, c->C, c->pairs, first_frame, n, total, d_rgba);
         if (e != hipSuccess) return fail_hip(c, e, "sgx_render_batch: fused launch");
         if (n_out) *n_out = n;
         return SGX_OK;

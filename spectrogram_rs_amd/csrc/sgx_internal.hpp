@@ -106,7 +106,6 @@ struct sgx_ctx {
     void *d_w4800 = nullptr;       // tables of the tuned 4800-point kernel (W = 2400: the application's window at 48 kHz)
     void *d_real = nullptr;        // tables of the real-input 4096-point kernel (independent mono frames at W 2048 / H 256)
     void *d_chz = nullptr;         // chirp-z through the mixed-radix kernel's stages (or null: the radix-4 ladder of stft_bluestein.hip)
-    void *d_fast_16k = nullptr;    // tables of the 16384-point kernel, first design (one 1024-thread workgroup per transform)
     void *d_q16k = nullptr;        // tables of the 16384-point kernel, four 4096-point residues of the output (SGX_FLAG_RESIDUE_16K)
     void *d_d16k = nullptr;        // tables of the 16384-point kernel, four time-decimated 4096-point transforms per lane quad (the default)
 
@@ -131,6 +130,7 @@ struct sgx_ctx {
     mutable std::vector<std::pair<std::array<size_t, 3>, int>> occupancy_cache;
     // objects that hold a pointer into this context (sgx_view): sgx_destroy detaches them, their calls then fail cleanly
     std::vector<struct sgx_view *> views;
+    std::vector<struct sgx_image *> images;   // sgx_image.hip: the image rings created on this context
 
     std::string err;
 };
@@ -141,16 +141,6 @@ inline bool fast4096_supported(const sgx_ctx *c) { return c->W == 2048; }   // t
 // kernel launchers (each returns hipSuccess or the launch error)
 hipError_t launch_stft_generic(const sgx_ctx *c, const float *d_pcm, uint32_t channels, uint32_t pairs, size_t first_frame,
                                size_t n_frames, size_t total_frames, float *d_mags);
-#ifdef SGX_WITH_VARIANTS   // make VARIANTS=1: the superseded A/B kernels (stft4096.hip, stft4096_wgp.hip, stft16384_wg.hip)
-hipError_t fast4096_init(sgx_ctx *c);
-void fast4096_destroy(sgx_ctx *c);
-hipError_t launch_stft_fast4096(const sgx_ctx *c, const float *d_pcm, uint32_t channels, uint32_t pairs, size_t first_frame,
-                                size_t n_frames, size_t total_frames, float *d_mags);
-#else
-inline hipError_t fast4096_init(sgx_ctx *) { return hipSuccess; }
-inline void fast4096_destroy(sgx_ctx *) {}
-inline hipError_t launch_stft_fast4096(const sgx_ctx *, const float *, uint32_t, uint32_t, size_t, size_t, size_t, float *) { return hipErrorNotSupported; }
-#endif
 hipError_t wg4096_init(sgx_ctx *c, void **out);
 void wg4096_destroy(void *tables);
 hipError_t launch_stft_wg4096(const sgx_ctx *c, const void *tables, const float *d_pcm, uint32_t channels, uint32_t pairs,
@@ -163,24 +153,6 @@ void lut_seed_coefficients(const sgx_ctx *c, float &a, float &b);
 namespace wg { bool seed_within_one(const std::vector<float> &thr, double guess_a, double guess_b); }   // stft4096_wg.hip: is floor(log2(p + 1e-7) a + b) within one of the threshold count for every power?   // LUT level ~ floor(log2(power + 1e-7) a + b): the seed of the threshold count
 hipError_t launch_render_wg4096(const sgx_ctx *c, const void *tables, const float *d_pcm, uint32_t channels, uint32_t pairs,
                                 size_t first_frame, size_t n_frames, size_t total_frames, uint8_t *d_rgba);
-#ifdef SGX_WITH_VARIANTS
-hipError_t launch_stft_wgp4096(const sgx_ctx *c, const void *tables, const float *d_pcm, uint32_t channels, uint32_t pairs,
-                               size_t first_frame, size_t n_frames, size_t total_frames, float *d_mags);
-hipError_t launch_render_wgp4096(const sgx_ctx *c, const void *tables, const float *d_pcm, uint32_t channels, uint32_t pairs,
-                                 size_t first_frame, size_t n_frames, size_t total_frames, uint8_t *d_rgba);
-bool wg16384_supported(const sgx_ctx *c);
-hipError_t wg16384_init(sgx_ctx *c, void **out);
-void wg16384_destroy(void *tables);
-hipError_t launch_stft_wg16384(const sgx_ctx *c, const void *tables, const float *d_pcm, uint32_t channels, uint32_t pairs,
-                               size_t first_frame, size_t n_frames, size_t total_frames, float *d_mags);
-#else
-inline hipError_t launch_stft_wgp4096(const sgx_ctx *, const void *, const float *, uint32_t, uint32_t, size_t, size_t, size_t, float *) { return hipErrorNotSupported; }
-inline hipError_t launch_render_wgp4096(const sgx_ctx *, const void *, const float *, uint32_t, uint32_t, size_t, size_t, size_t, uint8_t *) { return hipErrorNotSupported; }
-inline bool wg16384_supported(const sgx_ctx *) { return false; }
-inline hipError_t wg16384_init(sgx_ctx *, void **) { return hipErrorNotSupported; }
-inline void wg16384_destroy(void *) {}
-inline hipError_t launch_stft_wg16384(const sgx_ctx *, const void *, const float *, uint32_t, uint32_t, size_t, size_t, size_t, float *) { return hipErrorNotSupported; }
-#endif
 bool d16384_supported(const sgx_ctx *c);
 hipError_t d16384_init(sgx_ctx *c, void **out);
 void d16384_destroy(void *tables);
@@ -231,6 +203,8 @@ hipError_t launch_render(const sgx_ctx *c, const float *d_mags, size_t n_columns
 hipError_t launch_magnitude_in(const sgx_ctx *c, const float *d_mags, size_t n_columns, const RowEntry *d_rows,
                                const SampleEntry *d_samples, uint32_t n_ranges, float *d_out);
 void detach_views(sgx_ctx *c);   // sgx_view.hip: every live view of the context forgets it
+void detach_images(sgx_ctx *c);   // sgx_image.hip
+sgx_ctx *image_context(const struct sgx_image *im);
 sgx_ctx *view_context(const struct sgx_view *v);   // sgx_view.hip: the context a view was created on (nullptr once that context is gone)
 hipError_t launch_white_noise(const sgx_ctx *c, float *d_out, uint64_t first, size_t n, uint32_t channels, uint32_t seed);
 hipError_t launch_checksum(const sgx_ctx *c, const uint32_t *d_words, size_t n_words, uint64_t base_word,

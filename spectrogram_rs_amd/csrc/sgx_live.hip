@@ -129,11 +129,11 @@ size_t sgx_live_occupied(const sgx_live *l)
     return (size_t)(head - tail);
 }
 
-static int live_tick(sgx_live *l, int what, void *h_out, sgx_view *view, size_t max_frames, size_t *n_frames);
+static int live_tick(sgx_live *l, int what, void *h_out, sgx_view *view, sgx_image *image, size_t max_frames, size_t *n_frames);
 
 int sgx_live_tick(sgx_live *l, int what, void *h_out, size_t max_frames, size_t *n_frames)
 {
-    return live_tick(l, what, h_out, nullptr, max_frames, n_frames);
+    return live_tick(l, what, h_out, nullptr, nullptr, max_frames, n_frames);
 }
 
 // GPUSpectrogram::render (gpu_spectrogram.rs:255-275): this tick's frames go from the transform straight into the widget's ring
@@ -141,10 +141,16 @@ int sgx_live_tick(sgx_live *l, int what, void *h_out, size_t max_frames, size_t 
 int sgx_live_tick_view(sgx_live *l, sgx_view *view, size_t max_frames, size_t *n_frames)
 {
     if (!view) { if (n_frames) *n_frames = 0; return SGX_ERR_INVALID_ARG; }
-    return live_tick(l, SGX_LIVE_MAGS_F16, nullptr, view, max_frames, n_frames);
+    return live_tick(l, SGX_LIVE_MAGS_F16, nullptr, view, nullptr, max_frames, n_frames);
 }
 
-static int live_tick(sgx_live *l, int what, void *h_out, sgx_view *view, size_t max_frames, size_t *n_frames)
+int sgx_live_tick_image(sgx_live *l, sgx_image *image, size_t max_frames, size_t *n_frames)
+{
+    if (!image) { if (n_frames) *n_frames = 0; return SGX_ERR_INVALID_ARG; }
+    return live_tick(l, SGX_LIVE_RGBA, nullptr, nullptr, image, max_frames, n_frames);
+}
+
+static int live_tick(sgx_live *l, int what, void *h_out, sgx_view *view, sgx_image *image, size_t max_frames, size_t *n_frames)
 {
     if (n_frames) *n_frames = 0;
     if (!l) return SGX_ERR_INVALID_ARG;
@@ -152,6 +158,8 @@ static int live_tick(sgx_live *l, int what, void *h_out, sgx_view *view, size_t 
     // a view of another context has another row length (its M), another stream and possibly another device: refused before any work
     if (view && sgx::view_context(view) != c)
         return live_fail(l, SGX_ERR_INVALID_ARG, "sgx_live_tick_view: the view belongs to another (or a destroyed) context");
+    if (image && sgx::image_context(image) != c)
+        return live_fail(l, SGX_ERR_INVALID_ARG, "sgx_live_tick_image: the image belongs to another (or a destroyed) context");
     size_t frame_bytes;
     switch (what) {
     case SGX_LIVE_MAGS: frame_bytes = (size_t)c->M * 2 * sizeof(float); break;
@@ -181,7 +189,7 @@ static int live_tick(sgx_live *l, int what, void *h_out, sgx_view *view, size_t 
     const bool truncated = frames > max_frames;
     if (truncated) frames = max_frames;
     if (frames) {
-        if (!h_out && !view) return live_fail(l, SGX_ERR_INVALID_ARG, "sgx_live_tick: null output buffer");
+        if (!h_out && !view && !image) return live_fail(l, SGX_ERR_INVALID_ARG, "sgx_live_tick: null output buffer");
         const size_t need = frames * frame_bytes;
         if (need > l->out_bytes) {
             LIVE_HIP(l, hipStreamSynchronize(c->stream));
@@ -200,6 +208,9 @@ static int live_tick(sgx_live *l, int what, void *h_out, sgx_view *view, size_t 
         if (got != frames) return live_fail(l, SGX_ERR_INVALID_ARG, "sgx_live_tick: frame count mismatch");
         if (view) {
             rc = sgx_view_write_rows(view, l->d_out, frames, nullptr);
+            if (rc != SGX_OK) return rc;
+        } else if (image) {
+            rc = sgx_image_write_columns(image, static_cast<const uint8_t *>(l->d_out), frames, nullptr);
             if (rc != SGX_OK) return rc;
         } else {
             LIVE_HIP(l, hipMemcpyAsync(h_out, l->d_out, need, hipMemcpyDeviceToHost, c->stream));

@@ -20,8 +20,7 @@ class SpectrogramEngine:
                  f_min: float = 32.0, f_max: float = 22030.0, min_db: float = -70.0, max_db: float = -10.0,
                  interp: int = _lib.INTERP_CUBIC, lut_index_mode: int = _lib.LUT_FLOOR_N,
                  device: Optional[int] = None, force_generic: bool = False, gradient: Optional[str] = None,
-                 wave_kernel: bool = False, fused_render: bool = True, packed_kernel: bool = False,
-                 independent_frames: bool = False, legacy_16k: bool = False, lut_walk: bool = False, residue_16k: bool = False,
+                 fused_render: bool = True, independent_frames: bool = False, lut_walk: bool = False, residue_16k: bool = False,
                  mixed_generic: bool = False, complex_mono: bool = False, paired_frames: bool = False):
         import torch
 
@@ -41,9 +40,8 @@ class SpectrogramEngine:
         cfg.min_db, cfg.max_db = min_db, max_db
         cfg.interp, cfg.lut_index_mode = interp, lut_index_mode
         cfg.device = -1 if device is None else int(device)
-        cfg.flags = (_lib.FLAG_FORCE_GENERIC if force_generic else 0) | (_lib.FLAG_WAVE_KERNEL if wave_kernel else 0) \
-            | (0 if fused_render else _lib.FLAG_NO_FUSED_RENDER) | (_lib.FLAG_PACKED_KERNEL if packed_kernel else 0) \
-            | (_lib.FLAG_INDEPENDENT_FRAMES if independent_frames else 0) | (_lib.FLAG_LEGACY_16K if legacy_16k else 0) \
+        cfg.flags = (_lib.FLAG_FORCE_GENERIC if force_generic else 0) | (0 if fused_render else _lib.FLAG_NO_FUSED_RENDER) \
+            | (_lib.FLAG_INDEPENDENT_FRAMES if independent_frames else 0) \
             | (_lib.FLAG_LUT_WALK if lut_walk else 0) | (_lib.FLAG_RESIDUE_16K if residue_16k else 0) | (_lib.FLAG_MIXED_GENERIC if mixed_generic else 0) \
             | (_lib.FLAG_COMPLEX_MONO if complex_mono else 0) | (_lib.FLAG_PAIRED_FRAMES if paired_frames else 0)
         if device is not None and torch.cuda.is_available():
@@ -242,6 +240,10 @@ class SpectrogramEngine:
         self._rings = [r for r in self._rings if r() is not None] + [weakref.ref(ring)]
         return ring
 
+    def image(self, width: int = 1024) -> "ImageRing":
+        """the row-major width x rows RGBA image ring of SimpleSpectrogram (simple_spectrogram.rs:89-94) on the device"""
+        return ImageRing(self, width)
+
     def view(self, viewport_frames: int = 2048) -> "ViewRing":
         """GPUSpectrogram's F16F16 ring texture + fragment program on the device (include/sgx.h: sgx_view)."""
         import weakref
@@ -379,6 +381,17 @@ class LiveRing:
         e._check(self._lib.sgx_live_tick(self._h, code, out.ctypes.data_as(C.c_void_p), max_frames, C.byref(got)))
         return out[:got.value]
 
+    def tick_image(self, image: "ImageRing", max_frames: Optional[int] = None) -> int:
+        """one GUI tick of SimpleSpectrogram (simple_spectrogram.rs:136-165): every complete frame becomes a pixel column of the image,
+        device to device; returns the number of columns written"""
+        e = self.engine
+        if max_frames is None:
+            max_frames = e.num_frames(self.capacity)
+        e.use_current_stream()
+        got = C.c_size_t(0)
+        e._check(self._lib.sgx_live_tick_image(self._h, image._h, max_frames, C.byref(got)))
+        return int(got.value)
+
     def tick_into(self, view: "ViewRing", max_frames: Optional[int] = None) -> int:
         """One GUI tick of the default widget (gpu_spectrogram.rs:255-275): every complete frame of the ring goes, as a half-pair
         row, straight into `view`'s ring texture -- device to device, no host copy.  Returns the number of rows appended."""
@@ -388,6 +401,55 @@ class LiveRing:
         got = C.c_size_t(0)
         e._check(self._lib.sgx_live_tick_view(self._h, view._h, max_frames, C.byref(got)))
         return int(got.value)
+
+
+class ImageRing:
+    """sgx_image: the width x rows RGBA Pixbuf of simple_spectrogram.rs:89-94 on the device, written one pixel column per frame at
+    `offset` (:140-164) and read back as it lies or as the scrolling picture of :181-209."""
+
+    def __init__(self, engine: SpectrogramEngine, width: int = 1024):
+        self.engine = engine
+        self.width, self.height = int(width), engine.R
+        self._lib = engine._lib
+        self._h = C.c_void_p()
+        engine._check(self._lib.sgx_image_create(engine._ctx, self.width, C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.sgx_image_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def offset(self) -> int:
+        return int(self._lib.sgx_image_offset(self._h))
+
+    def write_columns(self, rgba) -> int:
+        """append [n][rows][4] uint8 pixel columns (a device tensor, e.g. render_batch(...)[:, 0]); returns the new offset"""
+        import torch
+
+        e = self.engine
+        assert rgba.is_cuda and rgba.device == e.device and rgba.dtype == torch.uint8 and rgba.is_contiguous()
+        n = rgba.numel() // (e.R * 4)
+        assert rgba.numel() == n * e.R * 4
+        e.use_current_stream()
+        off = C.c_uint32(0)
+        e._check(self._lib.sgx_image_write_columns(self._h, C.c_void_p(rgba.data_ptr()), n, C.byref(off)))
+        return int(off.value)
+
+    def read(self, scrolled: bool = False, out=None):
+        """[rows][width][4] uint8: the buffer as it lies, or (scrolled) columns [offset, width) followed by [0, offset)"""
+        import torch
+
+        e = self.engine
+        out = e._out(out, (self.height, self.width, 4), torch.uint8)
+        e._check(self._lib.sgx_image_read(self._h, 1 if scrolled else 0, C.c_void_p(out.data_ptr())))
+        return out
 
 
 class ViewRing:

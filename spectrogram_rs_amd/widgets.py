@@ -34,13 +34,12 @@ class SimpleSpectrogram:
         self.input_stream = sample_stream
         self.width, self.height = width, height
         self.palette = ColorScheme.new_mono("magma", "magma")  # :95
-        self.offset = 0
+        self.image = None   # the Pixbuf of :89-94 as a device-resident ring (engine.image: sgx_image_*)
         self._period, self._window_samples, self._device, self._interp = period, window_samples, device, interp
         self.stride = 2.0 / width  # :102
         self.engine: Optional[SpectrogramEngine] = None
         self.live = None
         self.set_sample_rate(sample_rate)
-        self.buffer = torch.zeros((height, width, 4), dtype=torch.uint8, device=self.engine.device)
 
     def set_sample_rate(self, sample_rate: int) -> None:
         """:214-219 -- replaces the transform wholesale"""
@@ -51,12 +50,25 @@ class SimpleSpectrogram:
         if self.live is not None:
             self.live.close()
             self.live = None
+        kept = None   # the reference's Pixbuf outlives the transform (:214-219 replace `fft` only): carry the picture over
+        if self.image is not None:
+            kept = (self.image.read().permute(1, 0, 2).contiguous(), self.image.offset)
+            self.image.close()
+            self.image = None
         if self.engine is not None:
             self.engine.close()
         kw = dict(window_samples=self._window_samples) if self._window_samples else dict(period=self._period)
         self.engine = SpectrogramEngine(float(sr), hop_samples=max(hop, 1), channels=2, rows=self.height,
                                         interp=self._interp, device=self._device, **kw)
         self.palette.apply(self.engine)
+        self.image = self.engine.image(self.width)
+        if kept is not None:
+            import torch
+
+            cols, k = kept                      # columns in x order; k dummy columns first, so that the ring ends at offset k again
+            cols = cols.to(self.engine.device)
+            self.image.write_columns(cols[:k].contiguous())
+            self.image.write_columns(torch.cat([cols[k:], cols[:k]]).contiguous())
         # the reference's ring outlives the transform; the device-resident one is rebuilt with it (samples in
         # flight at a sample-rate change are dropped)
         self.live = self.engine.live(max(4096, 2 * self.engine.W), reference_skip=True) if self.input_stream is None else None
@@ -75,33 +87,30 @@ class SimpleSpectrogram:
 
         eng = self.engine
         if self.live is not None:
-            cols = torch.from_numpy(self.live.tick("rgba")).to(eng.device)  # [frames][R][4]
-            frames = cols.shape[0]
-            if frames:
-                px = (self.offset + torch.arange(frames, device=eng.device)) % self.width
-                keep = slice(max(frames - self.width, 0), frames)
-                self.buffer[:, px[keep], :] = cols[keep].permute(1, 0, 2)
-                self.offset = (self.offset + frames) % self.width
-            return frames
+            return self.live.tick_image(self.image)     # device to device: only the new samples cross the bus
         n = len(self.input_stream)
         frames = eng.num_frames(n)
         if frames:
             lr = self.input_stream.iter()[:(frames - 1) * eng.H + eng.W]
             pcm = torch.from_numpy(np.ascontiguousarray(lr)).to(eng.device).reshape(-1)
-            cols = eng.render_batch(pcm)[:, 0]                      # [frames][R][4], image-row order
-            px = (self.offset + torch.arange(frames, device=eng.device)) % self.width
-            keep = slice(max(frames - self.width, 0), frames)       # later columns overwrite earlier ones
-            self.buffer[:, px[keep], :] = cols[keep].permute(1, 0, 2)
-            self.offset = (self.offset + frames) % self.width       # :164
+            cols = eng.render_batch(pcm)[:, 0].contiguous()        # [frames][R][4], image-row order
+            self.image.write_columns(cols)                          # put_pixel column by column + offset = (px + 1) % width (:150-164)
         self.input_stream.skip((frames + 1) * eng.H)                # audio_transform.rs:37-41
         return frames
 
     def scrolled(self):
         """The image the two append_scaled_texture calls compose (:181-209): columns
         [offset, width) followed by [0, offset)."""
-        import torch
+        return self.image.read(scrolled=True)
 
-        return torch.cat([self.buffer[:, self.offset:], self.buffer[:, :self.offset]], dim=1)
+    @property
+    def offset(self) -> int:
+        return self.image.offset
+
+    @property
+    def buffer(self):
+        """[height][width][4] uint8: the Pixbuf as it lies"""
+        return self.image.read()
 
 
 VIEWPORT_FRAMES = 2048                                                        # gpu_spectrogram.rs:20

@@ -40,31 +40,18 @@ def to_dev(torch, a):
     return torch.from_numpy(np.ascontiguousarray(a, np.float32)).cuda().reshape(-1)
 
 
-def has_variants():
-    """make VARIANTS=1 builds the superseded A/B kernels too (wave-per-transform, packed, first 16384-point design)"""
-    from spectrogram_rs_amd import _lib
-    return b"+variants" in _lib.load().sgx_version()
-
-
 # ---- the transform -----------------------------------------------------------------------------
 
-@pytest.mark.parametrize("variant", ["default", "paired", "complex", "packed", "wave", "generic", "generic_paired", "packed_paired", "wave_paired"])
+@pytest.mark.parametrize("variant", ["default", "paired", "complex", "generic", "generic_paired"])
 @pytest.mark.parametrize("channels", [1, 2])
 def test_stft_batch_matches_oracle(torch_cuda, mags_err, variant, channels):
     # every kernel that can serve W = 2048: workgroup-per-transform (default; a mono stream: the real-input kernel, "paired": two
-    # frames per transform, "complex": every frame its (s, s) transform), its packed-arithmetic twin, the wave-per-transform
-    # kernel, and the generic power-of-two kernel
+    # frames per transform, "complex": every frame its (s, s) transform) and the generic power-of-two kernel
     torch = torch_cuda
-    kw = {"default": {}, "paired": {"paired_frames": True}, "complex": {"complex_mono": True}, "packed": {"packed_kernel": True},
-          "wave": {"wave_kernel": True}, "generic": {"force_generic": True}, "generic_paired": {"force_generic": True, "paired_frames": True},
-          "packed_paired": {"packed_kernel": True, "paired_frames": True}, "wave_paired": {"wave_kernel": True, "paired_frames": True}}[variant]
-    if variant.split("_")[0] in ("packed", "wave") and not has_variants():
-        from spectrogram_rs_amd import SgxError
-        with pytest.raises(SgxError, match="VARIANTS=1"):   # the default build leaves the superseded kernels out and says so
-            engine(window_samples=W, hop_samples=H, channels=channels, **kw)
-        pytest.skip("superseded A/B kernel: not in the default build (make VARIANTS=1)")
+    kw = {"default": {}, "paired": {"paired_frames": True}, "complex": {"complex_mono": True}, "generic": {"force_generic": True},
+          "generic_paired": {"force_generic": True, "paired_frames": True}}[variant]
     eng = engine(window_samples=W, hop_samples=H, channels=channels, **kw)
-    assert eng.info.stft_kernel == {"default": 2, "paired": 2, "complex": 2, "packed": 3, "wave": 1, "generic": 0}[variant.split("_")[0]]
+    assert eng.info.stft_kernel == {"default": 2, "paired": 2, "complex": 2, "generic": 0}[variant.split("_")[0]]
     assert bool(eng.info.render_path & 8) == (variant == "default" and channels == 1)
     n = W + H * 130 + 77
     pcm = oracle.white_noise(n * channels, seed=11 + channels)
@@ -281,7 +268,7 @@ def test_short_ragged_and_empty_inputs(torch_cuda):
     assert np.array_equal(part, full[3:5])
     assert eng.stft_batch(to_dev(torch, pcm), first_frame=99).shape[0] == 0
     # mono: two frames share a transform, paired by GLOBAL index -- any sub-range gives the same bytes
-    for kw in (dict(), dict(paired_frames=True), dict(wave_kernel=True), dict(packed_kernel=True)) if has_variants() else (dict(), dict(paired_frames=True)):
+    for kw in (dict(), dict(paired_frames=True)):
         mono = engine(window_samples=W, hop_samples=H, channels=1, **kw)
         m = to_dev(torch, oracle.white_noise(W + 12 * H, seed=6))
         full = mono.stft_batch(m)

@@ -27,14 +27,13 @@ def main():
     ap.add_argument("--frames", type=int, default=200_000)
     ap.add_argument("--generic", action="store_true")
     ap.add_argument("--render", action="store_true")
-    ap.add_argument("--packed", action="store_true")
     ap.add_argument("--walk", action="store_true", help="fused pixel kernel: walk the LUT thresholds (the first version) instead of seed + one compare pair")
     ap.add_argument("--interp", type=int, default=0)
     args = ap.parse_args()
     F = args.frames
     for ch in (1, 2):
         eng = SpectrogramEngine(48000.0, window_samples=2048, hop_samples=256, channels=ch, force_generic=args.generic,
-                                gradient="viridis", packed_kernel=args.packed, lut_walk=args.walk, interp=args.interp)
+                                gradient="viridis", lut_walk=args.walk, interp=args.interp)
         n = (F - 1) * eng.H + eng.W
         pcm = eng.white_noise(n)
         out = torch.empty((F, 1, eng.M, 2), dtype=torch.float32, device="cuda")
@@ -54,9 +53,9 @@ if __name__ == "__main__" and not any(f in sys.argv for f in ("--extra", "--live
     main()
 
 
-def config4(frames=20000, legacy=False, channels=8, residue=False):
+def config4(frames=20000, channels=8, residue=False):
     """BASELINE config 4: 16384-point STFT, hop 512, 8 interleaved channels (4 pairs)"""
-    eng = SpectrogramEngine(48000.0, window_samples=8192, hop_samples=512, channels=channels, legacy_16k=legacy, residue_16k=residue)
+    eng = SpectrogramEngine(48000.0, window_samples=8192, hop_samples=512, channels=channels, residue_16k=residue)
     n = (frames - 1) * eng.H + eng.W
     pcm = eng.white_noise(n)
     out = torch.empty((frames, eng.pairs, eng.M, 2), dtype=torch.float32, device="cuda")
@@ -81,20 +80,13 @@ def app_default(frames=20000):
 
 if __name__ == "__main__" and "--config4" in sys.argv:
     for ch in ((2,) if "--stereo-only" in sys.argv else (8,) if "--ch8-only" in sys.argv else (8, 2, 1)):
-        if "--new-only" in sys.argv:
-            config4(legacy=False, channels=ch)
-            continue
         if "--quad-vs-residue" in sys.argv:
             a = config4(channels=ch, residue=True)
             b = config4(channels=ch, residue=False)
             print(f"  ch={ch}: max |residue - quad| = {(a - b).abs().max().item():.3e} (peak {a.abs().max().item():.3e})", flush=True)
             del a, b
             continue
-        a = config4(legacy=True, channels=ch)
-        b = config4(legacy=False, channels=ch)
-        d = (a - b).abs().max().item()
-        print(f"  ch={ch}: max |legacy - new| = {d:.3e} (peak {a.abs().max().item():.3e})", flush=True)
-        del a, b
+        config4(channels=ch)
 
 if __name__ == "__main__" and "--extra" in sys.argv:
     config4()
