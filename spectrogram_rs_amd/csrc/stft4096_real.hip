@@ -105,6 +105,14 @@ constexpr int kRowsF32 = 0, kRowsF16 = 1, kPixels = 2;   // what a launch writes
 // SLIDE: H = 256, the window slides in registers (above).  Else: any hop (a frame starts on any sample): the eight columns of the
 // next frame pair are requested where the sliding form requests its one, straight into R -- dead since pass 1 -- and every sample is
 // fetched 2048 / H times, through L2.
+#if SGX_STAMPS
+// diagnostic build only (tools/k1r_phases.py): per-phase wave cycles (s_memtime), summed over all waves and iterations
+__device__ unsigned long long g_phase_cycles_r[24];
+#define SGX_STAMP(i) { const unsigned long long now_ = __builtin_readcyclecounter(); st_acc[i] += now_ - st_last; st_last = now_; }
+#else
+#define SGX_STAMP(i)
+#endif
+
 template <int MODE, int PIX, bool SLIDE>
 __global__ void __launch_bounds__(256, 4) stft4096_real_kernel(Params p)
 {
@@ -203,7 +211,12 @@ __global__ void __launch_bounds__(256, 4) stft4096_real_kernel(Params p)
 
     char *out = reinterpret_cast<char *>(p.mags);
     constexpr int kBin = F16 ? 4 : 8;             // bytes per output bin
+#if SGX_STAMPS
+    unsigned long long st_acc[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_last = __builtin_readcyclecounter();
+#endif
     for (unsigned long long job = job_begin; job < job_end; ++job) {
+        SGX_STAMP(19)
         const unsigned long long fa = p.first_frame + 2 * job;             // frame A; B = fa + 1
         const unsigned long long la = 2 * job, lb = la + 1;                // their rows in the output
         const bool have_b = lb < p.n_frames;                                // (a B outside the range is computed and dropped)
@@ -223,7 +236,9 @@ __global__ void __launch_bounds__(256, 4) stft4096_real_kernel(Params p)
             for (int a = 0; a < 4; ++a) { zr[a] = R[2 * a + 1].x * win[2 * a]; zi[a] = R[2 * a + 1].y * win[2 * a + 1]; }
             fft8_half_zero(zr, zi, vr, vi);
         }
+        SGX_STAMP(0)    // Hann + pass 1 (two frames)
         lds_barrier();  // the previous iteration's partner reads are complete
+        SGX_STAMP(1)    // barrier 0
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const float2 ya = make_float2(yr[q], yi[q]), yb = make_float2(vr[q], vi[q]);
@@ -231,7 +246,9 @@ __global__ void __launch_bounds__(256, 4) stft4096_real_kernel(Params p)
             buf[(8 + q) * kS1 + tid] = q == 0 ? yb : cmulf(yb, tw1[q]);
         }
         __builtin_amdgcn_s_setprio(0);  // (wave priorities: stft4096_wg.hip)
+        SGX_STAMP(2)    // twiddles + image-1 writes
         lds_barrier();
+        SGX_STAMP(3)    // barrier 1
 
         // ---- pass 2: thread (g2 = 8 F + q1, t0): 16-point FFT over t1, then twiddle w_256^{t0 q2}
         float xr[16], xi[16];
@@ -241,14 +258,18 @@ __global__ void __launch_bounds__(256, 4) stft4096_real_kernel(Params p)
             xr[t1] = v.x; xi[t1] = v.y;
         }
         fft16(xr, xi);
+        SGX_STAMP(4)    // image-1 reads + FFT16
         lds_barrier();  // everyone has read image 1
+        SGX_STAMP(5)    // barrier 2
 #pragma unroll
         for (int q2 = 0; q2 < 16; ++q2) {
             const int pos = FFT16_OUT[q2];
             const float2 v = make_float2(xr[pos], xi[pos]);
             buf[t0_2 * kS2 + cbase2 + 8 * q2] = q2 == 0 ? v : cmulf(v, tw2[q2 * 16 + t0_2]);
         }
+        SGX_STAMP(6)    // pass-2 twiddles + image-2 writes
         lds_barrier();
+        SGX_STAMP(7)    // barrier 3
 
         // ---- pass 3: thread (F, u): 16-point FFT over t0 -> Z[u + 128 q3]
 #pragma unroll
@@ -268,7 +289,9 @@ __global__ void __launch_bounds__(256, 4) stft4096_real_kernel(Params p)
 
         if (MODE == kPixels) __builtin_amdgcn_s_setprio(1);   // the pixel passes are long: 3 only from the row pass (the pixel stores) on
         else __builtin_amdgcn_s_setprio(3);
+        SGX_STAMP(8)    // image-2 reads + FFT16 + next column requested
         lds_barrier();  // everyone has read image 2
+        SGX_STAMP(9)    // barrier 4
         // partner exchange: publish q3 = 8..15
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -280,7 +303,9 @@ __global__ void __launch_bounds__(256, 4) stft4096_real_kernel(Params p)
             xch[tid].x = tid < 128 ? L.x : R[7].x;
             xch[tid].y = tid < 128 ? L.y : R[7].y;
         }
+        SGX_STAMP(10)   // partner + window-exchange writes
         lds_barrier();
+        SGX_STAMP(11)   // barrier 5
         if (SLIDE) {
             const float2 Y = xch[(tid + 128) & 255];
             // ---- slide the window by two half rows, here: L is dead from now on (the Hann products of this iteration were taken at its top)
@@ -314,6 +339,7 @@ __global__ void __launch_bounds__(256, 4) stft4096_real_kernel(Params p)
             m2[q3] = __builtin_amdgcn_sqrtf(fmaf(br, br, bi * bi));   // |S[2048 - k]| 2 / W
         }
 
+        SGX_STAMP(12)   // window slide + partner reads + untangle + sqrt
         // ---- store row [M][2] (or half pairs): bin k at byte kBin (k - 1).  Straight-line code: the wait for the prefetched rows below
         // is then vmcnt(stores issued since).  Thread 0's q3 = 0 slot: bin 1024 from m1, and a second copy of it where its m2 would go.
         if (MODE != kPixels) {
@@ -342,6 +368,7 @@ __global__ void __launch_bounds__(256, 4) stft4096_real_kernel(Params p)
             float2 *vbuf = mpair + wg::kColSlots;          // [sample slot]
             float *mcol = reinterpret_cast<float *>(buf) + F;
             lds_barrier();  // partner and exchange reads done: the image can be overwritten
+            SGX_STAMP(13)   // (pixels) barrier 6
 #pragma unroll
             for (int q3 = 0; q3 < 8; ++q3) {
                 const bool self = q3 == 0 && u == 0;       // thread 0's bin-1024 slot: m1 twice
@@ -353,13 +380,17 @@ __global__ void __launch_bounds__(256, 4) stft4096_real_kernel(Params p)
                     mcol[2 * (kM + 1)] = mcol[2 * (kM + 2)] = m2[0];
                 }
             }
+            SGX_STAMP(14)   // (pixels) column writes
             lds_barrier();
+            SGX_STAMP(15)   // (pixels) barrier 7
             wg::sample_pass<PIX>(p, mpair, vbuf, tid);
             // the fused pixel path requests the next iteration's load HERE, straight into L (dead since the slide): requested in front
             // of the exchange like the rows' it is two more live registers through the sample pass -- two spills, and a spill reload
             // is a vector-memory load the compiler waits for with vmcnt(0), this load included (same device: 3.79 -> 3.68 ms)
             if (SLIDE) L = column(columns_from(128 * (fa + 2) + 1152), 0);
+            SGX_STAMP(16)   // (pixels) sample pass
             lds_barrier();
+            SGX_STAMP(17)   // (pixels) barrier 8
             uchar4 *rgba = reinterpret_cast<uchar4 *>(p.rgba);
             __builtin_amdgcn_s_setprio(3);
             wg::row_pass<true, PIX>(p, row_words, vbuf, rgba + la * (size_t)p.R, rgba + lb * (size_t)p.R, true, have_b, pal, tid);
@@ -371,7 +402,15 @@ __global__ void __launch_bounds__(256, 4) stft4096_real_kernel(Params p)
             asm volatile("" : "+v"(Ln.x), "+v"(Ln.y));
             L = Ln;
         }
+        SGX_STAMP(18)   // rows: 16 stores issued + wait for the next column; pixels: the row pass (sums, dB, LUT, pixel stores)
     }
+#if SGX_STAMPS
+    if ((tid & 63) == 0) {
+#pragma unroll
+        for (int i = 0; i < 20; ++i) atomicAdd(&g_phase_cycles_r[i], st_acc[i]);
+        atomicAdd(&g_phase_cycles_r[20], (unsigned long long)(job_end - job_begin));
+    }
+#endif
 }
 
 struct RealTables {
@@ -379,6 +418,18 @@ struct RealTables {
 };
 
 }  // namespace wgr
+
+#if SGX_STAMPS
+extern "C" __attribute__((visibility("default"))) int sgx_debug_phase_cycles_r(unsigned long long *h_out, int reset)
+{
+    hipError_t e = hipMemcpyFromSymbol(h_out, HIP_SYMBOL(wgr::g_phase_cycles_r), sizeof(unsigned long long) * 24);
+    if (e == hipSuccess && reset) {
+        unsigned long long zero[24] = {0};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(wgr::g_phase_cycles_r), zero, sizeof(zero));
+    }
+    return e == hipSuccess ? 0 : -1;
+}
+#endif
 
 hipError_t real4096_init(sgx_ctx *c, void **out)
 {

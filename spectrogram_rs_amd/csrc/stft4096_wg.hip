@@ -525,7 +525,7 @@ hipError_t wg4096_init(sgx_ctx *c, void **out)
     };
     for (size_t i = 0; i < rows.size(); ++i) {
         const auto &r = c->tab.rows[i];
-        if (r.count >= 65536 || samples.size() >= 65536) fusable = false;
+        if (r.count >= 256 || samples.size() >= 65536) fusable = false;   // (block_max_cnt holds a byte per block of 256 rows)
         rows[i] = ((uint32_t)samples.size() & 0xffffu) | ((r.count & 0xffffu) << 16);
         for (uint32_t j = 0; j < r.count; ++j) samples.push_back(packed(c->tab.samples[r.first + j]));
         if (r.count >= 4 && (r.count & 1u) == 0) samples.push_back(samples.back());   // the pad slot
@@ -539,6 +539,9 @@ hipError_t wg4096_init(sgx_ctx *c, void **out)
         bool single = true;
         for (size_t i = 256 * blk; i < 256 * (blk + 1) && i < rows.size(); ++i) single = single && c->tab.rows[i].count == 1;
         if (single && 256 * blk < rows.size()) t->single_rows |= 1u << blk;
+        uint32_t mx = 0;
+        for (size_t i = 256 * blk; i < 256 * (blk + 1) && i < rows.size(); ++i) mx = mx > c->tab.rows[i].count ? mx : c->tab.rows[i].count;
+        t->block_max_cnt |= (mx > 255 ? 255u : mx) << (8 * blk);     // (a row of 256 samples or more: not fusable, below)
     }
 
     auto up = [](auto **dst, const auto &v) {
@@ -657,6 +660,7 @@ hipError_t launch_wg(const sgx_ctx *c, const void *tables, const float *d_pcm, u
             lut_seed_coefficients(c, p.guess_a, p.guess_b);
             p.seed_pm1 = wg4096_seed_is_within_one(c) ? 1u : 0u;
             p.single_rows = t->single_rows;
+            p.block_max_cnt = t->block_max_cnt;
         }
         // A one-channel stream (include/sgx.h, "Mono streams"): by default every frame its own real-input transform
         // (stft4096_real.hip); SGX_FLAG_PAIRED_FRAMES: two frames per transform; SGX_FLAG_COMPLEX_MONO: every frame as its own (s, s)

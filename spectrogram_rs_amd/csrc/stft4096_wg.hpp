@@ -9,6 +9,12 @@ namespace sgx {
 namespace wg {
 
 constexpr int kW = 2048, kP = 4096, kM = 2047;
+#ifndef SGX_ROW_BATCH
+#define SGX_ROW_BATCH 0   // row pass, 1: four samples per trip with a launch-uniform trip count (measured round 5: 3.90 vs 3.82 ms per 1e6 frames -- the selects cost more than the latency saved)
+#endif
+#ifndef SGX_SAMPLE_PRELOAD
+#define SGX_SAMPLE_PRELOAD 9   // sample pass: a thread's table words are requested this many steps ahead (9 = all at once; 0: the loop of rounds 1-4, one step ahead.  Same device, config 3 cosine / cubic: 0: 3.85 / 4.13 ms, 3: 3.94 / 4.16, 9: 3.84 / 4.07)
+#endif
 // Sliding the sample window in registers (2 new rows per mono transform instead of 9 loads): every
 // sample is fetched once per workgroup.  It pins 7 VGPRs across the FFT passes (the scalar kernel
 // then spills 3 registers) but the launch is bound by total HBM traffic, and dropping the overlap
@@ -47,6 +53,7 @@ struct Params {
     float guess_a, guess_b;    // LUT index ~ floor(log2(power + 1e-7) * a + b), then exact fix-up
     uint32_t seed_pm1;         // the host has shown that this seed is never off by more than one (seed_within_one): one compare pair fixes it
     uint32_t single_rows;      // bit i: every row of block i (rows 256 i .. 256 i + 255) averages exactly one sample
+    uint32_t block_max_cnt;    // byte i: the largest sample count of a row of block i (row pass: a launch-uniform trip count per block)
     // the real-input kernel (stft4096_real.hip: every mono frame its own transform; tw1 is then [8][256] w_2048^{t q1})
     const float2 *twu;         // [8][128] w_4096^{u + 128 q3} at [q3][u]; [0][0] holds w_4096^{1024} = -i
     unsigned long long stream_samples;   // samples the frames of the stream cover: columns past them read as zero
@@ -71,6 +78,7 @@ struct WgTables {
     PackedSample *d_samples = nullptr;
     uint32_t n_samples = 0;
     uint32_t single_rows = 0;          // Params::single_rows
+    uint32_t block_max_cnt = 0;        // Params::block_max_cnt
     bool fusable = false;
     mutable float *d_planes = nullptr;   // more than two channels: (l, r) pair planes of the sample range of a call, grown on demand
     mutable size_t planes_floats = 0;
@@ -206,6 +214,22 @@ __device__ __forceinline__ void sample_pass_for(const Params &p, const float2 *P
         const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rt, (int)((i < p.n_samples ? i : 0u) * 8u), 0, 0);
         return PackedSample{(int32_t)v.x, __uint_as_float(v.y)};
     };
+#if SGX_SAMPLE_PRELOAD
+    // the nine steps unrolled (kMaxFusedSamples / 256 rounded up), a thread's table words requested kAhead steps ahead: their L1 / L2
+    // latencies overlap each other instead of following one another (all nine at once: 18 registers, 52 bytes of scratch)
+    constexpr int kSteps = (kMaxFusedSamples + 255) / 256, kAhead = SGX_SAMPLE_PRELOAD;
+    PackedSample se[kSteps];
+    asm volatile("" : "+v"(tid));   // (opaque: the unrolled steps' table offsets and slot addresses are not to be hoisted out of the transform loop -- they spill)
+#pragma unroll
+    for (int k = 0; k < kAhead && k < kSteps; ++k) se[k] = item(tid + 256 * k);
+#pragma unroll
+    for (int k = 0; k < kSteps; ++k) {
+        if (k + kAhead < kSteps) se[k + kAhead] = item(tid + 256 * (k + kAhead));
+        const uint32_t s = tid + 256 * k;
+        if (s < p.n_samples) vbuf[s] = interp_sample2<COSINE>(P, se[k].i0, se[k].w);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#else
     uint32_t s = tid;
     PackedSample se = item(s);
     while (s < p.n_samples) {
@@ -215,6 +239,7 @@ __device__ __forceinline__ void sample_pass_for(const Params &p, const float2 *P
         se = se_next;
         s = s_next;
     }
+#endif
 }
 
 template <int PIX>
@@ -278,11 +303,30 @@ __device__ __forceinline__ void row_pass(const Params &p, const uint32_t (&row_w
             r = v.y;
         } else {
             float sl = 0.0f, sr = 0.0f;
+#if SGX_ROW_BATCH
+            // Complex::sum in lin_space order (interpolated_frequency_sample.rs:66-72), four samples per trip: the four LDS reads are
+            // independent (one latency per trip instead of one per sample), the adds stay in order.  The trip count is the block's largest
+            // row (launch-uniform: no divergent loop); a lane whose row is shorter reads its own last sample again and adds +0 instead
+            // (x + 0 is x; only l * l + r * r is used, so the sign of a zero does not matter).
+            const uint32_t trips = (((p.block_max_cnt >> (8 * i_row)) & 0xffu) + 3u) >> 2;
+            const uint32_t last = first + cnt - 1;
+            for (uint32_t t = 0; t < trips; ++t) {
+                const uint32_t i0 = first + 4 * t;
+                const float2 v0 = vbuf[i0 < last ? i0 : last], v1 = vbuf[i0 + 1 < last ? i0 + 1 : last];
+                const float2 v2 = vbuf[i0 + 2 < last ? i0 + 2 : last], v3 = vbuf[i0 + 3 < last ? i0 + 3 : last];
+                const bool k0 = 4 * t < cnt, k1 = 4 * t + 1 < cnt, k2 = 4 * t + 2 < cnt, k3 = 4 * t + 3 < cnt;
+                sl = sl + (k0 ? v0.x : 0.0f); sr = sr + (k0 ? v0.y : 0.0f);
+                sl = sl + (k1 ? v1.x : 0.0f); sr = sr + (k1 ? v1.y : 0.0f);
+                sl = sl + (k2 ? v2.x : 0.0f); sr = sr + (k2 ? v2.y : 0.0f);
+                sl = sl + (k3 ? v3.x : 0.0f); sr = sr + (k3 ? v3.y : 0.0f);
+            }
+#else
             for (uint32_t i = 0; i < cnt; ++i) {
                 const float2 v = vbuf[first + i];
                 sl = sl + v.x;
                 sr = sr + v.y;
             }
+#endif
             l = sl;
             r = sr;
             if (cnt > 1) {  // x / 1.0 == x: only rows that average several samples divide (:72)
