@@ -105,6 +105,9 @@ constexpr int kRowsF32 = 0, kRowsF16 = 1, kPixels = 2;   // what a launch writes
 // SLIDE: H = 256, the window slides in registers (above).  Else: any hop (a frame starts on any sample): the eight columns of the
 // next frame pair are requested where the sliding form requests its one, straight into R -- dead since pass 1 -- and every sample is
 // fetched 2048 / H times, through L2.
+#ifndef SGX_K1R_INTERLEAVE
+#define SGX_K1R_INTERLEAVE 1
+#endif
 #if SGX_STAMPS
 // diagnostic build only (tools/k1r_phases.py): per-phase wave cycles (s_memtime), summed over all waves and iterations
 __device__ unsigned long long g_phase_cycles_r[24];
@@ -320,11 +323,37 @@ __global__ void __launch_bounds__(256, 4) stft4096_real_kernel(Params p)
         // (fft.rs:81) -- on the self-paired bin 1024: Z = P = its register 8, twiddle -i (twu[0][0])
         const int pcol = F * 128 + (u == 0 ? 256 : 128 - u);
         float m1[8], m2[8];
+        // rows: every bin pair is stored as soon as it is computed (SGX_K1R_INTERLEAVE; stft4096_wg.hip does the same for (l, r) rows):
+        // sixteen stores spread over the untangle instead of one burst behind it
+        constexpr bool kInterleave = MODE != kPixels && SLIDE && SGX_K1R_INTERLEAVE;   // (same device, 1e6 frames: H 256 3.64 / 3.87 / 3.84 -> 3.56 / 3.82 / 3.81 ms; any other hop -- eight column loads in flight around the stores -- 4.02 -> 4.29: the burst stays there)
+        const long long row = (long long)(F == 0 ? la : lb) * (long long)kM * kBin - kBin;      // byte of the (absent) bin 0
+        const __amdgpu_buffer_rsrc_t r = out_rsrc(out, MODE != kPixels ? row : 0, MODE != kPixels && (F == 0 || have_b));
+        const int l1 = kBin * u, l2 = kBin * (1152 - u);                                        // bins u + 128 q3 ; 2048 - u - 128 q3 = (1152 - u) + 128 (7 - q3)
+        auto store_pair = [&](const int q3) {
+            // bin k at byte kBin (k - 1).  Thread 0's q3 = 0 slot: bin 1024 from m1, and a second copy of it where its m2 would go.
+            const float a = m1[q3], b = (q3 == 0 && u == 0) ? m1[0] : m2[q3];
+            const int o1 = (q3 == 0 && u == 0) ? kBin * 1024 : l1;
+            const int o2 = (q3 == 0 && u == 0) ? kBin * 128 : l2;                               // 128 + 128 * 7 = 1024
+            const int s1 = kBin * 128 * q3, s2 = kBin * 128 * (7 - q3);
+            if (F16) {
+                const __half2 ha = __floats2half2_rn(a, a), hb = __floats2half2_rn(b, b);
+                __builtin_amdgcn_raw_buffer_store_b32(*reinterpret_cast<const uint32_t *>(&ha), r, o1 + (s1 & 2047), s1 & ~2047, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(*reinterpret_cast<const uint32_t *>(&hb), r, o2 + (s2 & 2047), s2 & ~2047, 0);
+            } else {
+                __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(a), __float_as_uint(a)}, r, o1 + (s1 & 2047), s1 & ~2047, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(b), __float_as_uint(b)}, r, o2 + (s2 & 2047), s2 & ~2047, 0);
+            }
+        };
+        float2 pvs[8];
+        if (kInterleave) {
+#pragma unroll
+            for (int q3 = 0; q3 < 8; ++q3) pvs[q3] = buf[(7 - q3) * 256 + pcol];
+        }
 #pragma unroll
         for (int q3 = 0; q3 < 8; ++q3) {
             const int pos = FFT16_OUT[q3];
             float zr_ = xr[pos], zi_ = xi[pos];
-            float2 pv = buf[(7 - q3) * 256 + pcol];
+            float2 pv = kInterleave ? pvs[q3] : buf[(7 - q3) * 256 + pcol];
             if (q3 == 0) {
                 const float2 own = buf[F * 128];              // thread 0 of the frame: its register 8 as published
                 const int p8 = FFT16_OUT[8];
@@ -337,29 +366,17 @@ __global__ void __launch_bounds__(256, 4) stft4096_real_kernel(Params p)
             const float ar = er + wr, ai = ei + wi, br = er - wr, bi = ei - wi;
             m1[q3] = __builtin_amdgcn_sqrtf(fmaf(ar, ar, ai * ai));   // |S[k]| 2 / W      (the scale rides on the window)
             m2[q3] = __builtin_amdgcn_sqrtf(fmaf(br, br, bi * bi));   // |S[2048 - k]| 2 / W
+            if (kInterleave) {
+                store_pair(q3);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
 
-        SGX_STAMP(12)   // window slide + partner reads + untangle + sqrt
-        // ---- store row [M][2] (or half pairs): bin k at byte kBin (k - 1).  Straight-line code: the wait for the prefetched rows below
-        // is then vmcnt(stores issued since).  Thread 0's q3 = 0 slot: bin 1024 from m1, and a second copy of it where its m2 would go.
+        // ---- store row [M][2] (or half pairs): straight-line code: the wait for the prefetched rows below is then vmcnt(stores issued since)
         if (MODE != kPixels) {
-            const long long row = (long long)(F == 0 ? la : lb) * (long long)kM * kBin - kBin;      // byte of the (absent) bin 0
-            const __amdgpu_buffer_rsrc_t r = out_rsrc(out, row, F == 0 || have_b);
-            const int l1 = kBin * u, l2 = kBin * (1152 - u);                                        // bins u + 128 q3 ; 2048 - u - 128 q3 = (1152 - u) + 128 (7 - q3)
+            if (!kInterleave) {
 #pragma unroll
-            for (int q3 = 0; q3 < 8; ++q3) {
-                const float a = m1[q3], b = (q3 == 0 && u == 0) ? m1[0] : m2[q3];
-                const int o1 = (q3 == 0 && u == 0) ? kBin * 1024 : l1;
-                const int o2 = (q3 == 0 && u == 0) ? kBin * 128 : l2;                               // 128 + 128 * 7 = 1024
-                const int s1 = kBin * 128 * q3, s2 = kBin * 128 * (7 - q3);
-                if (F16) {
-                    const __half2 ha = __floats2half2_rn(a, a), hb = __floats2half2_rn(b, b);
-                    __builtin_amdgcn_raw_buffer_store_b32(*reinterpret_cast<const uint32_t *>(&ha), r, o1 + (s1 & 2047), s1 & ~2047, 0);
-                    __builtin_amdgcn_raw_buffer_store_b32(*reinterpret_cast<const uint32_t *>(&hb), r, o2 + (s2 & 2047), s2 & ~2047, 0);
-                } else {
-                    __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(a), __float_as_uint(a)}, r, o1 + (s1 & 2047), s1 & ~2047, 0);
-                    __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(b), __float_as_uint(b)}, r, o2 + (s2 & 2047), s2 & ~2047, 0);
-                }
+                for (int q3 = 0; q3 < 8; ++q3) store_pair(q3);
             }
         } else {
             // ---- fused pixel columns (simple_spectrogram.rs:141-161): the pair's magnitudes go to LDS as float2 per bin -- (frame A,
