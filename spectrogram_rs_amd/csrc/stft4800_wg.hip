@@ -256,58 +256,80 @@ __global__ void __launch_bounds__(kT) __attribute__((amdgpu_waves_per_eu(4, 4)))
         //      thread 0 is its own partner one slot up (q3' = 15 - q3; its q3 = 0 is bin 0, never stored)
         const int tid = lane();
         const int pcol = tid == 0 ? kT : kT - tid;   // slot s of the partner at buf[s kT + (pcol mod kT)]: thread 0 reads one slot up
+        // Every segment is stored as soon as its bins are split (order 1, 0, 2 .. 7: segment 0's dropped lane re-stores its segment-1 bin):
+        // eight stores spread over the split instead of a burst of eight behind it -- a wave stalls at the issue of a store while the
+        // CU's vector-memory path drains the previous ones (profiles/r05_k1_stereo.txt; W48_BURST restores the burst for A/B).
         float ml[8], mr[8];
+        float2 pb[8];
 #pragma unroll
         for (int q3 = 0; q3 < 8; ++q3) {
             const int at = (7 - q3) * kT + pcol;     // thread 0, q3 = 0: slot 8 does not exist -- reads slot 7 of column 0 instead
-            const float2 b = buf[(q3 == 0 && tid == 0) ? 7 * kT : at];
+            pb[q3] = buf[(q3 == 0 && tid == 0) ? 7 * kT : at];
+        }
+        // ---- store [F][pairs][M][2]: uniform row base (SGPR) + one 32-bit lane offset + a scalar offset per q3.
+        // STRAIGHT-LINE code: the wait for the prefetched samples in `take` below is vmcnt(stores issued since), and the compiler
+        // can only count stores it does not have to branch around -- with one branch in here it waits for every store to be
+        // acknowledged by memory, once per transform (measured: 3.4 us per transform instead of 1.9).  So:
+        //   * lanes whose bin is not an output (bin 0 = lane 0 at q3 = 0; bins >= 2400 = lanes >= 160 at q3 = 7) store a bin they
+        //     do own a second time (lane 0: its q3 = 1 bin; lanes >= 160: their q3 = 6 bin) -- same address, same value.  The
+        //     q3 = 6 bin lies one kT-slab BELOW the q3 = 7 scalar offset: the descriptors start one slab in front of the row and
+        //     every lane offset carries + kT bins, so that no lane offset is ever negative (as the unsigned 32-bit voffset of a
+        //     raw buffer store a negative one is ~4 GiB: dropped by the range check today, a stray write if that ever changed);
+        //   * a mono pair whose first or second frame lies outside the requested range stores the other row twice.
+        char *base = reinterpret_cast<char *>(p.mags);
+        const int bin_bytes = F16 ? 4 : 8;
+        const bool sa = have_first, sb = MODE == 1 ? have_second : false;
+        const long long fa = sa ? f0 : f1, fb = sb ? f1 : f0;            // (row, values) of the two stores of a mono pair
+        const __amdgpu_buffer_rsrc_t ra = uniform_rsrc(base + ((long long)((size_t)fa * p.pairs * (size_t)kM) - 1 - kT) * bin_bytes);
+        const __amdgpu_buffer_rsrc_t rb = uniform_rsrc(base + ((long long)((size_t)fb * p.pairs * (size_t)kM) - 1 - kT) * bin_bytes);
+        const bool drop0 = tid == 0, drop7 = tid >= kW - 7 * kT;
+        auto split = [&](const int q3) {
+            const float2 b = pb[q3];
             const float ar = y[q3].x, ai = y[q3].y;
             const float sr_ = ar + b.x, si_ = ai - b.y;   // a + conj(b) = 2 L^
             const float dr_ = ar - b.x, di_ = ai + b.y;   // a - conj(b) = 2i R^
             ml[q3] = __builtin_amdgcn_sqrtf(fmaf(sr_, sr_, si_ * si_)) * p.half_scale;
             mr[q3] = __builtin_amdgcn_sqrtf(fmaf(dr_, dr_, di_ * di_)) * p.half_scale;
-        }
-
-        {
-            // ---- store [F][pairs][M][2]: uniform row base (SGPR) + one 32-bit lane offset + a scalar offset per q3.
-            // STRAIGHT-LINE code: the wait for the prefetched samples in `take` below is vmcnt(stores issued since), and the compiler
-            // can only count stores it does not have to branch around -- with one branch in here it waits for every store to be
-            // acknowledged by memory, once per transform (measured: 3.4 us per transform instead of 1.9).  So:
-            //   * lanes whose bin is not an output (bin 0 = lane 0 at q3 = 0; bins >= 2400 = lanes >= 160 at q3 = 7) store a bin they
-            //     do own a second time (lane 0: its q3 = 1 bin; lanes >= 160: their q3 = 6 bin) -- same address, same value.  The
-            //     q3 = 6 bin lies one kT-slab BELOW the q3 = 7 scalar offset: the descriptors start one slab in front of the row and
-            //     every lane offset carries + kT bins, so that no lane offset is ever negative (as the unsigned 32-bit voffset of a
-            //     raw buffer store a negative one is ~4 GiB: dropped by the range check today, a stray write if that ever changed);
-            //   * a mono pair whose first or second frame lies outside the requested range stores the other row twice.
-            char *base = reinterpret_cast<char *>(p.mags);
-            const int bin_bytes = F16 ? 4 : 8;
-            const bool sa = have_first, sb = MODE == 1 ? have_second : false;
-            const long long fa = sa ? f0 : f1, fb = sb ? f1 : f0;            // (row, values) of the two stores of a mono pair
-            const __amdgpu_buffer_rsrc_t ra = uniform_rsrc(base + ((long long)((size_t)fa * p.pairs * (size_t)kM) - 1 - kT) * bin_bytes);
-            const __amdgpu_buffer_rsrc_t rb = uniform_rsrc(base + ((long long)((size_t)fb * p.pairs * (size_t)kM) - 1 - kT) * bin_bytes);
-            const bool drop0 = tid == 0, drop7 = tid >= kW - 7 * kT;
-#pragma unroll
-            for (int q3 = 0; q3 < 8; ++q3) {
-                float l = ml[q3], r = mr[q3];
-                if ((W48_ABL & 1) && l != -12345.0f) continue;
-                int lane_off = bin_bytes * (tid + kT);
-                if (q3 == 0) { l = drop0 ? ml[1] : l; r = drop0 ? mr[1] : r; lane_off = drop0 ? bin_bytes * 2 * kT : lane_off; }
-                if (q3 == 7) { l = drop7 ? ml[6] : l; r = drop7 ? mr[6] : r; lane_off = drop7 ? bin_bytes * tid : lane_off; }
-                const float va = MODE == 1 ? (sa ? l : r) : l, vb = MODE == 1 ? (sb ? r : l) : r;
-                if (F16) {
-                    const __half2 ha = MODE == 1 ? __floats2half2_rn(va, va) : __floats2half2_rn(l, r);
-                    __builtin_amdgcn_raw_buffer_store_b32(*reinterpret_cast<const uint32_t *>(&ha), ra, lane_off, bin_bytes * kT * q3, 0);
-                    if (MODE == 1) {
-                        const __half2 hb = __floats2half2_rn(vb, vb);
-                        __builtin_amdgcn_raw_buffer_store_b32(*reinterpret_cast<const uint32_t *>(&hb), rb, lane_off, bin_bytes * kT * q3, 0);
-                    }
-                } else {
-                    const u32x2 da = MODE == 1 ? u32x2{__float_as_uint(va), __float_as_uint(va)} : u32x2{__float_as_uint(l), __float_as_uint(r)};
-                    __builtin_amdgcn_raw_buffer_store_b64(da, ra, lane_off, bin_bytes * kT * q3, 2);
-                    if (MODE == 1) __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(vb), __float_as_uint(vb)}, rb, lane_off, bin_bytes * kT * q3, 2);
+        };
+        auto store = [&](const int q3) {
+            float l = ml[q3], r = mr[q3];
+            if ((W48_ABL & 1) && l != -12345.0f) return;
+            int lane_off = bin_bytes * (tid + kT);
+            if (q3 == 0) { l = drop0 ? ml[1] : l; r = drop0 ? mr[1] : r; lane_off = drop0 ? bin_bytes * 2 * kT : lane_off; }
+            if (q3 == 7) { l = drop7 ? ml[6] : l; r = drop7 ? mr[6] : r; lane_off = drop7 ? bin_bytes * tid : lane_off; }
+            const float va = MODE == 1 ? (sa ? l : r) : l, vb = MODE == 1 ? (sb ? r : l) : r;
+            if (F16) {
+                const __half2 ha = MODE == 1 ? __floats2half2_rn(va, va) : __floats2half2_rn(l, r);
+                __builtin_amdgcn_raw_buffer_store_b32(*reinterpret_cast<const uint32_t *>(&ha), ra, lane_off, bin_bytes * kT * q3, 0);
+                if (MODE == 1) {
+                    const __half2 hb = __floats2half2_rn(vb, vb);
+                    __builtin_amdgcn_raw_buffer_store_b32(*reinterpret_cast<const uint32_t *>(&hb), rb, lane_off, bin_bytes * kT * q3, 0);
                 }
+            } else {
+                const u32x2 da = MODE == 1 ? u32x2{__float_as_uint(va), __float_as_uint(va)} : u32x2{__float_as_uint(l), __float_as_uint(r)};
+                __builtin_amdgcn_raw_buffer_store_b64(da, ra, lane_off, bin_bytes * kT * q3, 2);
+                if (MODE == 1) __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(vb), __float_as_uint(vb)}, rb, lane_off, bin_bytes * kT * q3, 2);
             }
+        };
+#ifdef W48_BURST
+#pragma unroll
+        for (int q3 = 0; q3 < 8; ++q3) split(q3);
+#pragma unroll
+        for (int q3 = 0; q3 < 8; ++q3) store(q3);
+#else
+        split(1);
+        split(0);
+        store(1);
+        __builtin_amdgcn_sched_barrier(0);
+        store(0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q3 = 2; q3 < 8; ++q3) {
+            split(q3);
+            store(q3);
+            __builtin_amdgcn_sched_barrier(0);
         }
+#endif
         take(nxt.data_second);
     }
 }
