@@ -57,7 +57,7 @@ ALGO_BYTES_STFT = H * 1 * 4 + M * 2 * 4  # 17 400 B / frame: each input sample o
 ALGO_BYTES_PIXEL = H * 1 * 4 + R * 4     # 5 120 B / frame
 W4, H4, C4 = 8192, 512, 8
 ALGO_BYTES_CFG4 = H4 * C4 * 4 + (C4 // 2) * (W4 - 1) * 8  # 278 496 B / hop position
-PROFILE_ROUND = "r04"
+PROFILE_ROUND = "r05"
 W_APP, H_APP = 2400, 93     # the application's own operating point: 48 kHz x 0.05 s (gpu_spectrogram.rs:323), hop (2/1024) s (simple_spectrogram.rs:102)
 ALGO_BYTES_STEREO = H * 2 * 4 + M * 2 * 4                     # 18 424 B / frame: an (l, r) stream, what the reference feeds
 ALGO_BYTES_APP = H_APP * 2 * 4 + (W_APP - 1) * 2 * 4          # 19 936 B / frame
@@ -739,7 +739,7 @@ def stereo_leg(args, torch, device):
         "frames_per_s": Fs / (mean * 1e-3), **leg_times(m),
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "bytes_per_frame": ALGO_BYTES_STEREO, "frames_per_launch": Fs,
-                     "kernel": "sgx::wg::stft4096_wg_kernel<false, 1, true, 0>",
+                     "kernel": "sgx::wg::stft4096_wg_kernel<false, 0, true, 0>",   # (l, r) at hop 256: the sliding-window instantiation
                      "first_allocation": first_allocation_of(torch, first, m, lambda buf: eng.stft_batch(pcm, out=buf), Fs * ALGO_BYTES_STEREO, args),
                      "placement": placement,
                      "note": "bound by the transform rate of the kernel (LDS exchanges + vector issue, DESIGN section 4 K1), not by HBM"},

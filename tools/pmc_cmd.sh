@@ -5,4 +5,6 @@ out=$1; ctrs=$2; shift 2
 repo=$(cd "$(dirname "$0")/.." && pwd)
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --pmc $ctrs --output-format csv -d $repo/gpurun_out/$out -- python3 "$@" > $repo/gpurun_out/$out.log 2>&1
-echo "pmc $out rc=$?"
+rc=$?
+echo "pmc $out rc=$rc"
+exit $rc

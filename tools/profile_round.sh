@@ -12,7 +12,7 @@ tools/pmc_bench.sh pr_sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU S
 tools/pmc_bench.sh pr_sq2 SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_WAIT_INST_LDS || exit 1
 python3 tools/pmc_summary.py gpurun_out/pr_sq1_bench gpurun_out/pr_sq2_bench > gpurun_out/pr_sq_counters.txt
 # the two summaries bench.py quotes (stamped with the kernel sources' hash): profiles/<round>_hbm_traffic.json, <round>_pixel_pipes.json
-python3 tools/pmc_round.py ${ROUND:-r04} gpurun_out/pr_fetch_bench gpurun_out/pr_fetch_micro gpurun_out/pr_write_bench gpurun_out/pr_write_micro \
+python3 tools/pmc_round.py ${ROUND:-r05} gpurun_out/pr_fetch_bench gpurun_out/pr_fetch_micro gpurun_out/pr_write_bench gpurun_out/pr_write_micro \
     gpurun_out/pr_sq1_bench gpurun_out/pr_sq2_bench > gpurun_out/pr_round.txt || exit 1
 (cd gpurun_out && find pr_* -name '*.csv' | sort) > gpurun_out/pr_files.txt   # this run's files: gpurun MERGES into the caller's gpurun_out/, older runs' stay there
 python3 -c "from bench import csrc_sha16; print(csrc_sha16())" > gpurun_out/pr_csrc_sha16.txt   # what tools/profiles_from_round.py checks the tree against
