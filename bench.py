@@ -560,7 +560,7 @@ def place_output(torch, n_candidates, alloc, launch, bytes_per_launch, reps=10, 
     if len(cands) == 1:
         launch(cands[0])
         torch.cuda.synchronize()
-        return cands[0], None, {"candidates": 1, "chosen": 0, "kept_selection": False,
+        return cands[0], None, {"candidates": 1, "requested": max(1, n_candidates), "chosen": 0, "kept_selection": False,
                                 "why": "one candidate: the first allocation is the buffer"}
     t0 = time.perf_counter()
     while time.perf_counter() - t0 < heat_s:          # heat: every candidate in turn
@@ -582,7 +582,7 @@ def place_output(torch, n_candidates, alloc, launch, bytes_per_launch, reps=10, 
     torch.cuda.empty_cache()
     frac = lambda ms: bytes_per_launch / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
     return keep_buf, first_buf, {
-        "candidates": len(order), "protocol": f"{heat_s:.1f} s of launches over all candidates, then two passes in opposite order, {reps} launches per candidate and pass",
+        "candidates": len(order), "requested": max(1, n_candidates), "protocol": f"{heat_s:.1f} s of launches over all candidates, then two passes in opposite order, {reps} launches per candidate and pass",
         "pass1_ms_per_launch": pass1, "pass2_ms_per_launch": pass2, "stable_within_2pct": stable,
         "spread": (max(mean) - min(mean)) / min(mean), "fastest": best, "chosen": chosen, "kept_selection": bool(keep),
         "frac_of_candidate_0": frac(mean[0]), "frac_of_fastest": frac(mean[best]),

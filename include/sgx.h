@@ -118,6 +118,9 @@ typedef struct sgx_info {
     uint32_t sample_rate_u32; /* SampleRate(sample_rate as u32)      simple_spectrogram.rs:138 */
     uint32_t total_samples_per_column; /* sum over rows of magnitude_in's sample count */
     uint32_t stft_kernel;     /* 0 = generic power-of-two, 2 = 4096-point workgroup-per-transform (default at W 2048), 4 = Bluestein chirp-z (any 2W), 5 = 16384-point as four 4096-point residues of the output (SGX_FLAG_RESIDUE_16K), 6 = mixed radix (2W = 2^a 3^b 5^c 7^d <= 20480, e.g. the application's 4800, 4410 and 19200), 8 = 16384-point as four time-decimated 4096-point transforms in the lanes of a quad, one 1024-thread workgroup per transform (default for W = 8192), 9 = 4800-point workgroup-per-transform, 16 x 20 x 15 (default for W = 2400, the application's window at 48 kHz; streams of more than two channels run 6) */
+                              /* (magnitudes: the tuned kernels -- 2, 6, 8, 9 and the chirp-z plans of 4 -- take |re + i im| through the hardware
+                                 square root of fma(re, re, im * im): 1 ulp; the generic kernel (0) and the radix-4 Bluestein ladder use the
+                                 correctly rounded sqrtf.  Rows of different kernels for the same input agree within the tolerance, not bit for bit) */
     uint32_t render_path;     /* sgx_render_batch as configured NOW (palette included): bit 0 = one fused PCM-to-pixel kernel (the
                                  4096-point kernel, or a compile-time plan of the mixed-radix kernel whose LDS image holds the column),
                                  bit 1 = its LUT index is seed + one compare pair (else seed + walk); neither = two kernels;
