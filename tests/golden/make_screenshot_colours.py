@@ -13,6 +13,8 @@ Stored per image -- DATA, not the picture:
                       one-pixel border (rows within 4 px of the first / last opaque row) left out: the x axis line
   <name>_colours      every distinct opaque RGB triple, [n][3] u8
   <name>_counts       how many opaque pixels carry it, [n] u32
+  <name>_axis_geometry  [y_top, y_bottom] of the vertical (frequency) axis line and the centre rows of its tick marks, top to bottom,
+                      in screenshot pixels: the log-frequency axis of simple_spectrogram.rs:107 (32 .. 22030 Hz, ticks at 32 * 2^k) as drawn
 tests/test_host_logic.py reads the file; nothing on the GPU box needs /root/reference.
 """
 import os
@@ -42,6 +44,19 @@ def longest_run_colour(rgb, opaque, background):
     return colour, best
 
 
+def axis_geometry(rgb, opaque, axis):
+    """[y_top, y_bottom, tick centres ...] of the vertical axis: the column with the most axis-coloured pixels above the x axis line;
+    ticks = runs of axis colour just left of it"""
+    m = (rgb == axis).all(axis=2) & opaque
+    y_axis = int(np.argmax(m.sum(axis=1)))                      # the horizontal (time) axis line
+    x_axis = int(np.argmax(m[:y_axis].sum(axis=0)))             # the vertical (frequency) axis line
+    ys = np.flatnonzero(m[:y_axis + 1, x_axis])
+    left = np.flatnonzero(m[:y_axis + 1, x_axis - 4])
+    runs = np.split(left, np.flatnonzero(np.diff(left) > 1) + 1)
+    ticks = [float(r.mean()) for r in runs if len(r)]
+    return np.array([float(ys.min()), float(y_axis)] + ticks, np.float64)
+
+
 def main():
     import matplotlib.image as mi
 
@@ -56,6 +71,7 @@ def main():
         axis, run = longest_run_colour(rgb, opaque, background)
         out[name + "_background"] = background
         out[name + "_axis"] = axis
+        out[name + "_axis_geometry"] = axis_geometry(rgb, opaque, axis)
         out[name + "_colours"] = cols.astype(np.uint8)
         out[name + "_counts"] = cnt.astype(np.uint32)
         print(name, "opaque pixels", int(opaque.sum()), "distinct", len(cols), "background", tuple(int(c) for c in background),

@@ -292,6 +292,35 @@ def test_reference_screenshots_pin_the_table_values_and_cools_curve():
     assert exact >= 0.5 and near >= 0.75, (exact, near)                                # measured: 0.540, 0.768
 
 
+def test_reference_screenshots_pin_the_log_frequency_axis():
+    # The same four screenshots show the frequency axis of simple_spectrogram.rs:107 -- (32.0..22030.0).reversible_log_scale() -- as
+    # drawn: a vertical axis line whose top end is the range's upper end, tick marks at 32 * 2^k Hz (labels 32.0 ... 16384.0).
+    # tests/golden/screenshot_colours.npz keeps the geometry (top / bottom row of the line, the ticks' centre rows).  What this pins,
+    # independently of this build: rows a18 / a19 -- the axis is linear in log f and runs from 32 Hz to 22030 Hz (LogCoordf64::map,
+    # the inverse of the `unmap` the pixel path calls, log_scaling.rs:47-51,114-119).  Resolution: 1.5 screenshot pixels of 501 = 2 % in
+    # frequency: a range end of 20 kHz or 24 kHz would be 7 pixels off.
+    import os
+    import numpy as np
+    import oracle
+    shots = np.load(os.path.join(os.path.dirname(__file__), "golden", "screenshot_colours.npz"))
+    for name in ("viridis", "magma", "plasma", "cool"):
+        g = shots[name + "_axis_geometry"]
+        y_top, ticks = g[0], g[2:]
+        assert len(ticks) == 10                                    # 32, 64, ..., 16384 Hz, top to bottom: 16384 first
+        k = np.arange(9, -1, -1, dtype=np.float64)                 # octaves above 32 Hz
+        b, c = np.polyfit(k, ticks, 1)                             # y = c + b k: b < 0 pixels per octave, c = the row of 32 Hz
+        assert np.abs(ticks - (c + b * k)).max() <= 1.5            # linear in log f (the ticks are snapped to device pixels)
+        octaves = np.log2(22030.0 / 32.0)
+        assert abs((c + b * octaves) - y_top) <= 1.5               # ... and the line ends where 22030 Hz falls
+        assert abs((c + b * np.log2(20000.0 / 32.0)) - y_top) > 5 and abs((c + b * np.log2(24000.0 / 32.0)) - y_top) > 5
+        # the oracle's (and through test_gpu_parity the engine's) row edges are that axis: unmap at a tick's height returns its frequency
+        N = 1_000_000
+        for kk, y in zip(k, ticks):
+            pfrac = (c - y) / (c - (c + b * octaves))
+            f = oracle.log_unmap(32.0, 22030.0, int(round(pfrac * N)), 0, N)
+            assert abs(f / (32.0 * 2.0 ** kk) - 1.0) <= 0.02, (name, kk, f)
+
+
 def test_integration_md_shows_the_binding_files_verbatim():
     # INTEGRATION.md's Rust blocks are generated from bindings/rust/*.rs (tools/sync_integration.py): no drift, no stubs
     import os
