@@ -95,6 +95,34 @@ def test_other_sizes_and_channel_pairs(torch_cuda, mags_err, Wt, Ht, ch):
     assert mags_err(got, ref) <= 2.0
 
 
+@pytest.mark.parametrize("ch,kw", [(2, {}), (4, {}), (1, {}), (1, {"paired_frames": True}), (1, {"complex_mono": True})])
+def test_sliding_windows_over_long_runs(torch_cuda, mags_err, ch, kw):
+    # At H = 256 the 4096-point kernels slide their sample window in registers: a persistent workgroup loads a whole window only for the
+    # FIRST transform of its run and one new row per transform after that.  A launch of a few hundred frames gives every workgroup one
+    # transform -- the sliding code never runs.  Here every workgroup owns ~6 consecutive transforms: every frame must equal, bit for bit,
+    # the same frame computed alone (a one-frame launch: whole-window load) and, on a sample, the oracle's.
+    torch = torch_cuda
+    F = 6151
+    eng = engine(window_samples=W, hop_samples=H, channels=ch, gradient="viridis", **kw)
+    pcm = oracle.white_noise(((F - 1) * H + W) * ch, seed=77 + ch)
+    dev = to_dev(torch, pcm)
+    full = eng.stft_batch(dev)
+    half = eng.stft_batch_f16(dev)
+    pix = eng.render_batch(dev)
+    assert full.shape[0] == F
+    rng = np.random.default_rng(3)
+    for t in sorted(set([0, 1, 2, 5, 6, 7, F - 2, F - 1] + [int(v) for v in rng.integers(0, F, 24)])):
+        cnt = 2 if (ch == 1 and t + 1 < F) else 1          # mono kernels take frames in pairs: an even start, two frames
+        t0 = t - (t & 1) if ch == 1 else t
+        assert torch.equal(eng.stft_batch(dev, first_frame=t0, max_frames=cnt), full[t0:t0 + cnt]), t
+        assert torch.equal(eng.stft_batch_f16(dev, first_frame=t0, max_frames=cnt), half[t0:t0 + cnt]), t
+        assert torch.equal(eng.render_batch(dev, first_frame=t0, max_frames=cnt), pix[t0:t0 + cnt]), t
+    pick = np.unique(np.concatenate([[0, 1, 6, 7, F - 1], rng.integers(0, F, 40)]))
+    got = full.cpu().numpy()[pick]
+    ref = np.stack([oracle.stream_process(pcm[t * H * ch:(t * H + W) * ch], ch, W, H)[0] for t in pick])
+    assert mags_err(got, ref) <= 2.0
+
+
 @pytest.mark.parametrize("ch,Ht", [(4, 256), (8, 256), (8, 100), (6, 512)])
 def test_4096_point_kernel_on_interleaved_channel_pairs(torch_cuda, mags_err, gradients, ch, Ht):
     # more than two channels at W = 2048: the pairs are split into planes and each runs the two-channel kernel (transform,
