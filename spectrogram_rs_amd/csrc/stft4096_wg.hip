@@ -198,6 +198,19 @@ __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
     // stream overlaps the other workgroups' arithmetic better: +6 % (mono), and with the intermediate steps 1 and 2 for
     // the second pass +12 % for stereo input (same-device A/B; the steps cost mono 1 %).  The fused pixel path holds
     // priority 1 through its sample pass and 3 from its row pass on: +12 % over no priorities.
+    // The next transform's samples, requested in front of the stores, are waited for behind them, in straight-line code: that is
+    // vmcnt(stores issued since), which the older loads satisfy while the stores are still in flight.  Left pending across the back
+    // edge the compiler merged them with the entry path and waited at the top of every iteration with vmcnt(5) .. vmcnt(0): for every
+    // row store of the transform to be acknowledged by memory.  (The sliding mono window does the same by hand, below.)
+    auto next_samples_are_here = [&]() {
+        if (kSlide2) {
+            asm volatile("" : "+v"(ld0), "+v"(ld1));
+        } else {
+            asm volatile("" : "+v"(sa[0]), "+v"(sa[1]), "+v"(sa[2]), "+v"(sa[3]), "+v"(sa[4]), "+v"(sa[5]), "+v"(sa[6]), "+v"(sa[7]));
+            if ((MONO && PAIRING != kPairAdjacentRow) || (!MONO && C2))
+                asm volatile("" : "+v"(sb[0]), "+v"(sb[1]), "+v"(sb[2]), "+v"(sb[3]), "+v"(sb[4]), "+v"(sb[5]), "+v"(sb[6]), "+v"(sb[7]));
+        }
+    };
 #if SGX_STAMPS
     unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long st_last = __builtin_readcyclecounter();
@@ -419,6 +432,10 @@ __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
 
             lds_barrier();
             sample_pass<PIX>(p, m2, vbuf, tid);
+            // the fused pixel path waits for the next transform's samples HERE: the sample pass has just waited for its table words with
+            // vmcnt(0), so they are there -- behind the row pass, whose pixel stores sit in a loop the compiler cannot count through,
+            // the same wait is a vmcnt(0) again: every pixel store just issued acknowledged by memory, once per column
+            if (!(MONO && PAIRING == kPairAdjacentRow && kSlideWindow)) next_samples_are_here();
             lds_barrier();
             uchar4 *rgba = reinterpret_cast<uchar4 *>(p.rgba);
             uchar4 *dst_a = rgba + ((size_t)(have_first ? f0 : 0) * p.pairs + p.pair) * (size_t)p.R;
@@ -427,18 +444,7 @@ __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
             row_pass<MONO, PIX>(p, row_words, vbuf, dst_a, dst_b, have_first, have_second, pal, tid);
         }
         SGX_STAMP(13)   // row stores issued (fused pixel path: the pixel passes)
-        if (kSlide2) {
-            asm volatile("" : "+v"(ld0), "+v"(ld1));    // the new row, behind the stores: vmcnt(stores issued since)
-        } else if (!(MONO && PAIRING == kPairAdjacentRow && kSlideWindow)) {
-            // The next transform's samples, requested in front of the stores, are waited for HERE, behind them: in straight-line code
-            // that is vmcnt(stores issued since), which the older loads satisfy while the stores are still in flight.  Left pending
-            // across the back edge the compiler merged them with the entry path and waited at the top of every iteration with
-            // vmcnt(5) .. vmcnt(0): for every row store of the transform to be acknowledged by memory.  (The sliding mono window does
-            // the same by hand, above.)
-            asm volatile("" : "+v"(sa[0]), "+v"(sa[1]), "+v"(sa[2]), "+v"(sa[3]), "+v"(sa[4]), "+v"(sa[5]), "+v"(sa[6]), "+v"(sa[7]));
-            if ((MONO && PAIRING != kPairAdjacentRow) || (!MONO && C2))
-                asm volatile("" : "+v"(sb[0]), "+v"(sb[1]), "+v"(sb[2]), "+v"(sb[3]), "+v"(sb[4]), "+v"(sb[5]), "+v"(sb[6]), "+v"(sb[7]));
-        }
+        if (!RENDER && !(MONO && PAIRING == kPairAdjacentRow && kSlideWindow)) next_samples_are_here();   // rows: behind the stores, vmcnt(stores issued since)
     }
 #if SGX_STAMPS
     if ((tid & 63) == 0) {
