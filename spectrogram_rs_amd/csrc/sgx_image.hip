@@ -44,8 +44,10 @@ __global__ void __launch_bounds__(256) image_scatter_kernel(const uchar4 *cols, 
 // out[row][x] = image[row][(x + offset) % width]: the picture the two append_scaled_texture calls compose (:181-209)
 __global__ void __launch_bounds__(256) image_scrolled_kernel(const uchar4 *image, uchar4 *out, uint32_t width, uint32_t height, uint32_t offset)
 {
-    const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x, row = blockIdx.y;
-    if (x < width) out[(size_t)row * width + x] = image[(size_t)row * width + (x + offset) % width];
+    const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= width) return;
+    for (uint32_t row = blockIdx.y; row < height; row += gridDim.y)      // (65 536 rows are allowed, 65 535 blocks along y are)
+        out[(size_t)row * width + x] = image[(size_t)row * width + (x + offset) % width];
 }
 
 void detach_images(sgx_ctx *c)
@@ -151,7 +153,7 @@ int sgx_image_read(sgx_image *im, int scrolled, uint8_t *d_out)
     if (!scrolled || im->offset == 0) {
         IMAGE_HIP(im, hipMemcpyAsync(d_out, im->d_pixels, (size_t)im->width * im->height * sizeof(uchar4), hipMemcpyDeviceToDevice, c->stream));
     } else {
-        hipLaunchKernelGGL(sgx::image_scrolled_kernel, dim3((im->width + 255) / 256, im->height), dim3(256), 0, c->stream,
+        hipLaunchKernelGGL(sgx::image_scrolled_kernel, dim3((im->width + 255) / 256, im->height < 65535u ? im->height : 65535u), dim3(256), 0, c->stream,
                            im->d_pixels, reinterpret_cast<uchar4 *>(d_out), im->width, im->height, im->offset);
         IMAGE_HIP(im, hipGetLastError());
     }
