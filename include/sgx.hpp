@@ -206,9 +206,56 @@ public:
         return out;
     }
 
+    sgx_live *raw() { return live_; }
+
 private:
     FastFourierTransform &transform_;
     sgx_live *live_ = nullptr;
+};
+
+// SimpleSpectrogram's Pixbuf ring on the device (sgx_image_*): `buffer` + `offset` of simple_spectrogram.rs:60-66,89-94, the
+// put_pixel loop with its offset update (:140-164) as tick(), the picture of the two sub-images (:181-209) as scrolled().
+class ImageRing {
+public:
+    ImageRing(FastFourierTransform &transform, std::uint32_t width, std::uint32_t rows) : transform_(transform), width_(width), rows_(rows)
+    {
+        const int rc = sgx_image_create(transform.ctx(), width, &image_);
+        if (rc != SGX_OK) throw Error(rc, sgx_last_error(transform.ctx()));
+    }
+    ImageRing(const ImageRing &) = delete;
+    ImageRing &operator=(const ImageRing &) = delete;
+    ~ImageRing() { sgx_image_destroy(image_); }
+
+    // one GUI tick: every complete frame of the capture ring becomes a pixel column at `offset`, device to device
+    std::size_t tick(LiveRing &live)
+    {
+        std::size_t got = 0;
+        const int rc = sgx_live_tick_image(live.raw(), image_, width_, &got);
+        if (rc != SGX_OK) throw Error(rc, sgx_last_error(transform_.ctx()));
+        return got;
+    }
+    std::size_t offset() const { return sgx_image_offset(image_); }
+
+    // [rows][width][4] bytes on the host: the buffer as it lies, or the scrolled picture
+    std::vector<std::uint8_t> pixels(bool scrolled = false)
+    {
+        const std::size_t bytes = (std::size_t)rows_ * width_ * 4;
+        void *d = nullptr;
+        if (hipMalloc(&d, bytes) != hipSuccess) throw Error(SGX_ERR_HIP, "hipMalloc");
+        std::vector<std::uint8_t> out(bytes);
+        int rc = sgx_image_read(image_, scrolled ? 1 : 0, static_cast<std::uint8_t *>(d));
+        if (rc == SGX_OK) rc = sgx_sync(transform_.ctx());
+        const hipError_t e = rc == SGX_OK ? hipMemcpy(out.data(), d, bytes, hipMemcpyDeviceToHost) : hipSuccess;
+        (void)hipFree(d);
+        if (rc != SGX_OK) throw Error(rc, sgx_last_error(transform_.ctx()));
+        if (e != hipSuccess) throw Error(SGX_ERR_HIP, hipGetErrorString(e));
+        return out;
+    }
+
+private:
+    FastFourierTransform &transform_;
+    sgx_image *image_ = nullptr;
+    std::uint32_t width_, rows_;
 };
 
 // audio_transform.rs:14-43; the three members are public and assignable, as in the reference

@@ -51,6 +51,35 @@ int main(int argc, char **argv)
             try { live.push(reinterpret_cast<const float *>(lr.data()), 6, 3); } catch (const Error &) { refused = true; }
             if (!refused) return 8;
         }
+        // SimpleSpectrogram's Pixbuf ring: the same pieces, a tick into a 16-column image after each; against the columns the host-side
+        // tick returns, put in place one by one as the reference does (:150-164)
+        {
+            const uint32_t width = 16, rows = 1024;
+            LiveRing live_a(fft, 1 << 16), live_b(fft, 1 << 16);
+            ImageRing image(fft, width, rows);
+            std::vector<uint8_t> want((size_t)rows * width * 4, 0), cols(64 * (size_t)rows * 4);
+            size_t off = 0, total = 0;
+            for (size_t i = 0; i < n; i += 480) {
+                const size_t m = n - i < 480 ? n - i : 480;
+                live_a.push(reinterpret_cast<const float *>(lr.data() + i), 2 * m, 2);
+                live_b.push(reinterpret_cast<const float *>(lr.data() + i), 2 * m, 2);
+                total += image.tick(live_a);
+                size_t got = 0;
+                if (sgx_live_tick(live_b.raw(), SGX_LIVE_RGBA, cols.data(), 64, &got) != SGX_OK) return 9;
+                for (size_t c = 0; c < got; ++c) {
+                    for (uint32_t y = 0; y < rows; ++y)
+                        for (int b = 0; b < 4; ++b) want[((size_t)y * width + off) * 4 + b] = cols[(c * rows + y) * 4 + b];
+                    off = (off + 1) % width;
+                }
+            }
+            if (total != frames.size() || image.offset() != off) { fprintf(stderr, "image ring: %zu columns, offset %zu (want %zu, %zu)\n", total, image.offset(), frames.size(), off); return 10; }
+            if (image.pixels() != want) { fprintf(stderr, "image ring: pixels differ from the column-by-column scatter\n"); return 11; }
+            const auto scrolled = image.pixels(true);
+            for (uint32_t y = 0; y < rows; ++y)
+                for (uint32_t x = 0; x < width; ++x)
+                    for (int b = 0; b < 4; ++b)
+                        if (scrolled[((size_t)y * width + x) * 4 + b] != want[((size_t)y * width + (x + off) % width) * 4 + b]) { fprintf(stderr, "image ring: scrolled picture\n"); return 12; }
+        }
         FILE *f = fopen(argv[1], "wb");
         const uint64_t hdr[4] = {frames.size(), fft.num_output_frequencies(), stream.stride_samples(), ring.occupied_len()};
         fwrite(hdr, sizeof(hdr), 1, f);
