@@ -108,6 +108,46 @@ constexpr int kRowsF32 = 0, kRowsF16 = 1, kPixels = 2;   // what a launch writes
 #ifndef SGX_K1R_INTERLEAVE
 #define SGX_K1R_INTERLEAVE 1
 #endif
+#ifndef SGX_ADDTID_R
+#define SGX_ADDTID_R 1   // (0: the b64 transposes of the non-sliding instantiation, for A/B)
+#endif
+// TR (the sliding instantiation): the two LDS transposes as real / imaginary planes, written with ds_write_addtid_b32 and read back in
+// 16-byte pieces, as in stft4096_wg.hip (there: why pass 1 then runs column t = (tid >> 4) + 16 (tid & 15)).  Image 1: rows 8 F + q1 of 272
+// words; image 2: rows q2 of 280 words -- its readers are the threads (F, u = q1 + 8 q2), and with that lane order 280 is the stride whose
+// 16-byte reads are conflict-free (tools/lds_b128_conflicts.py).  The imaginary plane starts 4 480 words in, for both.
+constexpr int kPlaneIm = 4480;                                        // words
+constexpr int kBufComplexTR = kPlaneIm;                               // 2 * 4 480 words = 35 840 B: 1 KB more than the b64 images
+static_assert(kBufComplexTR >= kBufComplex && 16 * 280 <= kPlaneIm, "the planes hold both images");
+constexpr size_t kLdsBytesR = (size_t)(kBufComplexTR + 256) * sizeof(float2);
+constexpr size_t kLdsBytesRenderR = kLdsBytesR + 256 * sizeof(uint2);
+static_assert(4 * kLdsBytesRenderR <= 160 * 1024, "four workgroups per CU");
+// rows ra and rb (STRIDE words each) of both planes, this wave's 64 words: LDS address = M0 + offset + 4 * lane.  M0 is set inside the
+// statement (the compiler neither knows about nor relies on its value) and one wait state separates a scalar write of M0 from an
+// add-TID instruction (tools/isa_check_addtid.py looks at every build).
+template <int STRIDE>
+__device__ __forceinline__ void addtid_rows(float2 a, float2 b, uint32_t m0_wave, int ra, int rb)
+{
+    asm volatile("s_mov_b32 m0, %4\n\t"
+                 "s_nop 0\n\t"
+                 "ds_write_addtid_b32 %0 offset:%5\n\t"
+                 "ds_write_addtid_b32 %1 offset:%6\n\t"
+                 "ds_write_addtid_b32 %2 offset:%7\n\t"
+                 "ds_write_addtid_b32 %3 offset:%8"
+                 :
+                 : "v"(a.x), "v"(a.y), "v"(b.x), "v"(b.y), "s"(m0_wave), "i"(4 * STRIDE * ra), "i"(4 * STRIDE * ra + 4 * kPlaneIm), "i"(4 * STRIDE * rb), "i"(4 * STRIDE * rb + 4 * kPlaneIm)
+                 : "memory");
+}
+__device__ __forceinline__ void read_planes(const float4 *rd4, float (&xr)[16], float (&xi)[16])
+{
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float4 r = rd4[c], i = rd4[c + kPlaneIm / 4];
+        xr[4 * c] = r.x; xr[4 * c + 1] = r.y; xr[4 * c + 2] = r.z; xr[4 * c + 3] = r.w;
+        xi[4 * c] = i.x; xi[4 * c + 1] = i.y; xi[4 * c + 2] = i.z; xi[4 * c + 3] = i.w;
+    }
+}
+__device__ __forceinline__ float lane_xor8(float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x128, 0xf, 0xf, true)); }   // row_ror:8
+
 #if SGX_STAMPS
 // diagnostic build only (tools/k1r_phases.py): per-phase wave cycles (s_memtime), summed over all waves and iterations
 __device__ unsigned long long g_phase_cycles_r[24];
@@ -121,11 +161,19 @@ __global__ void __launch_bounds__(256, 4) stft4096_real_kernel(Params p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float2 *buf = reinterpret_cast<float2 *>(smem_raw);
-    float2 *tw2 = buf + kBufComplex;
+    constexpr bool TR = SLIDE && SGX_ADDTID_R;
+    float2 *tw2 = buf + (TR ? kBufComplexTR : kBufComplex);
     uint2 *pal = reinterpret_cast<uint2 *>(tw2 + 256);          // kPixels only: [256] {threshold, RGBA} (wg::pixel_for)
     constexpr bool F16 = MODE == kRowsF16;
 
     const int tid = threadIdx.x;
+    const int t_p1 = TR ? (tid >> 4) + 16 * (tid & 15) : tid;     // pass-1 column of this thread
+    float *plane = reinterpret_cast<float *>(smem_raw);
+    const uint32_t m0_wave = __builtin_amdgcn_readfirstlane((uint32_t)(tid >> 6) * 272u);   // TR: byte offset of this wave inside a plane row (64 + 4 words per wave)
+    // TR read sides: image 1, thread (g2 = tid >> 4, t0 = tid & 15): the words of writers 16 t0 .. + 15 of row g2; image 2, thread (F, u):
+    // the words of writers 16 (8 F + q1) .. + 15 of row q2
+    const float4 *rd4_1 = reinterpret_cast<const float4 *>(plane + 272 * (tid >> 4) + 68 * ((tid & 15) >> 2) + 16 * (tid & 3));
+    const float4 *rd4_2 = reinterpret_cast<const float4 *>(plane + 280 * ((tid & 127) >> 3) + 68 * ((8 * (tid >> 7) + (tid & 7)) >> 2) + 16 * (tid & 3));
     tw2[tid] = p.tw2[tid];
     uint32_t row_words[4] = {0u, 0u, 0u, 0u};  // kPixels: the table words of this thread's rows tid + 256 i
     if (MODE == kPixels) {
@@ -141,12 +189,12 @@ __global__ void __launch_bounds__(256, 4) stft4096_real_kernel(Params p)
     float win[8];
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
-        win[2 * a] = p.window[2 * tid + 512 * a] * (1.0f / 2048.0f);
-        win[2 * a + 1] = p.window[2 * tid + 512 * a + 1] * (1.0f / 2048.0f);
+        win[2 * a] = p.window[2 * t_p1 + 512 * a] * (1.0f / 2048.0f);
+        win[2 * a + 1] = p.window[2 * t_p1 + 512 * a + 1] * (1.0f / 2048.0f);
     }
     float2 tw1[8];
 #pragma unroll
-    for (int q = 1; q < 8; ++q) tw1[q] = p.tw1[q * 256 + tid];
+    for (int q = 1; q < 8; ++q) tw1[q] = p.tw1[q * 256 + t_p1];
     const int F = tid >> 7, u = tid & 127;        // pass-3 / output role: frame of the pair, bins u + 128 q3
     float2 twu[8];
 #pragma unroll
@@ -174,7 +222,7 @@ __global__ void __launch_bounds__(256, 4) stft4096_real_kernel(Params p)
     };
     auto columns_from = [&](unsigned long long col0) { return samples_from(2 * col0); };
     auto column = [&](__amdgpu_buffer_rsrc_t r, int byte_offset) {
-        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, tid * 8, byte_offset, 0);
+        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, t_p1 * 8, byte_offset, 0);
         return make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
     };
     float2 R[8];        // R[j] = c[128 fa + tid + 128 j]: rows a = j / 2 of frame A (even j) and frame B (odd j)
@@ -245,8 +293,12 @@ __global__ void __launch_bounds__(256, 4) stft4096_real_kernel(Params p)
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const float2 ya = make_float2(yr[q], yi[q]), yb = make_float2(vr[q], vi[q]);
-            buf[q * kS1 + tid] = q == 0 ? ya : cmulf(ya, tw1[q]);
-            buf[(8 + q) * kS1 + tid] = q == 0 ? yb : cmulf(yb, tw1[q]);
+            if (TR) {
+                addtid_rows<272>(q == 0 ? ya : cmulf(ya, tw1[q]), q == 0 ? yb : cmulf(yb, tw1[q]), m0_wave, q, 8 + q);
+            } else {
+                buf[q * kS1 + tid] = q == 0 ? ya : cmulf(ya, tw1[q]);
+                buf[(8 + q) * kS1 + tid] = q == 0 ? yb : cmulf(yb, tw1[q]);
+            }
         }
         __builtin_amdgcn_s_setprio(0);  // (wave priorities: stft4096_wg.hip)
         SGX_STAMP(2)    // twiddles + image-1 writes
@@ -257,9 +309,11 @@ __global__ void __launch_bounds__(256, 4) stft4096_real_kernel(Params p)
         float xr[16], xi[16];
 #pragma unroll
         for (int t1 = 0; t1 < 16; ++t1) {
+            if (TR) break;
             const float2 v = buf[g2 * kS1 + t0_2 + 16 * t1];
             xr[t1] = v.x; xi[t1] = v.y;
         }
+        if (TR) read_planes(rd4_1, xr, xi);
         fft16(xr, xi);
         SGX_STAMP(4)    // image-1 reads + FFT16
         lds_barrier();  // everyone has read image 1
@@ -268,7 +322,15 @@ __global__ void __launch_bounds__(256, 4) stft4096_real_kernel(Params p)
         for (int q2 = 0; q2 < 16; ++q2) {
             const int pos = FFT16_OUT[q2];
             const float2 v = make_float2(xr[pos], xi[pos]);
-            buf[t0_2 * kS2 + cbase2 + 8 * q2] = q2 == 0 ? v : cmulf(v, tw2[q2 * 16 + t0_2]);
+            if (!TR) buf[t0_2 * kS2 + cbase2 + 8 * q2] = q2 == 0 ? v : cmulf(v, tw2[q2 * 16 + t0_2]);
+        }
+        if (TR) {
+#pragma unroll
+            for (int q2 = 0; q2 < 16; q2 += 2) {
+                const int pa = FFT16_OUT[q2], pb = FFT16_OUT[q2 + 1];
+                const float2 va = make_float2(xr[pa], xi[pa]), vb = make_float2(xr[pb], xi[pb]);
+                addtid_rows<280>(q2 == 0 ? va : cmulf(va, tw2[q2 * 16 + t0_2]), cmulf(vb, tw2[(q2 + 1) * 16 + t0_2]), m0_wave, q2, q2 + 1);
+            }
         }
         SGX_STAMP(6)    // pass-2 twiddles + image-2 writes
         lds_barrier();
@@ -277,9 +339,11 @@ __global__ void __launch_bounds__(256, 4) stft4096_real_kernel(Params p)
         // ---- pass 3: thread (F, u): 16-point FFT over t0 -> Z[u + 128 q3]
 #pragma unroll
         for (int t0 = 0; t0 < 16; ++t0) {
+            if (TR) break;
             const float2 v = buf[t0 * kS2 + tid];
             xr[t0] = v.x; xi[t0] = v.y;
         }
+        if (TR) read_planes(rd4_2, xr, xi);
         fft16(xr, xi);
 
         // ---- rows: the load of the NEXT iteration (its R[9]), ahead of this iteration's stores (vmcnt retires in issue order), into a
@@ -302,7 +366,7 @@ __global__ void __launch_bounds__(256, 4) stft4096_real_kernel(Params p)
             buf[j * 256 + tid] = make_float2(xr[pos], xi[pos]);
         }
         // the next R[6] = c[128 fa + 1024 + tid] of the thread half a row away: its L (lower half publishes) or its R[7] (upper half)
-        if (SLIDE) {
+        if (SLIDE && !TR) {
             xch[tid].x = tid < 128 ? L.x : R[7].x;
             xch[tid].y = tid < 128 ? L.y : R[7].y;
         }
@@ -310,7 +374,8 @@ __global__ void __launch_bounds__(256, 4) stft4096_real_kernel(Params p)
         lds_barrier();
         SGX_STAMP(11)   // barrier 5
         if (SLIDE) {
-            const float2 Y = xch[(tid + 128) & 255];
+            // (TR: column t + 128 is lane ^ 8 of the same wave -- no trip through LDS)
+            const float2 Y = TR ? make_float2(lane_xor8((tid & 8) ? R[7].x : L.x), lane_xor8((tid & 8) ? R[7].y : L.y)) : xch[(tid + 128) & 255];
             // ---- slide the window by two half rows, here: L is dead from now on (the Hann products of this iteration were taken at its top)
 #pragma unroll
             for (int j = 0; j < 6; ++j) R[j] = R[j + 2];
@@ -525,14 +590,15 @@ hipError_t launch_real4096(const sgx_ctx *c, const void *real_tables, Params p, 
     const dim3 grid((unsigned)blocks), block(256);
     auto launch = [&](auto slide_c) {
         constexpr bool S_ = decltype(slide_c)::value;
+        constexpr size_t lds_rows = (S_ && SGX_ADDTID_R) ? kLdsBytesR : kLdsBytes, lds_render = (S_ && SGX_ADDTID_R) ? kLdsBytesRenderR : kLdsBytesRender;
         if (render) {
-            if (!p.seed_pm1) hipLaunchKernelGGL((stft4096_real_kernel<kPixels, kPixGeneric, S_>), grid, block, kLdsBytesRender, c->stream, p);
-            else if (p.interp == SGX_INTERP_COSINE) hipLaunchKernelGGL((stft4096_real_kernel<kPixels, kPixCosine, S_>), grid, block, kLdsBytesRender, c->stream, p);
-            else hipLaunchKernelGGL((stft4096_real_kernel<kPixels, kPixCubic, S_>), grid, block, kLdsBytesRender, c->stream, p);
+            if (!p.seed_pm1) hipLaunchKernelGGL((stft4096_real_kernel<kPixels, kPixGeneric, S_>), grid, block, lds_render, c->stream, p);
+            else if (p.interp == SGX_INTERP_COSINE) hipLaunchKernelGGL((stft4096_real_kernel<kPixels, kPixCosine, S_>), grid, block, lds_render, c->stream, p);
+            else hipLaunchKernelGGL((stft4096_real_kernel<kPixels, kPixCubic, S_>), grid, block, lds_render, c->stream, p);
         } else if (out_f16) {
-            hipLaunchKernelGGL((stft4096_real_kernel<kRowsF16, kPixNone, S_>), grid, block, kLdsBytes, c->stream, p);
+            hipLaunchKernelGGL((stft4096_real_kernel<kRowsF16, kPixNone, S_>), grid, block, lds_rows, c->stream, p);
         } else {
-            hipLaunchKernelGGL((stft4096_real_kernel<kRowsF32, kPixNone, S_>), grid, block, kLdsBytes, c->stream, p);
+            hipLaunchKernelGGL((stft4096_real_kernel<kRowsF32, kPixNone, S_>), grid, block, lds_rows, c->stream, p);
         }
     };
     if (c->H == 256) launch(std::true_type{});

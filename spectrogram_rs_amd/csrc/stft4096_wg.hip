@@ -53,6 +53,34 @@ __device__ unsigned long long g_phase_cycles[20];
 #endif
 
 // PIX: kPixNone = rows (float or half pairs); else the fused pixel path with that pixel code (stft4096_wg.hpp)
+#ifndef SGX_ADDTID
+#define SGX_ADDTID 1   // (0: the (l, r) sliding kernel with the b64 transposes of every other instantiation, for A/B)
+#endif
+// rows q and q + 1 of the real and the imaginary plane, this wave's 64 words of each: LDS address = M0 + offset + 4 * lane
+// (M0 is set inside the statement: the compiler neither knows about nor relies on its value)
+__device__ __forceinline__ void addtid_rows(float2 a, float2 b, uint32_t m0_wave, int q)
+{
+    asm volatile("s_mov_b32 m0, %4\n\t"
+                 "s_nop 0\n\t"            // one wait state between a scalar write of M0 and an add-TID LDS instruction (the compiler does not see into the statement)
+                 "ds_write_addtid_b32 %0 offset:%5\n\t"
+                 "ds_write_addtid_b32 %1 offset:%6\n\t"
+                 "ds_write_addtid_b32 %2 offset:%7\n\t"
+                 "ds_write_addtid_b32 %3 offset:%8"
+                 :
+                 : "v"(a.x), "v"(a.y), "v"(b.x), "v"(b.y), "s"(m0_wave), "i"(1088 * q), "i"(1088 * q + 17408), "i"(1088 * (q + 1)), "i"(1088 * (q + 1) + 17408)
+                 : "memory");
+}
+// the 16 values of this thread's next transform: 16 consecutive words of its row in either plane
+__device__ __forceinline__ void read_planes(const float4 *rd4, float (&xr)[16], float (&xi)[16])
+{
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float4 r = rd4[c], i = rd4[c + 1088];
+        xr[4 * c] = r.x; xr[4 * c + 1] = r.y; xr[4 * c + 2] = r.z; xr[4 * c + 3] = r.w;
+        xi[4 * c] = i.x; xi[4 * c + 1] = i.y; xi[4 * c + 2] = i.z; xi[4 * c + 3] = i.w;
+    }
+}
+
 template <bool MONO, int PAIRING, bool C2, int PIX>
 __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
 {
@@ -65,6 +93,18 @@ __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
     uint2 *pal = reinterpret_cast<uint2 *>(tw2 + 256);          // RENDER only: [256] {threshold, RGBA} (pixel_for)
 
     const int tid = threadIdx.x;
+    constexpr bool kSlide2 = !MONO && C2 && PAIRING == kPairAdjacentRow;   // an (l, r) stream at H = 256: sliding register window
+    // TR: the two LDS transposes as real / imaginary PLANES written with ds_write_addtid_b32 (no address register, 2 cycles per wave and
+    // dword against 6 per ds_write_b64) and read back as 16-byte pieces.  A plane row is the 256 threads of the writing pass in thread
+    // order, 4 words of padding behind every wave (272 words: 16-byte reads of 16 consecutive threads' words are conflict-free within
+    // and across the lane groups of ds_read_b128), so the 16 values a thread of the NEXT pass transforms must sit in 16 consecutive
+    // threads of THIS one: pass 1 runs column t = (tid >> 4) + 16 (tid & 15) instead of t = tid.  Only the sliding window can afford
+    // that: its one 8-byte load per transform is the only one whose lanes then stride 128 bytes.
+    constexpr bool TR = kSlide2 && SGX_ADDTID;
+    const int t_p1 = TR ? (tid >> 4) + 16 * (tid & 15) : tid;     // pass-1 column of this thread
+    float *plane = reinterpret_cast<float *>(smem_raw);           // TR: re [16][272], im [16][272] behind it (34 816 B, the images' bytes)
+    const uint32_t m0_wave = __builtin_amdgcn_readfirstlane((uint32_t)(tid >> 6) * 272u);   // TR: byte offset of this wave inside a plane row
+    const float4 *rd4 = reinterpret_cast<const float4 *>(plane + 272 * (tid >> 4) + 68 * ((tid & 15) >> 2) + 16 * (tid & 3));   // TR: both read sides
     tw2[tid] = p.tw2[tid];
     uint32_t row_words[4] = {0u, 0u, 0u, 0u};  // RENDER: the table words of this thread's rows tid + 256 i
     if (RENDER) {
@@ -82,10 +122,10 @@ __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
     static_assert((kW & (kW - 1)) == 0, "the scale must be a power of two to move it");
     float win[8];
 #pragma unroll
-    for (int a = 0; a < 8; ++a) win[a] = p.window[tid + 256 * a] * inv_w;
+    for (int a = 0; a < 8; ++a) win[a] = p.window[t_p1 + 256 * a] * inv_w;
     float2 tw1[16];
 #pragma unroll
-    for (int q = 1; q < 16; ++q) tw1[q] = p.tw1[q * 256 + tid];
+    for (int q = 1; q < 16; ++q) tw1[q] = p.tw1[q * 256 + t_p1];
 
     const int q1_2 = tid >> 4, t0_2 = tid & 15;                 // pass-2 role
     __syncthreads();
@@ -97,7 +137,6 @@ __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
     // Software pipeline: the samples of transform j+1 are requested while transform j is still in
     // its FFT passes, i.e. BEFORE j's magnitude stores.  vmcnt retires in issue order, so a load
     // issued after 16-32 stores would have to wait for all of them to reach memory first.
-    constexpr bool kSlide2 = !MONO && C2 && PAIRING == kPairAdjacentRow;   // an (l, r) stream at H = 256: sliding register window
     float sa[(MONO && PAIRING == kPairAdjacentRow) ? 9 : 8], sb[8];
     float ld0 = 0.0f, ld1 = 0.0f;   // sliding window: the two rows requested for the next transform
     bool pending = false;
@@ -152,13 +191,13 @@ __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
                     // registers and ONE 8-byte load per thread fetches the new row 7 (round 1 tried this at the register cap and lost 8 %;
                     // the kernel has 15 registers to spare now, and what the seven saved loads relieve is the CU's vector-memory path,
                     // which the row stores share: profiles/r05_k1_stereo.txt)
-                    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r0, tid * 8, 2048 * 7, 0);
+                    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r0, t_p1 * 8, 2048 * 7, 0);
                     ld0 = __uint_as_float(v.x); ld1 = __uint_as_float(v.y);
                     pending = true;
                 } else {
 #pragma unroll
                     for (int a = 0; a < 8; ++a) {
-                        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r0, tid * 8, 2048 * a, 0);
+                        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r0, t_p1 * 8, 2048 * a, 0);
                         sa[a] = __uint_as_float(v.x); sb[a] = __uint_as_float(v.y);
                     }
                 }
@@ -292,8 +331,13 @@ __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
             const int pos = FFT8_OUT[j];
             const float2 ve = make_float2(er[pos], ei[pos]);
             const float2 vo = make_float2(orr[pos], oi[pos]);
-            buf[(2 * j) * kS1 + tid] = j == 0 ? ve : cmulf(ve, tw1[2 * j]);
-            buf[(2 * j + 1) * kS1 + tid] = cmulf(vo, tw1[2 * j + 1]);
+            if (TR) {
+                const float2 a = j == 0 ? ve : cmulf(ve, tw1[2 * j]), b = cmulf(vo, tw1[2 * j + 1]);
+                addtid_rows(a, b, m0_wave, 2 * j);
+            } else {
+                buf[(2 * j) * kS1 + tid] = j == 0 ? ve : cmulf(ve, tw1[2 * j]);
+                buf[(2 * j + 1) * kS1 + tid] = cmulf(vo, tw1[2 * j + 1]);
+            }
         }
         __builtin_amdgcn_s_setprio(0);  // (wave priorities: see the note at the head of the loop)
         SGX_STAMP(2)    // twiddles + image-1 writes (to completion: the stamp drains lgkmcnt)
@@ -304,9 +348,11 @@ __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
         float xr[16], xi[16];
 #pragma unroll
         for (int t1 = 0; t1 < 16; ++t1) {
+            if (TR) break;
             const float2 v = buf[q1_2 * kS1 + t0_2 + 16 * t1];
             xr[t1] = v.x; xi[t1] = v.y;
         }
+        if (TR) read_planes(rd4, xr, xi);
         fft16(xr, xi);
         if (!MONO) __builtin_amdgcn_s_setprio(RENDER ? 2 : SGX_PRIO_A);   // (fused (l, r) pixels: 2 / 2 measured 3 % ahead of 1 / 2, rows the other way round)
         SGX_STAMP(4)    // image-1 reads + FFT16
@@ -316,7 +362,15 @@ __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
         for (int q2 = 0; q2 < 16; ++q2) {
             const int pos = FFT16_OUT[q2];
             const float2 v = make_float2(xr[pos], xi[pos]);
-            buf[t0_2 * kS2 + q1_2 + 16 * q2] = q2 == 0 ? v : cmulf(v, tw2[q2 * 16 + t0_2]);
+            if (!TR) buf[t0_2 * kS2 + q1_2 + 16 * q2] = q2 == 0 ? v : cmulf(v, tw2[q2 * 16 + t0_2]);
+        }
+        if (TR) {
+#pragma unroll
+            for (int q2 = 0; q2 < 16; q2 += 2) {
+                const int pa = FFT16_OUT[q2], pb2 = FFT16_OUT[q2 + 1];
+                const float2 va = make_float2(xr[pa], xi[pa]), vb = make_float2(xr[pb2], xi[pb2]);
+                addtid_rows(q2 == 0 ? va : cmulf(va, tw2[q2 * 16 + t0_2]), cmulf(vb, tw2[(q2 + 1) * 16 + t0_2]), m0_wave, q2);
+            }
         }
         if (!MONO) __builtin_amdgcn_s_setprio(SGX_PRIO_B);
         SGX_STAMP(6)    // twiddles (LDS reads) + image-2 writes
@@ -326,9 +380,11 @@ __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
         // ---- pass 3: thread u = q1 + 16 q2: 16-point FFT over t0 -> bins k = u + 256 q3
 #pragma unroll
         for (int t0 = 0; t0 < 16; ++t0) {
+            if (TR) break;
             const float2 v = buf[t0 * kS2 + col];
             xr[t0] = v.x; xi[t0] = v.y;
         }
+        if (TR) read_planes(rd4, xr, xi);
         fft16(xr, xi);
         if (job + 1 < job_end) fetch(job + 1, true);  // ahead of this transform's stores (see above)
         if (RENDER) __builtin_amdgcn_s_setprio(1);  // the pixel passes are long: 3 only from the row pass (the pixel stores) on

@@ -11,6 +11,7 @@ FLAGS="-O3 -std=c++17 -fPIC -fvisibility=hidden -ffp-contract=off -fno-slp-vecto
 /opt/rocm/bin/hipcc $FLAGS "$@" -c ${SRC:-stft4096_wg.hip} -o build/ab/$name.o
 /opt/rocm/bin/hipcc $FLAGS "$@" -S --cuda-device-only ${SRC:-stft4096_wg.hip} -o build/ab/$name.s 2>/dev/null
 if grep -q buffer_store_dwordx4 build/ab/$name.s; then python3 ../../tools/isa_check_store16.py build/ab/$name.s; fi
+if grep -q addtid build/ab/$name.s; then python3 ../../tools/isa_check_addtid.py build/ab/$name.s; fi
 objs=$(ls build/*.o | grep -v ${SRC:-stft4096_wg.hip}.o)
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -o ../ab/$name.so $objs build/ab/$name.o
 echo built ../ab/$name.so

@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Build-time check on device assembly: the hardware wants one wait state between a scalar write of M0 and an LDS add-TID instruction
+(ds_write_addtid_b32 / ds_read_addtid_b32 take their base from M0), and the compiler cannot see into the inline statements that issue
+them (stft4096_wg.hip, stft4096_real.hip: the plane transposes).  Without it the FIRST transpose write of a wave used the M0 it was
+launched with: the first transform of every workgroup wrong now and then (round 5).  Also fails if anything between two such statements
+writes M0 to something the next add-TID would inherit.  usage: isa_check_addtid.py file.s ..."""
+import re
+import sys
+
+bad = total = 0
+for path in sys.argv[1:]:
+    since_m0 = None   # instructions issued since the last scalar write of M0 (None: M0 never written in this function)
+    for n, line in enumerate(open(path), 1):
+        t = line.strip()
+        if not t or t.startswith((";", "//", ".")) or t.endswith(":"):
+            if t.endswith(":") and not t.startswith(".L"):
+                since_m0 = None
+            continue
+        op = t.split()[0]
+        if re.match(r"s_\w+\s+m0\b", t):
+            since_m0 = 0
+            continue
+        if "addtid" in op:
+            total += 1
+            if since_m0 is None or since_m0 < 1:
+                bad += 1
+                print("%s:%d: %s -- %s" % (path, n, t, "M0 never set in this function" if since_m0 is None else "no wait state behind the write of M0"))
+        if since_m0 is not None:
+            since_m0 += 1
+print("isa_check_addtid: %d add-TID instruction(s) checked, %d problem(s)" % (total, bad))
+sys.exit(1 if bad else 0)
