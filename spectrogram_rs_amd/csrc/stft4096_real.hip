@@ -52,6 +52,9 @@ using wg::kS1;
 using wg::kS2;
 using wg::kW;
 using wg::lds_barrier;
+using wg::lds_read_alone;
+using wg::lds_cfloat2;
+using wg::lds_ptr;
 using wg::pcm_rsrc;
 using wg::u32x2;
 
@@ -325,11 +328,12 @@ __global__ void __launch_bounds__(256, 4) stft4096_real_kernel(Params p)
             if (!TR) buf[t0_2 * kS2 + cbase2 + 8 * q2] = q2 == 0 ? v : cmulf(v, tw2[q2 * 16 + t0_2]);
         }
         if (TR) {
+            lds_cfloat2 *tw2p = lds_ptr(tw2 + t0_2);
 #pragma unroll
             for (int q2 = 0; q2 < 16; q2 += 2) {
                 const int pa = FFT16_OUT[q2], pb = FFT16_OUT[q2 + 1];
                 const float2 va = make_float2(xr[pa], xi[pa]), vb = make_float2(xr[pb], xi[pb]);
-                addtid_rows<280>(q2 == 0 ? va : cmulf(va, tw2[q2 * 16 + t0_2]), cmulf(vb, tw2[(q2 + 1) * 16 + t0_2]), m0_wave, q2, q2 + 1);
+                addtid_rows<280>(q2 == 0 ? va : cmulf(va, lds_read_alone(tw2p, q2 * 16)), cmulf(vb, lds_read_alone(tw2p, (q2 + 1) * 16)), m0_wave, q2, q2 + 1);
             }
         }
         SGX_STAMP(6)    // pass-2 twiddles + image-2 writes

@@ -365,11 +365,12 @@ __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
             if (!TR) buf[t0_2 * kS2 + q1_2 + 16 * q2] = q2 == 0 ? v : cmulf(v, tw2[q2 * 16 + t0_2]);
         }
         if (TR) {
+            lds_cfloat2 *tw2p = lds_ptr(tw2 + t0_2);
 #pragma unroll
             for (int q2 = 0; q2 < 16; q2 += 2) {
                 const int pa = FFT16_OUT[q2], pb2 = FFT16_OUT[q2 + 1];
                 const float2 va = make_float2(xr[pa], xi[pa]), vb = make_float2(xr[pb2], xi[pb2]);
-                addtid_rows(q2 == 0 ? va : cmulf(va, tw2[q2 * 16 + t0_2]), cmulf(vb, tw2[(q2 + 1) * 16 + t0_2]), m0_wave, q2);
+                addtid_rows(q2 == 0 ? va : cmulf(va, lds_read_alone(tw2p, q2 * 16)), cmulf(vb, lds_read_alone(tw2p, (q2 + 1) * 16)), m0_wave, q2);
             }
         }
         if (!MONO) __builtin_amdgcn_s_setprio(SGX_PRIO_B);
