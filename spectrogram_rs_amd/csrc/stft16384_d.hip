@@ -81,6 +81,20 @@ __device__ __forceinline__ float2 cmulf(float2 a, float2 b)
 {
     return make_float2(fmaf(a.x, b.x, -(a.y * b.y)), fmaf(a.x, b.y, a.y * b.x));
 }
+// An 8-byte LDS read that stays one (stft4096_wg.hpp: a merged ds_read2_b64 / ds_read2st64_b64 holds the LDS pipe for 8 cycles, two
+// ds_read_b64 for 2 each): the empty statement makes the base a new value for every read.
+#ifndef SGX_NO_READ2
+#define SGX_NO_READ2 55   // (every site but the recombination twiddles: there the separate reads cost two spilled registers)
+#endif
+typedef const f2v __attribute__((address_space(3))) lds_cfloat2;
+__device__ __forceinline__ lds_cfloat2 *lds_ptr(const float2 *p) { return (lds_cfloat2 *)p; }
+template <int SITE>   // (one bit of SGX_NO_READ2 per read site, for A/B)
+__device__ __forceinline__ float2 lds_read_alone(lds_cfloat2 *&base, int idx)
+{
+    if ((SGX_NO_READ2 >> SITE) & 1) asm("" : "+v"(base));
+    const f2v v = base[idx];
+    return make_float2(v.x, v.y);
+}
 // the value of another lane of the quad
 template <int PERM>
 __device__ __forceinline__ float quad(float v)
@@ -270,14 +284,15 @@ __global__ void __launch_bounds__(1024, 1) stft16384_d_kernel(Params p)
     static_assert(kStage + 2 * kRegion <= kBufComplex, "the staged row must fit behind the partner slots");
     struct Pending { long long f0, f1; uint32_t pair; bool have_first, have_second, valid; } prev{0, 0, 0, false, false, false};
     auto flush = [&](const Pending &o) {
-        const float2 *stage = buf + kStage;
+        lds_cfloat2 *stage = lds_ptr(buf + kStage);
         // rows: bin k lives at byte 8 (k - 1) of its row
         const __amdgpu_buffer_rsrc_t r0 = uniform_rsrc(p.mags + (((size_t)(o.have_first ? o.f0 : 0) * p.pairs + o.pair) * (size_t)kM) * 2);
         const __amdgpu_buffer_rsrc_t r1 = uniform_rsrc(p.mags + (((size_t)o.f1 * p.pairs + o.pair) * (size_t)kM) * 2);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int c = tid + 1024 * i;           // bins 2 c, 2 c + 1 (0-based); the last piece of the row holds one bin
-            const float2 ev = stage[stage_index(c)], od = stage[kRegion + stage_index(c)];   // bins 2 c and 2 c + 1
+            lds_cfloat2 *sc = stage + stage_index(c);
+            const float2 ev = lds_read_alone<4>(sc, 0), od = lds_read_alone<4>(sc, kRegion);   // bins 2 c and 2 c + 1
             const float4 v = make_float4(ev.x, ev.y, od.x, od.y);
             if (!D_STORE_OK(v.x)) continue;
             const bool whole = c != 4095;
@@ -363,10 +378,10 @@ __global__ void __launch_bounds__(1024, 1) stft16384_d_kernel(Params p)
         float xr[16], xi[16];
         {
             const int q1_2 = tid >> 6, low = tid & 63;   // low = 4 t0 + r
-            const float2 *r2 = buf + 4 * q1_2 * kS1 + low;
+            lds_cfloat2 *r2 = lds_ptr(buf + 4 * q1_2 * kS1 + low);
 #pragma unroll
             for (int t1 = 0; t1 < 16; ++t1) {
-                const float2 v = r2[64 * t1];
+                const float2 v = lds_read_alone<0>(r2, 64 * t1);
                 xr[t1] = v.x; xi[t1] = v.y;
             }
             fft16(xr, xi);
@@ -376,22 +391,22 @@ __global__ void __launch_bounds__(1024, 1) stft16384_d_kernel(Params p)
             // the pass-3 thread (q1, q2, r) -- LDS instructions of one wave execute in order, so neither the overwrite nor the read-back
             // needs a workgroup barrier, and the sixteen waves drift apart through two of the three FFT passes.
             float2 *w2 = buf + 4 * q1_2 * kS1 + low;
-            const float2 *tw = tw2 + low;
+            lds_cfloat2 *tw = lds_ptr(tw2 + low);
 #pragma unroll
             for (int q2 = 0; q2 < 16; ++q2) {
                 const int pos = FFT16_OUT[q2];
                 const float2 v = make_float2(xr[pos], xi[pos]);
-                w2[68 * q2] = q2 == 0 ? v : cmulf(v, tw[64 * q2]);
+                w2[68 * q2] = q2 == 0 ? v : cmulf(v, lds_read_alone<1>(tw, 64 * q2));
             }
         }
         SGX_STAMP(8)    // pass-2 twiddles + writes (to completion)
 
         // ---- pass 3: lane (q1, q2, r) = (wave, (tid >> 2) & 15, tid & 3), i.e. u = q1 + 16 q2: FFT16 over t0 -> q3
         {
-            const float2 *r3 = buf + 4 * (tid >> 6) * kS1 + 68 * ((tid >> 2) & 15) + (tid & 3);
+            lds_cfloat2 *r3 = lds_ptr(buf + 4 * (tid >> 6) * kS1 + 68 * ((tid >> 2) & 15) + (tid & 3));
 #pragma unroll
             for (int t0 = 0; t0 < 16; ++t0) {
-                const float2 v = r3[4 * t0];
+                const float2 v = lds_read_alone<2>(r3, 4 * t0);
                 xr[t0] = v.x; xi[t0] = v.y;
             }
         }
@@ -408,12 +423,13 @@ __global__ void __launch_bounds__(1024, 1) stft16384_d_kernel(Params p)
         //      Registers q3 >= 8 ("hi"): the same with the roles of the lane halves exchanged (stage A: lanes 0, 1: own - partner;
         //        lanes 2, 3: own + partner -> O0, O1, E0, E1; lane 1 turns O1; stage B: lanes 0, 2: own - partner; lanes 1, 3: own +
         //        partner) -> c = 3, 1, 2, 0 in lanes 0, 1, 2, 3: every lane ends with kept bins in one half and partners in the other.
+        lds_cfloat2 *tw3p = lds_ptr(tw3 + L);
 #pragma unroll
         for (int q3 = 0; q3 < 16; ++q3) {
             const int pos = FFT16_OUT[q3];
             float ar = xr[pos], ai = xi[pos];
             if (q3 > 0) {
-                const float2 t = tw3[4 * q3 + L];
+                const float2 t = lds_read_alone<3>(tw3p, 4 * q3);
                 const float br = fmaf(ar, t.x, -(ai * t.y)), bi = fmaf(ar, t.y, ai * t.x);
                 ar = br; ai = bi;
             }
@@ -457,7 +473,7 @@ __global__ void __launch_bounds__(1024, 1) stft16384_d_kernel(Params p)
         //      quad: lane 2 (k = 4096) <- lane 3's slot 0; lanes 1, 3 (k = 6144, 2048) <- slot 0 of lanes 2, 0
         const int u = (tid >> 6) + 16 * ((tid >> 2) & 15);
         const int up = 256 - u, pslot = 4 * (up & 15) + 68 * ((up >> 4) & 15) + L;   // (u = 0: unused)
-        const float2 *pp = buf + (u == 0 ? 1088 + L : pslot);                                  // + 1088 (7 - qq), qq >= 1
+        lds_cfloat2 *pp = lds_ptr(buf + (u == 0 ? 1088 + L : pslot));                          // + 1088 (7 - qq), qq >= 1
         const float2 *pp0 = buf + (u == 0 ? (L == 2 ? 3 : (L == 1 ? 2 : 0)) : 1088 * 7 + pslot);   // qq = 0
         const int kbase = (L == 0 ? 0 : (L == 1 ? 6144 : (L == 2 ? 4096 : 2048))) + u;        // bin k = kbase + 256 qq
         // The row is put together in LDS and leaves as 16 bytes per lane, consecutive lanes consecutive addresses: a wave of this
@@ -470,7 +486,7 @@ __global__ void __launch_bounds__(1024, 1) stft16384_d_kernel(Params p)
 #pragma unroll
         for (int qq = 0; qq < 8; ++qq) {
             const int pos = FFT16_OUT[qq];
-            const float2 pv = qq == 0 ? pp0[0] : pp[1088 * (7 - qq)];
+            const float2 pv = qq == 0 ? pp0[0] : lds_read_alone<5>(pp, 1088 * (7 - qq));
             const float ar = xr[pos], ai = xi[pos];
             const float sr_ = ar + pv.x, si_ = ai - pv.y;   // a + conj(b) = 2 L^
             const float dr_ = ar - pv.x, di_ = ai + pv.y;   // a - conj(b) = 2i R^
