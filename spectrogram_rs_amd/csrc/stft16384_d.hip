@@ -483,6 +483,7 @@ __global__ void __launch_bounds__(1024, 1) stft16384_d_kernel(Params p)
         // partner slots and the first eight rows of the next image (no barrier between the partner reads and these writes);
         // bin k at stage_slot(k - 1).  The row is read back and stored by the next iteration (`flush`).
         float2 *stage = buf + kStage;
+        float2 *st1 = stage + stage_slot(kbase + 255);
 #pragma unroll
         for (int qq = 0; qq < 8; ++qq) {
             const int pos = FFT16_OUT[qq];
@@ -493,8 +494,11 @@ __global__ void __launch_bounds__(1024, 1) stft16384_d_kernel(Params p)
             const float ml = __builtin_amdgcn_sqrtf(fmaf(sr_, sr_, si_ * si_));  // the scale 1 / W rides on the window
             const float mr = __builtin_amdgcn_sqrtf(fmaf(dr_, dr_, di_ * di_));
             const bool dc = qq == 0 && tid == 0;   // k = 0 (DC) is not an output (fft.rs:81)
-            const int b = kbase + 256 * qq - 1;     // 0-based bin
-            if (!dc) stage[stage_slot(b)] = make_float2(ml, mr);
+            // 0-based bin b = kbase + 256 qq - 1.  For qq >= 1 the swizzle bits of stage_slot (bit 5 and bits 11, 12 of b) do not depend on
+            // qq, and it only touches the low three index bits: slot(qq) = slot(1) + 128 (qq - 1) -- one address, seven immediates, instead
+            // of eight swizzles (~70 vector instructions per transform)
+            if (qq == 0) { if (!dc) stage[stage_slot(kbase - 1)] = make_float2(ml, mr); }
+            else st1[128 * (qq - 1)] = make_float2(ml, mr);
         }
         SGX_STAMP(14)   // partner reads + split + staging writes
         prev = Pending{f0, f1, pair, have_first, have_second, true};

@@ -8,6 +8,15 @@ import re
 import sys
 
 bad = total = 0
+_addtid_files = {}
+
+
+def uses_addtid(path):
+    if path not in _addtid_files:
+        _addtid_files[path] = "addtid" in open(path).read()
+    return _addtid_files[path]
+
+
 for path in sys.argv[1:]:
     since_m0 = None   # instructions issued since the last scalar write of M0 (None: M0 never written in this function)
     for n, line in enumerate(open(path), 1):
@@ -19,7 +28,13 @@ for path in sys.argv[1:]:
         op = t.split()[0]
         if re.match(r"s_\w+\s+m0\b", t):
             since_m0 = 0
+            last_m0_write = (path, n, t)
             continue
+        if re.search(r"\bm0\b", t) and uses_addtid(path):
+            # anything else that reads or writes M0 in a file whose kernels issue add-TID stores: the statements set M0 behind the
+            # compiler's back, so compiler-generated users of M0 (s_movrel, LDS-DMA, readlane by M0 ...) must not exist beside them
+            bad += 1
+            print("%s:%d: %s -- another user of M0 beside the add-TID statements" % (path, n, t))
         if "addtid" in op:
             total += 1
             if since_m0 is None or since_m0 < 1:
