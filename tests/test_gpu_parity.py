@@ -465,6 +465,12 @@ def test_full_size_properties(torch_cuda, mags_err):
     half *= 2.0
     assert bool(torch.equal(half, mags))
     del half
+    # the first transform of a workgroup's run is a transform like any other: a shorter launch that starts one frame on has ~1000 run
+    # starts of its own, every one of them the middle of a run of the full launch -- same bytes (this is what catches state a kernel
+    # carries into its loop: registers, LDS, M0)
+    shifted = eng.stft_batch(pcm, first_frame=1, max_frames=200_000)
+    assert bool(torch.equal(shifted, mags[1:200_001]))
+    del shifted
     # Parseval per frame: sum_k (m_k W/2)^2 over k=1..W-1 vs the windowed energy (DC/Nyquist excluded: loose bound)
     win = torch.from_numpy(eng.window()).cuda()
     idx = torch.arange(W, device="cuda")[None, :] + (torch.tensor(ts, device="cuda") * H)[:, None]
@@ -515,6 +521,10 @@ def test_full_size_stereo_properties(torch_cuda, mags_err):
     half *= 2.0
     assert bool(torch.equal(half, mags))
     del half
+    # run starts of a shorter, shifted launch against the middle of the full launch's runs (see test_full_size_properties)
+    shifted = eng.stft_batch(pcm, first_frame=1, max_frames=200_000)
+    assert bool(torch.equal(shifted, mags[1:200_001]))
+    del shifted
     a = eng.checksum(mags)
     del mags
     lo = eng.stft_batch(pcm, first_frame=0, max_frames=333_333)
@@ -598,6 +608,10 @@ def test_full_size_pixel_properties(torch_cuda, gradients, interp):
     assert len(diff) <= 2e-3 * got.shape[0] * R and (not steps or max(steps) <= 1), (len(diff), max(steps or [0]))
     assert (got[..., 3] == 255).all()
     del host
+    # run starts of a shorter, shifted launch against the middle of the full launch's runs (see test_full_size_properties)
+    shifted = eng.render_batch(pcm, first_frame=1, max_frames=200_000)
+    assert bool(torch.equal(shifted, px[1:200_001]))
+    del shifted
     # determinism and shard-independence of the bytes
     a = eng.checksum(px)
     del px
