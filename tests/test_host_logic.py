@@ -331,3 +331,20 @@ def test_integration_md_shows_the_binding_files_verbatim():
     for name in os.listdir(os.path.join(root, "bindings", "rust")):
         text = open(os.path.join(root, "bindings", "rust", name)).read()
         assert "todo!" not in text and "unimplemented!" not in text, name
+
+
+def test_plane_transposes_read_conflict_free_at_the_strides_the_kernels_use():
+    # the 16-byte read sides of the LDS plane transposes (stft4096_wg.hip, stft4096_real.hip: `TR`) against the bank model of
+    # tools/lds_b128_conflicts.py: one lane per bank in every lane group -- and the strides the model assumes are the kernels'
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("lds_b128_conflicts", os.path.join(root, "tools", "lds_b128_conflicts.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    for name, w in mod.shipped():
+        assert w == 1, name
+    real = open(os.path.join(root, "spectrogram_rs_amd", "csrc", "stft4096_real.hip")).read()
+    wg = open(os.path.join(root, "spectrogram_rs_amd", "csrc", "stft4096_wg.hip")).read()
+    assert "addtid_rows<272>" in real and "addtid_rows<280>" in real
+    assert "plane + 272 * (tid >> 4) + 68 * ((tid & 15) >> 2) + 16 * (tid & 3)" in real and "plane + 272 * (tid >> 4) + 68 * ((tid & 15) >> 2) + 16 * (tid & 3)" in wg
+    assert "plane + 280 * ((tid & 127) >> 3) + 68 * ((8 * (tid >> 7) + (tid & 7)) >> 2) + 16 * (tid & 3)" in real

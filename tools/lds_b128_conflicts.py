@@ -26,10 +26,20 @@ def pos(writer_tid, pad=68):            # word of a writer thread inside a plane
     return pad * (writer_tid >> 6) + (writer_tid & 63)
 
 
-# K1 (4096 points): both read sides are row tid >> 4, the 16 words of writer threads 16 (tid & 15) .. + 15
-print("K1  image 1 / 2, row stride 272:", worst(lambda tid: 272 * (tid >> 4) + pos(16 * (tid & 15))))
-# K1R image 1: the same shape (rows 8 F + q1)
-print("K1R image 1, row stride 272    :", worst(lambda tid: 272 * (tid >> 4) + pos(16 * (tid & 15))))
-# K1R image 2: reader tid = 128 F + q1 + 8 q2 reads row q2, writer threads 16 (8 F + q1) .. + 15
-for stride in (272, 276, 280, 288):
-    print("K1R image 2, row stride %d    :" % stride, worst(lambda tid: stride * ((tid & 127) >> 3) + pos(16 * (8 * (tid >> 7) + (tid & 7)))))
+def shipped():
+    """(name, worst lanes per bank) for every 16-byte read side the kernels ship"""
+    return [
+        # K1 (4096 points): both read sides are row tid >> 4, the 16 words of writer threads 16 (tid & 15) .. + 15
+        ("K1 image 1 / 2, row stride 272", worst(lambda tid: 272 * (tid >> 4) + pos(16 * (tid & 15)))),
+        # K1R image 1: the same shape (rows 8 F + q1)
+        ("K1R image 1, row stride 272", worst(lambda tid: 272 * (tid >> 4) + pos(16 * (tid & 15)))),
+        # K1R image 2: reader tid = 128 F + q1 + 8 q2 reads row q2, writer threads 16 (8 F + q1) .. + 15
+        ("K1R image 2, row stride 280", worst(lambda tid: 280 * ((tid & 127) >> 3) + pos(16 * (8 * (tid >> 7) + (tid & 7))))),
+    ]
+
+
+if __name__ == "__main__":
+    for name, w in shipped():
+        print("%-34s: %d" % (name, w))
+    for stride in (272, 276, 288):   # what K1R's second image would do at other strides
+        print("K1R image 2, row stride %d (not used): %d" % (stride, worst(lambda tid: stride * ((tid & 127) >> 3) + pos(16 * (8 * (tid >> 7) + (tid & 7))))))
