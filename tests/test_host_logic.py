@@ -337,6 +337,7 @@ def test_plane_transposes_read_conflict_free_at_the_strides_the_kernels_use():
     # the 16-byte read sides of the LDS plane transposes (stft4096_wg.hip, stft4096_real.hip: `TR`) against the bank model of
     # tools/lds_b128_conflicts.py: one lane per bank in every lane group -- and the strides the model assumes are the kernels'
     import importlib.util
+    import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     spec = importlib.util.spec_from_file_location("lds_b128_conflicts", os.path.join(root, "tools", "lds_b128_conflicts.py"))
     mod = importlib.util.module_from_spec(spec)
