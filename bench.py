@@ -321,7 +321,10 @@ def main_rank(args):
     if os.environ.get("BENCH_SINGLE_DEVICE") == "1":
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # BENCH_GROUP_OF_ONE=1 (tests/test_gpu_config5.py, one-GPU box): a single launched rank takes the multi-rank path -- process group
+    # over `backend` (RCCL: init, barrier, all-reduce, all-gather execute for real; it refuses two ranks on one device), config-5 leg
+    grouped = world > 1 or (os.environ.get("BENCH_GROUP_OF_ONE") == "1" and "RANK" in os.environ)
+    if grouped:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
@@ -334,12 +337,12 @@ def main_rank(args):
     red_dev = torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")
 
     def barrier():
-        if world > 1:
+        if grouped:
             dist.barrier()
 
     def max_over_ranks(vals):
         t = torch.tensor(vals, dtype=torch.float64, device=red_dev)
-        if world > 1:
+        if grouped:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return [float(x) for x in t]
 
@@ -480,10 +483,10 @@ def main_rank(args):
     extra = {}
     watchdog = threading.Timer(args.leg_timeout, on_stall)
     watchdog.daemon = True
-    if world > 1:
+    if grouped:
         watchdog.start()
     try:
-        if world == 1:
+        if not grouped:
             del mags
             torch.cuda.empty_cache()
             if args.pixel_frames > 0:
@@ -516,13 +519,13 @@ def main_rank(args):
     watchdog.cancel()
 
     # ---- CPU baseline: the oracle on this host's cores (rank 0, N = 1 only) ------------------------
-    if rank == 0 and world == 1 and args.cpu_frames > 0:
+    if rank == 0 and not grouped and args.cpu_frames > 0:
         if pcm is None:
             pcm = eng.white_noise(W + 63 * H)     # the parity check of the leg reads the first 64 frames
         extra["cpu_baseline"] = cpu_baseline_leg(args, eng, pcm)
     if rank == 0:
         print(json.dumps(build_line(extra)), flush=True)
-    if world > 1:
+    if grouped:
         dist.destroy_process_group()
     return 0
 

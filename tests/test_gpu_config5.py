@@ -62,3 +62,27 @@ def test_config5_leg_a_rank_dying_inside_the_leg_fails_the_run():
     for ln in p.stdout.splitlines():
         if ln.startswith("{"):                 # rank 0 may still report: then the line says what happened
             assert "error" in json.loads(ln)
+
+
+def test_config5_leg_one_rank_over_rccl():
+    # RCCL itself on the box's one MI355X: a single launched rank (RANK / WORLD_SIZE as torch.distributed.run sets them) takes the
+    # multi-rank path of bench.py with the default backend -- process group init with device_id, barriers, the MAX all-reduce of the
+    # timings, the all-gather of the ranks -- and the config-5 leg with itself as the root.  (Two ranks on one device: RCCL answers
+    # "invalid usage", tools/rccl_probe.py.)  What an 8-GPU node adds is the point-to-point gather between devices.
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29581", BENCH_GROUP_OF_ONE="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    for k in ("BENCH_BACKEND", "BENCH_SINGLE_DEVICE", "BENCH_LAUNCH_ONLY"):
+        env.pop(k, None)
+    total = 100_001
+    argv = ["--gpus", "1", "--steps", "2", "--warmup", "1", "--frames", "65536", "--placements", "1", "--sustain-s", "0",
+            "--config5-frames", str(total), "--config5-chunk", str(CHUNK), "--leg-timeout", "120"]
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-4000:])
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert "error" not in line, line.get("error")
+    c5 = line["config5"]
+    assert c5["backend"] == "nccl" and c5["ranks_seen"] == [0]
+    assert c5["frames_total"] == total and c5["frames_per_gpu"] == [total] and c5["gathered_bytes"] == 0
+    assert c5["checksum_all_columns"] == single_process_checksum(total, 50_000)
