@@ -71,7 +71,7 @@ KERNEL_NAMES = {
     5: ("stft16384 as four 4096-point residues (512 threads = 256 lane pairs, DPP decimation)", "sgx::q16k::stft16384_q_kernel<false, true>"),
     6: ("mixed radix at the window's own length (compile-time plan)", "sgx::mix::stft_mixed_fixed_kernel"),
     8: ("stft16384 as four time-decimated 4096-point transforms in the lanes of a quad (1024 threads per transform, DPP recombination)",
-        "sgx::d16k::stft16384_d_kernel<false>"),
+        "sgx::d16k::stft16384_d_kernel<false, false>"),
     9: ("stft4800 workgroup-per-transform (320 threads, 16 x 20 x 15, resident twiddles, mono frame pairs)", "sgx::w48::stft4800_wg_kernel<0, false>"),
 }
 
@@ -880,7 +880,7 @@ def config4_leg(args, torch, device):
             "kernel": name[1],
             "first_allocation": first_allocation_of(torch, first, m, lambda buf: eng.stft_batch(pcm, out=buf), hops * ALGO_BYTES_CFG4, args),
             "placement": placement,
-            "note": "launch = the de-interleave pass + the transform kernel (both inside the timed call)",
+            "note": "launch = the de-interleave pass + the transform kernel (both inside the timed call); SGX_FLAG_DIRECT_CHANNELS reads the pairs where they lie instead: traffic = algorithmic, 2 % slower",
         },
     }
 

@@ -60,8 +60,9 @@ constexpr int kBufComplex = 4 * kImg;    // 17 408 complex = 139 264 B, the four
 constexpr size_t kLdsBytes = (size_t)(kBufComplex + 1024 + 64) * sizeof(float2);   // + tw2 [q2][t0][r], tw3 [q3][r]
 
 struct Params {
-    const float *pcm;        // MONO: [n] floats; else per-pair planes of (l, r): plane p starts at pcm + p * plane_floats
+    const float *pcm;        // MONO: [n] floats; DIRECT: the interleaved stream [n][C]; else per-pair planes of (l, r): plane p starts at pcm + p * plane_floats
     size_t plane_floats;
+    uint32_t stride_floats;  // DIRECT: floats from one sample of a pair to the next (the stream's channel count)
     long long sample_base;   // absolute sample index of pcm[0] (the de-interleaved workspace holds a sub-range)
     const float2 *T1;        // [16][1024]  w_16384^{q1 tid} at [q1][tid]
     const float2 *tw2;       // [16][16][4] w_1024^{q2 (4 t0 + r)} at [q2][t0][r]
@@ -165,7 +166,13 @@ __device__ unsigned long long g_phase_cycles16[24];
 #define SGX_STAMP(i)
 #endif
 
-template <bool MONO>
+// DIRECT: more than two interleaved channels, pair p = channels (2 p, 2 p + 1), read where they lie: 8-byte loads at a stride of C floats.
+// A wave's load then touches 64 x 4 C bytes instead of 512 contiguous ones (+4 % on this kernel at C = 8: 16 lines per load for 4), but
+// the four pairs of a hop position run on CUs of one XCD at the same time and share the lines in its L2 -- and the pass that used to split
+// the stream into (l, r) planes first (0.125 x the algorithmic bytes written and read back, 4.6 % of the launch, a workspace of the
+// stream's size grown on the first call) is not needed: HBM traffic 1.15 -> 1.0x x algorithmic, nothing allocated on the call -- for 2 %
+// of the time (same device 2.41-2.46 -> 2.47-2.50 ms per 80 000 transforms), which is why it is the opt-in (SGX_FLAG_DIRECT_CHANNELS).
+template <bool MONO, bool DIRECT = false>
 __global__ void __launch_bounds__(1024, 1) stft16384_d_kernel(Params p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -212,6 +219,8 @@ __global__ void __launch_bounds__(1024, 1) stft16384_d_kernel(Params p)
             const unsigned long long f = 2 * (p.pair_base + job);
             j.data_second = f + 1 < p.total_frames;
             j.base = p.pcm + ((long long)(f * p.H) - p.sample_base);
+        } else if (DIRECT) {
+            j.base = p.pcm + (size_t)((p.first_frame + hop) * p.H) * p.stride_floats + 2 * pair;
         } else {
             j.base = p.pcm + (size_t)pair * p.plane_floats + 2 * ((long long)((p.first_frame + hop) * p.H) - p.sample_base);
         }
@@ -221,6 +230,8 @@ __global__ void __launch_bounds__(1024, 1) stft16384_d_kernel(Params p)
     auto prefetch = [&](const JobIn &j) {
         const __amdgpu_buffer_rsrc_t rs = uniform_rsrc(j.base);
         const int sec = j.data_second ? second_off : 0;
+        const int lane_bytes = DIRECT ? (int)(4u * p.stride_floats) * tid : 8 * tid;                  // one sample of the pair per lane
+        const int row_bytes = DIRECT ? (int)(4096u * p.stride_floats) : 8192;                        // 1024 samples on
 #pragma unroll
         for (int a = 0; a < 8; ++a) {
 #ifdef D_ABL_NOLOAD
@@ -231,7 +242,7 @@ __global__ void __launch_bounds__(1024, 1) stft16384_d_kernel(Params p)
                 pl[a] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, 4 * tid, 4096 * a, 0));
                 pr[a] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, 4 * tid, 4096 * a + sec, 0));
             } else {
-                const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, 8 * tid, 8192 * a, 0);
+                const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, lane_bytes, row_bytes * a, 0);
                 pl[a] = __uint_as_float(v.x); pr[a] = __uint_as_float(v.y);
             }
 #endif
@@ -628,7 +639,10 @@ hipError_t launch_stft_d16384(const sgx_ctx *c, void *tables, const float *d_pcm
     const bool dup = channels == 1 && !mono;
     p.pair_base = mono ? first_frame / 2 : 0;
     p.n_jobs = mono ? (first_frame + n_frames + 1) / 2 - first_frame / 2 : (unsigned long long)n_frames * pairs;
-    if (channels > 2 || dup) {
+    // more than two channels: the sample range of the call split into per-pair (l, r) planes first (the default: 2 % faster), or -- under
+    // SGX_FLAG_DIRECT_CHANNELS -- every pair read where it lies (no workspace, no second kernel, HBM traffic = algorithmic)
+    const bool direct = channels > 2 && (c->cfg.flags & SGX_FLAG_DIRECT_CHANNELS);
+    if ((channels > 2 && !direct) || dup) {
         // per-pair planes of the sample range these frames read: [first_frame H, (first_frame + n - 1) H + W)
         const size_t first_sample = first_frame * (size_t)c->H;
         const size_t n_samp = (n_frames - 1) * (size_t)c->H + kW;
@@ -657,6 +671,7 @@ hipError_t launch_stft_d16384(const sgx_ctx *c, void *tables, const float *d_pcm
         p.pcm = d_pcm;
         p.plane_floats = 0;
         p.sample_base = 0;
+        p.stride_floats = channels;
     }
     // persistent workgroups, one per CU (145 KB of LDS); jobs are dealt round-robin in output-row order
     unsigned long long blocks = (unsigned long long)c->n_cu;
@@ -666,6 +681,7 @@ hipError_t launch_stft_d16384(const sgx_ctx *c, void *tables, const float *d_pcm
     p.jobs_per_xcd = ((p.n_jobs + p.xcds - 1) / p.xcds + group - 1) / group * group;
     const dim3 grid((unsigned)blocks), block(1024);
     if (mono) hipLaunchKernelGGL((stft16384_d_kernel<true>), grid, block, kLdsBytes, c->stream, p);
+    else if (direct) hipLaunchKernelGGL((stft16384_d_kernel<false, true>), grid, block, kLdsBytes, c->stream, p);
     else hipLaunchKernelGGL((stft16384_d_kernel<false>), grid, block, kLdsBytes, c->stream, p);
     return hipGetLastError();
 }

@@ -202,7 +202,7 @@ def test_app_point_4800_point_kernel(torch_cuda, mags_err, gradients, ch, paired
 
 
 @pytest.mark.parametrize("ch,variant", [(8, "quad"), (2, "quad"), (1, "quad"), (1, "quad_paired"), (8, "residue"), (2, "residue"), (1, "residue"),
-                                        (1, "residue_paired"), (8, "generic")])
+                                        (1, "residue_paired"), (8, "generic"), (8, "quad_direct"), (6, "quad_direct")])
 def test_config4_16384_point_kernel(torch_cuda, mags_err, ch, variant):
     # BASELINE config 4: W 8192 / P 16384, hop 512, interleaved channel pairs; the time-decimated lane-quad kernel (default), the
     # four-residue kernel of round 2 (SGX_FLAG_RESIDUE_16K) and the generic kernel, each against the oracle
@@ -211,9 +211,11 @@ def test_config4_16384_point_kernel(torch_cuda, mags_err, ch, variant):
     # (a mono stream: by default every frame its own (s, s) transform -- the lane-quad kernel on a duplicated plane, the four-residue
     # design through the generic kernel --, "_paired": two frames per transform, SGX_FLAG_PAIRED_FRAMES)
     paired = variant.endswith("_paired")
+    direct = variant.endswith("_direct")      # SGX_FLAG_DIRECT_CHANNELS: the pairs read where they lie, no planes
     variant = variant.split("_")[0]
     force_generic = variant == "generic"
-    eng = engine(window_samples=Wt, hop_samples=Ht, channels=ch, force_generic=force_generic, residue_16k=(variant == "residue"), paired_frames=paired)
+    eng = engine(window_samples=Wt, hop_samples=Ht, channels=ch, force_generic=force_generic, residue_16k=(variant == "residue"), paired_frames=paired,
+                 direct_channels=direct)
     assert eng.info.stft_kernel == {"quad": 8, "residue": 5, "generic": 0}[variant]
     n = Wt + 21 * Ht + 9
     pcm = oracle.white_noise(n * ch, seed=40 + ch)
@@ -222,6 +224,8 @@ def test_config4_16384_point_kernel(torch_cuda, mags_err, ch, variant):
     ref = oracle.stream_process(pcm, ch, Wt, Ht, threads=8)
     assert got.shape == ref.shape == (22, max(ch // 2, 1), Wt - 1, 2)
     assert mags_err(got, ref) <= 2.0
+    if direct:   # the same arithmetic on the same samples: the bytes of the default (planes) path
+        assert np.array_equal(engine(window_samples=Wt, hop_samples=Ht, channels=ch).stft_batch(dev).cpu().numpy(), got)
     lr = pcm.reshape(-1, ch)
     truth = oracle.np_truth_frame(np.stack([lr[5 * Ht:5 * Ht + Wt, 0], lr[5 * Ht:5 * Ht + Wt, min(1, ch - 1)]], 1), Wt)
     assert mags_err(got[5, 0], truth) <= 1.0
@@ -235,7 +239,7 @@ def test_config4_16384_point_kernel(torch_cuda, mags_err, ch, variant):
         shifted[2:] = dev
         assert shifted[2:].data_ptr() % 16 == 8
         assert np.array_equal(eng.stft_batch(shifted[2:]).cpu().numpy(), got)
-    if variant != "generic" and ch == 8:
+    if variant != "generic" and ch >= 6:
         # more jobs than persistent workgroups (142 hop positions x 4 pairs = 568 > 512): every workgroup runs several jobs with
         # different data -- a stale read of what the previous job left (the four-residue kernel parks half of its magnitudes in a
         # slot it reads back; both kernels re-use LDS images and prefetch registers across jobs) would show here
@@ -244,7 +248,7 @@ def test_config4_16384_point_kernel(torch_cuda, mags_err, ch, variant):
             pcm2 = oracle.white_noise((Wt + (hops - 1) * Ht) * ch, seed=77 + hops)
             got2 = eng.stft_batch(to_dev(torch, pcm2)).cpu().numpy()
             ref2 = oracle.stream_process(pcm2, ch, Wt, Ht, threads=8)
-            assert got2.shape == ref2.shape == (hops, 4, Wt - 1, 2) and mags_err(got2, ref2) <= 2.0
+            assert got2.shape == ref2.shape == (hops, ch // 2, Wt - 1, 2) and mags_err(got2, ref2) <= 2.0
     # the pixel path rides on it through the two-kernel route
     eng.set_builtin_gradient("viridis")
     rg = eng.render_batch(dev).cpu().numpy()

@@ -86,7 +86,8 @@ if t4a:
         "config 4: FETCH_SIZE / WRITE_SIZE count requests between L2 and the fabric, Infinity-Cache hits included. Per hop position the "
         f"transform kernel writes {write_kb:.0f} KB (262 KB of algorithmic output; nothing is parked since round 3's kernel, csrc/stft16384_d.hip) "
         f"and fetches {fetch_kb:.0f} KB: the (l, r) planes of the de-interleave pass, every sample wanted by 16 overlapping hop positions and "
-        "served mostly by L2 (16 KB algorithmic).  The de-interleave pass reads the interleaved stream once and writes the planes once.")
+        "served mostly by L2 (16 KB algorithmic).  The de-interleave pass reads the interleaved stream once and writes the planes once "
+        "(SGX_FLAG_DIRECT_CHANNELS reads the stream in place instead: traffic = algorithmic, 2 % slower).")
 json.dump(out, open(os.path.join(root, "profiles", f"{rnd}_hbm_traffic.json"), "w"), indent=1)
 
 # ---- pipes of the fused pixel kernel -------------------------------------------------------------------------------
