@@ -868,8 +868,18 @@ def config4_leg(args, torch, device):
     achieved = hops * ALGO_BYTES_CFG4 / (mean * 1e-3) / 1e9
     traffic = load_profile_json("hbm_traffic")
     name = KERNEL_NAMES.get(eng.info.stft_kernel, ("?", "?"))
+    # the same launch with the pairs read where they lie (SGX_FLAG_DIRECT_CHANNELS: one kernel, no planes, no workspace), beside it
+    eng_d = SpectrogramEngine(48000.0, window_samples=W4, hop_samples=H4, channels=C4, device=device, direct_channels=True)
+    same_bytes = eng_d.checksum(eng_d.stft_batch(pcm, max_frames=512)) == eng.checksum(eng.stft_batch(pcm, max_frames=512))
+    md = measure_leg(torch, lambda: eng_d.stft_batch(pcm, out=out), min(args.leg_sustain_s, 0.5))
+    direct = {"hop_positions_per_s": hops / (md["mean_ms"] * 1e-3), "frac": hops * ALGO_BYTES_CFG4 / (md["mean_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+              "same_bytes_as_default_on_512_hops": bool(same_bytes), "kernel": "sgx::d16k::stft16384_d_kernel<false, true>",
+              "what": "SGX_FLAG_DIRECT_CHANNELS: 8-byte loads at a 32-byte stride straight from the interleaved stream; HBM counters 1.02 x "
+                      "algorithmic (profiles/r05_k16.txt section 6) against the default's de-interleave pass + planes"}
+    eng_d.close()
     return {
         "workload": f"configs[3]: 16384-pt Hann STFT, hop 512, 8 interleaved channels, {hops} hop positions ({4 * hops} transforms)",
+        "direct_channels": direct,
         "hop_positions_per_s": hops / (mean * 1e-3), "transforms_per_s": 4 * hops / (mean * 1e-3),
         **leg_times(m), "kernel": name[0], "output_bytes": hops * (C4 // 2) * (W4 - 1) * 8,
         "roofline": {
