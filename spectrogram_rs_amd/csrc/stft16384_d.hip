@@ -170,8 +170,9 @@ __device__ unsigned long long g_phase_cycles16[24];
 // A wave's load then touches 64 x 4 C bytes instead of 512 contiguous ones (+4 % on this kernel at C = 8: 16 lines per load for 4), but
 // the four pairs of a hop position run on CUs of one XCD at the same time and share the lines in its L2 -- and the pass that used to split
 // the stream into (l, r) planes first (0.125 x the algorithmic bytes written and read back, 4.6 % of the launch, a workspace of the
-// stream's size grown on the first call) is not needed: HBM traffic 1.15 -> 1.0x x algorithmic, nothing allocated on the call -- for 2 %
-// of the time (same device 2.41-2.46 -> 2.47-2.50 ms per 80 000 transforms), which is why it is the opt-in (SGX_FLAG_DIRECT_CHANNELS).
+// stream's size grown on the first call) is not needed: HBM traffic 1.15 -> 1.02 x algorithmic, nothing allocated on the call.  Same
+// device, planes -> direct: 2.41-2.46 -> 2.47-2.50 ms per 80 000 transforms, 12.00-12.13 -> 11.87-12.06 ms at BASELINE config 4's own
+// 400 000 (there the 1.6 GB of planes no longer stay in the memory-side cache).  The default; SGX_FLAG_CHANNEL_PLANES is the A/B.
 template <bool MONO, bool DIRECT = false>
 __global__ void __launch_bounds__(1024, 1) stft16384_d_kernel(Params p)
 {
@@ -639,9 +640,9 @@ hipError_t launch_stft_d16384(const sgx_ctx *c, void *tables, const float *d_pcm
     const bool dup = channels == 1 && !mono;
     p.pair_base = mono ? first_frame / 2 : 0;
     p.n_jobs = mono ? (first_frame + n_frames + 1) / 2 - first_frame / 2 : (unsigned long long)n_frames * pairs;
-    // more than two channels: the sample range of the call split into per-pair (l, r) planes first (the default: 2 % faster), or -- under
-    // SGX_FLAG_DIRECT_CHANNELS -- every pair read where it lies (no workspace, no second kernel, HBM traffic = algorithmic)
-    const bool direct = channels > 2 && (c->cfg.flags & SGX_FLAG_DIRECT_CHANNELS);
+    // more than two channels: every pair read where it lies (no workspace, no second kernel, HBM traffic 1.02 x algorithmic), or -- under
+    // SGX_FLAG_CHANNEL_PLANES, the default of rounds 3-5 -- the sample range of the call split into per-pair (l, r) planes first
+    const bool direct = channels > 2 && !(c->cfg.flags & SGX_FLAG_CHANNEL_PLANES);
     if ((channels > 2 && !direct) || dup) {
         // per-pair planes of the sample range these frames read: [first_frame H, (first_frame + n - 1) H + W)
         const size_t first_sample = first_frame * (size_t)c->H;

@@ -60,7 +60,7 @@ def test_python_mirror_constants_match_the_header():
     for name, v in defs.items():
         if hasattr(_lib, name):
             assert getattr(_lib, name) == v, f"_lib.{name} = {getattr(_lib, name)}, sgx.h says {v}"
-    for must in ("FLAG_FORCE_GENERIC", "FLAG_NO_FUSED_RENDER", "FLAG_INDEPENDENT_FRAMES", "FLAG_RESIDUE_16K", "FLAG_MIXED_GENERIC", "FLAG_DIRECT_CHANNELS",
+    for must in ("FLAG_FORCE_GENERIC", "FLAG_NO_FUSED_RENDER", "FLAG_INDEPENDENT_FRAMES", "FLAG_RESIDUE_16K", "FLAG_MIXED_GENERIC", "FLAG_CHANNEL_PLANES",
                  "INTERP_CUBIC", "INTERP_COSINE", "LUT_FLOOR_N"):
         assert hasattr(_lib, must) and must in defs, must
 

@@ -202,7 +202,7 @@ def test_app_point_4800_point_kernel(torch_cuda, mags_err, gradients, ch, paired
 
 
 @pytest.mark.parametrize("ch,variant", [(8, "quad"), (2, "quad"), (1, "quad"), (1, "quad_paired"), (8, "residue"), (2, "residue"), (1, "residue"),
-                                        (1, "residue_paired"), (8, "generic"), (8, "quad_direct"), (6, "quad_direct")])
+                                        (1, "residue_paired"), (8, "generic"), (8, "quad_planes"), (6, "quad_planes")])
 def test_config4_16384_point_kernel(torch_cuda, mags_err, ch, variant):
     # BASELINE config 4: W 8192 / P 16384, hop 512, interleaved channel pairs; the time-decimated lane-quad kernel (default), the
     # four-residue kernel of round 2 (SGX_FLAG_RESIDUE_16K) and the generic kernel, each against the oracle
@@ -211,11 +211,11 @@ def test_config4_16384_point_kernel(torch_cuda, mags_err, ch, variant):
     # (a mono stream: by default every frame its own (s, s) transform -- the lane-quad kernel on a duplicated plane, the four-residue
     # design through the generic kernel --, "_paired": two frames per transform, SGX_FLAG_PAIRED_FRAMES)
     paired = variant.endswith("_paired")
-    direct = variant.endswith("_direct")      # SGX_FLAG_DIRECT_CHANNELS: the pairs read where they lie, no planes
+    planes = variant.endswith("_planes")      # SGX_FLAG_CHANNEL_PLANES: the sample range split into (l, r) planes first (default: pairs read where they lie)
     variant = variant.split("_")[0]
     force_generic = variant == "generic"
     eng = engine(window_samples=Wt, hop_samples=Ht, channels=ch, force_generic=force_generic, residue_16k=(variant == "residue"), paired_frames=paired,
-                 direct_channels=direct)
+                 channel_planes=planes)
     assert eng.info.stft_kernel == {"quad": 8, "residue": 5, "generic": 0}[variant]
     n = Wt + 21 * Ht + 9
     pcm = oracle.white_noise(n * ch, seed=40 + ch)
@@ -224,7 +224,7 @@ def test_config4_16384_point_kernel(torch_cuda, mags_err, ch, variant):
     ref = oracle.stream_process(pcm, ch, Wt, Ht, threads=8)
     assert got.shape == ref.shape == (22, max(ch // 2, 1), Wt - 1, 2)
     assert mags_err(got, ref) <= 2.0
-    if direct:   # the same arithmetic on the same samples: the bytes of the default (planes) path
+    if planes:   # the same arithmetic on the same samples: the bytes of the default path
         assert np.array_equal(engine(window_samples=Wt, hop_samples=Ht, channels=ch).stft_batch(dev).cpu().numpy(), got)
     lr = pcm.reshape(-1, ch)
     truth = oracle.np_truth_frame(np.stack([lr[5 * Ht:5 * Ht + Wt, 0], lr[5 * Ht:5 * Ht + Wt, min(1, ch - 1)]], 1), Wt)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """BASELINE config 4 alone (16384-point, hop 512, 8 interleaved channels): ms per launch, median of 9, for A/B builds under tools/ab.sh.
-usage: [hop positions] [direct]   (direct: SGX_FLAG_DIRECT_CHANNELS for the 8-channel stream)"""
+usage: [hop positions] [planes]   (planes: SGX_FLAG_CHANNEL_PLANES for the 8-channel stream)"""
 import os
 import sys
 
@@ -10,9 +10,9 @@ import torch
 from spectrogram_rs_amd import SpectrogramEngine
 
 HOPS = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
-DIRECT = len(sys.argv) > 2 and sys.argv[2] == "direct"
-for ch in ((8,) if DIRECT else (8, 2, 1)):
-    eng = SpectrogramEngine(48000.0, window_samples=8192, hop_samples=512, channels=ch, direct_channels=DIRECT)
+PLANES = len(sys.argv) > 2 and sys.argv[2] == "planes"
+for ch in ((8,) if PLANES else (8, 2, 1)):
+    eng = SpectrogramEngine(48000.0, window_samples=8192, hop_samples=512, channels=ch, channel_planes=PLANES)
     pcm = eng.white_noise((HOPS - 1) * 512 + 8192)
     out = torch.empty((HOPS, eng.pairs, 8191, 2), dtype=torch.float32, device="cuda")
     for _ in range(3):
