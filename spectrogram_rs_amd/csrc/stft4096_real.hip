@@ -310,23 +310,19 @@ __global__ void __launch_bounds__(256, 4) stft4096_real_kernel(Params p)
 
         // ---- pass 2: thread (g2 = 8 F + q1, t0): 16-point FFT over t1, then twiddle w_256^{t0 q2}
         float xr[16], xi[16];
+        if (TR) {
+            read_planes(rd4_1, xr, xi);
+        } else {
 #pragma unroll
-        for (int t1 = 0; t1 < 16; ++t1) {
-            if (TR) break;
-            const float2 v = buf[g2 * kS1 + t0_2 + 16 * t1];
-            xr[t1] = v.x; xi[t1] = v.y;
+            for (int t1 = 0; t1 < 16; ++t1) {
+                const float2 v = buf[g2 * kS1 + t0_2 + 16 * t1];
+                xr[t1] = v.x; xi[t1] = v.y;
+            }
         }
-        if (TR) read_planes(rd4_1, xr, xi);
         fft16(xr, xi);
         SGX_STAMP(4)    // image-1 reads + FFT16
         lds_barrier();  // everyone has read image 1
         SGX_STAMP(5)    // barrier 2
-#pragma unroll
-        for (int q2 = 0; q2 < 16; ++q2) {
-            const int pos = FFT16_OUT[q2];
-            const float2 v = make_float2(xr[pos], xi[pos]);
-            if (!TR) buf[t0_2 * kS2 + cbase2 + 8 * q2] = q2 == 0 ? v : cmulf(v, tw2[q2 * 16 + t0_2]);
-        }
         if (TR) {
             lds_cfloat2 *tw2p = lds_ptr(tw2 + t0_2);
 #pragma unroll
@@ -335,19 +331,28 @@ __global__ void __launch_bounds__(256, 4) stft4096_real_kernel(Params p)
                 const float2 va = make_float2(xr[pa], xi[pa]), vb = make_float2(xr[pb], xi[pb]);
                 addtid_rows<280>(q2 == 0 ? va : cmulf(va, lds_read_alone(tw2p, q2 * 16)), cmulf(vb, lds_read_alone(tw2p, (q2 + 1) * 16)), m0_wave, q2, q2 + 1);
             }
+        } else {
+#pragma unroll
+            for (int q2 = 0; q2 < 16; ++q2) {
+                const int pos = FFT16_OUT[q2];
+                const float2 v = make_float2(xr[pos], xi[pos]);
+                buf[t0_2 * kS2 + cbase2 + 8 * q2] = q2 == 0 ? v : cmulf(v, tw2[q2 * 16 + t0_2]);
+            }
         }
         SGX_STAMP(6)    // pass-2 twiddles + image-2 writes
         lds_barrier();
         SGX_STAMP(7)    // barrier 3
 
         // ---- pass 3: thread (F, u): 16-point FFT over t0 -> Z[u + 128 q3]
+        if (TR) {
+            read_planes(rd4_2, xr, xi);
+        } else {
 #pragma unroll
-        for (int t0 = 0; t0 < 16; ++t0) {
-            if (TR) break;
-            const float2 v = buf[t0 * kS2 + tid];
-            xr[t0] = v.x; xi[t0] = v.y;
+            for (int t0 = 0; t0 < 16; ++t0) {
+                const float2 v = buf[t0 * kS2 + tid];
+                xr[t0] = v.x; xi[t0] = v.y;
+            }
         }
-        if (TR) read_planes(rd4_2, xr, xi);
         fft16(xr, xi);
 
         // ---- rows: the load of the NEXT iteration (its R[9]), ahead of this iteration's stores (vmcnt retires in issue order), into a

@@ -346,24 +346,20 @@ __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
 
         // ---- pass 2: thread (q1, t0): 16-point FFT over t1, then twiddle w_256^{t0 q2}
         float xr[16], xi[16];
+        if (TR) {
+            read_planes(rd4, xr, xi);
+        } else {
 #pragma unroll
-        for (int t1 = 0; t1 < 16; ++t1) {
-            if (TR) break;
-            const float2 v = buf[q1_2 * kS1 + t0_2 + 16 * t1];
-            xr[t1] = v.x; xi[t1] = v.y;
+            for (int t1 = 0; t1 < 16; ++t1) {
+                const float2 v = buf[q1_2 * kS1 + t0_2 + 16 * t1];
+                xr[t1] = v.x; xi[t1] = v.y;
+            }
         }
-        if (TR) read_planes(rd4, xr, xi);
         fft16(xr, xi);
         if (!MONO) __builtin_amdgcn_s_setprio(RENDER ? 2 : SGX_PRIO_A);   // (fused (l, r) pixels: 2 / 2 measured 3 % ahead of 1 / 2, rows the other way round)
         SGX_STAMP(4)    // image-1 reads + FFT16
         lds_barrier();  // everyone has read image 1
         SGX_STAMP(5)    // barrier 2
-#pragma unroll
-        for (int q2 = 0; q2 < 16; ++q2) {
-            const int pos = FFT16_OUT[q2];
-            const float2 v = make_float2(xr[pos], xi[pos]);
-            if (!TR) buf[t0_2 * kS2 + q1_2 + 16 * q2] = q2 == 0 ? v : cmulf(v, tw2[q2 * 16 + t0_2]);
-        }
         if (TR) {
             lds_cfloat2 *tw2p = lds_ptr(tw2 + t0_2);
 #pragma unroll
@@ -372,6 +368,13 @@ __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
                 const float2 va = make_float2(xr[pa], xi[pa]), vb = make_float2(xr[pb2], xi[pb2]);
                 addtid_rows(q2 == 0 ? va : cmulf(va, lds_read_alone(tw2p, q2 * 16)), cmulf(vb, lds_read_alone(tw2p, (q2 + 1) * 16)), m0_wave, q2);
             }
+        } else {
+#pragma unroll
+            for (int q2 = 0; q2 < 16; ++q2) {
+                const int pos = FFT16_OUT[q2];
+                const float2 v = make_float2(xr[pos], xi[pos]);
+                buf[t0_2 * kS2 + q1_2 + 16 * q2] = q2 == 0 ? v : cmulf(v, tw2[q2 * 16 + t0_2]);
+            }
         }
         if (!MONO) __builtin_amdgcn_s_setprio(SGX_PRIO_B);
         SGX_STAMP(6)    // twiddles (LDS reads) + image-2 writes
@@ -379,13 +382,15 @@ __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
         SGX_STAMP(7)    // barrier 3
 
         // ---- pass 3: thread u = q1 + 16 q2: 16-point FFT over t0 -> bins k = u + 256 q3
+        if (TR) {
+            read_planes(rd4, xr, xi);
+        } else {
 #pragma unroll
-        for (int t0 = 0; t0 < 16; ++t0) {
-            if (TR) break;
-            const float2 v = buf[t0 * kS2 + col];
-            xr[t0] = v.x; xi[t0] = v.y;
+            for (int t0 = 0; t0 < 16; ++t0) {
+                const float2 v = buf[t0 * kS2 + col];
+                xr[t0] = v.x; xi[t0] = v.y;
+            }
         }
-        if (TR) read_planes(rd4, xr, xi);
         fft16(xr, xi);
         if (job + 1 < job_end) fetch(job + 1, true);  // ahead of this transform's stores (see above)
         if (RENDER) __builtin_amdgcn_s_setprio(1);  // the pixel passes are long: 3 only from the row pass (the pixel stores) on
