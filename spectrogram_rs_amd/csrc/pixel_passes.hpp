@@ -31,18 +31,7 @@ __device__ __forceinline__ void pixel_passes(const P &p, const float2 *m, float2
             const int32_t x3 = x1 + 2 < last ? x1 + 2 : last;
             const float2 y0 = m[x0], y1 = m[x1], y2 = m[x2], y3 = m[x3];
             const float mu = se.w0, mu2 = se.w1, mu3 = se.w2;
-            {
-                const float a0 = ((y3.x - y2.x) - y0.x) + y1.x;
-                const float a1 = (y0.x - y1.x) - a0;
-                const float a2 = y2.x - y0.x;
-                v.x = ((a0 * mu3) + (a1 * mu2)) + ((a2 * mu) + y1.x);
-            }
-            {
-                const float a0 = ((y3.y - y2.y) - y0.y) + y1.y;
-                const float a1 = (y0.y - y1.y) - a0;
-                const float a2 = y2.y - y0.y;
-                v.y = ((a0 * mu3) + (a1 * mu2)) + ((a2 * mu) + y1.y);
-            }
+            v = cubic_pair(y0, y1, y2, y3, mu, mu2, mu3);
         }
         vbuf[sidx] = v;
     }

@@ -12,6 +12,28 @@
 
 namespace sgx {
 
+// interpolated_frequency_sample.rs:89-105 on an (l, r) / (frame A, frame B) pair: both components in packed f32 instructions --
+// v_pk_add_f32 / v_pk_mul_f32 round each half as the scalar instructions do (the library is built with -ffp-contract=off), so the bits
+// are those of the two scalar evaluations; on the fused mono path 4-5 % of config 3's cubic leg (profiles/r05_pixel_lds.txt)
+#ifdef __HIPCC__
+typedef float sgx_f2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float2 cubic_pair(float2 y0, float2 y1, float2 y2, float2 y3, float mu, float mu2, float mu3)
+{
+#if defined(SGX_PK_PAIR) && !SGX_PK_PAIR   // (A/B: the scalar form)
+    float2 v;
+    { const float a0 = ((y3.x - y2.x) - y0.x) + y1.x, a1 = (y0.x - y1.x) - a0, a2 = y2.x - y0.x; v.x = ((a0 * mu3) + (a1 * mu2)) + ((a2 * mu) + y1.x); }
+    { const float a0 = ((y3.y - y2.y) - y0.y) + y1.y, a1 = (y0.y - y1.y) - a0, a2 = y2.y - y0.y; v.y = ((a0 * mu3) + (a1 * mu2)) + ((a2 * mu) + y1.y); }
+    return v;
+#endif
+    const sgx_f2v Y0 = {y0.x, y0.y}, Y1 = {y1.x, y1.y}, Y2 = {y2.x, y2.y}, Y3 = {y3.x, y3.y};
+    const sgx_f2v a0 = ((Y3 - Y2) - Y0) + Y1;
+    const sgx_f2v a1 = (Y0 - Y1) - a0;
+    const sgx_f2v a2 = Y2 - Y0;
+    const sgx_f2v r = ((a0 * mu3) + (a1 * mu2)) + ((a2 * mu) + Y1);
+    return make_float2(r.x, r.y);
+}
+#endif
+
 // The grid over the balance t = l / (|l| + |r|) that shortens the search for its colour segment: a monotone cell number,
 // the same IEEE double operations on the host (table) and on the device (lookup).
 constexpr int kTCells = 512;

@@ -297,18 +297,8 @@ __global__ void __launch_bounds__(256) render_kernel(RenderParams p)
                 const int32_t x3 = x1 + 2 < last ? x1 + 2 : last;
                 const float2 y0 = m[x0], y1 = m[x1], y2 = m[x2], y3 = m[x3];
                 const float mu = se.w0, mu2 = se.w1, mu3 = se.w2;
-                {
-                    const float a0 = ((y3.x - y2.x) - y0.x) + y1.x;
-                    const float a1 = (y0.x - y1.x) - a0;
-                    const float a2 = y2.x - y0.x;
-                    vl = ((a0 * mu3) + (a1 * mu2)) + ((a2 * mu) + y1.x);
-                }
-                {
-                    const float a0 = ((y3.y - y2.y) - y0.y) + y1.y;
-                    const float a1 = (y0.y - y1.y) - a0;
-                    const float a2 = y2.y - y0.y;
-                    vr = ((a0 * mu3) + (a1 * mu2)) + ((a2 * mu) + y1.y);
-                }
+                const float2 vv = cubic_pair(y0, y1, y2, y3, mu, mu2, mu3);
+                vl = vv.x; vr = vv.y;
             }
             sl = sl + vl;
             sr = sr + vr;
@@ -449,18 +439,7 @@ __global__ void __launch_bounds__(NT, 4) render_two_pass_kernel(RenderParams p, 
                     const int32_t x3 = x1 + 2 < last ? x1 + 2 : last;
                     const float2 y0 = m[x0], y1 = m[x1], y2 = m[x2], y3 = m[x3];
                     const float mu = wk, mu2 = mu * mu, mu3 = mu * mu2;   // num_traits::pow (:93-94), as the host table
-                    {
-                        const float a0 = ((y3.x - y2.x) - y0.x) + y1.x;
-                        const float a1 = (y0.x - y1.x) - a0;
-                        const float a2 = y2.x - y0.x;
-                        v.x = ((a0 * mu3) + (a1 * mu2)) + ((a2 * mu) + y1.x);
-                    }
-                    {
-                        const float a0 = ((y3.y - y2.y) - y0.y) + y1.y;
-                        const float a1 = (y0.y - y1.y) - a0;
-                        const float a2 = y2.y - y0.y;
-                        v.y = ((a0 * mu3) + (a1 * mu2)) + ((a2 * mu) + y1.y);
-                    }
+                    v = cubic_pair(y0, y1, y2, y3, mu, mu2, mu3);
                 }
                 vbuf[sidx] = v;
             }
@@ -483,18 +462,7 @@ __global__ void __launch_bounds__(NT, 4) render_two_pass_kernel(RenderParams p, 
                     const int32_t x3 = x1 + 2 < last ? x1 + 2 : last;
                     const float2 y0 = m[x0], y1 = m[x1], y2 = m[x2], y3 = m[x3];
                     const float mu = se.w0, mu2 = se.w1, mu3 = se.w2;
-                    {
-                        const float a0 = ((y3.x - y2.x) - y0.x) + y1.x;
-                        const float a1 = (y0.x - y1.x) - a0;
-                        const float a2 = y2.x - y0.x;
-                        v.x = ((a0 * mu3) + (a1 * mu2)) + ((a2 * mu) + y1.x);
-                    }
-                    {
-                        const float a0 = ((y3.y - y2.y) - y0.y) + y1.y;
-                        const float a1 = (y0.y - y1.y) - a0;
-                        const float a2 = y2.y - y0.y;
-                        v.y = ((a0 * mu3) + (a1 * mu2)) + ((a2 * mu) + y1.y);
-                    }
+                    v = cubic_pair(y0, y1, y2, y3, mu, mu2, mu3);
                 }
                 vbuf[sidx] = v;
                 sidx += NT;
@@ -715,18 +683,8 @@ __global__ void __launch_bounds__(256) magnitude_in_kernel(BandsParams p)
                 const int32_t x3 = x1 + 2 < last ? x1 + 2 : last;
                 const float2 y0 = m[x0], y1 = m[x1], y2 = m[x2], y3 = m[x3];
                 const float mu = se.w0, mu2 = se.w1, mu3 = se.w2;
-                {
-                    const float a0 = ((y3.x - y2.x) - y0.x) + y1.x;
-                    const float a1 = (y0.x - y1.x) - a0;
-                    const float a2 = y2.x - y0.x;
-                    vl = ((a0 * mu3) + (a1 * mu2)) + ((a2 * mu) + y1.x);
-                }
-                {
-                    const float a0 = ((y3.y - y2.y) - y0.y) + y1.y;
-                    const float a1 = (y0.y - y1.y) - a0;
-                    const float a2 = y2.y - y0.y;
-                    vr = ((a0 * mu3) + (a1 * mu2)) + ((a2 * mu) + y1.y);
-                }
+                const float2 vv = cubic_pair(y0, y1, y2, y3, mu, mu2, mu3);
+                vl = vv.x; vr = vv.y;
             }
             sl = sl + vl;
             sr = sr + vr;
