@@ -111,6 +111,9 @@ constexpr int kRowsF32 = 0, kRowsF16 = 1, kPixels = 2;   // what a launch writes
 #ifndef SGX_K1R_INTERLEAVE
 #define SGX_K1R_INTERLEAVE 1
 #endif
+#ifndef SGX_SAMPLE_EARLY
+#define SGX_SAMPLE_EARLY 1   // fused pixels: the sample-table words requested in front of the column writes (stft4096_wg.hpp: sample_request)
+#endif
 #ifndef SGX_ADDTID_R
 #define SGX_ADDTID_R 1   // (0: the b64 transposes of the non-sliding instantiation, for A/B)
 #endif
@@ -460,6 +463,14 @@ __global__ void __launch_bounds__(256, 4) stft4096_real_kernel(Params p)
             float *mcol = reinterpret_cast<float *>(buf) + F;
             lds_barrier();  // partner and exchange reads done: the image can be overwritten
             SGX_STAMP(13)   // (pixels) barrier 6
+            // the sample pass's table words (nine per thread, the same in every iteration but eighteen registers nobody has to spare across
+            // the transform) are requested as the column writes free m1 / m2, one word behind each pair of writes: their L1 / L2 latency
+            // falls on the rest of the writes and on the barrier instead of on the head of the pass
+            constexpr bool kEarlyWords = SGX_SAMPLE_EARLY && PIX != wg::kPixGeneric;   // (the generic instantiation -- interpolator and LUT walk at run time -- has no register left: one spill)
+            wg::SampleWords sw;
+            const __amdgpu_buffer_rsrc_t rt_words = wg::pcm_rsrc(reinterpret_cast<const float *>(p.samples));
+            int tid_w = tid;
+            asm volatile("" : "+v"(tid_w));   // (opaque: the nine table offsets are not to be hoisted out of the loop over the transforms)
 #pragma unroll
             for (int q3 = 0; q3 < 8; ++q3) {
                 const bool self = q3 == 0 && u == 0;       // thread 0's bin-1024 slot: m1 twice
@@ -470,11 +481,18 @@ __global__ void __launch_bounds__(256, 4) stft4096_real_kernel(Params p)
                     mcol[0] = m1[0];
                     mcol[2 * (kM + 1)] = mcol[2 * (kM + 2)] = m2[0];
                 }
+                if (kEarlyWords) {
+                    sw.se[q3] = wg::sample_word(rt_words, p, (uint32_t)tid_w + 256u * q3);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
+            if (kEarlyWords) sw.se[8] = wg::sample_word(rt_words, p, (uint32_t)tid_w + 2048u);
+            static_assert(wg::kSampleSteps == 9 && wg::kSampleEarly == 9, "one word per column-write step and one behind them");
             SGX_STAMP(14)   // (pixels) column writes
             lds_barrier();
             SGX_STAMP(15)   // (pixels) barrier 7
-            wg::sample_pass<PIX>(p, mpair, vbuf, tid);
+            if (kEarlyWords) wg::sample_pass_with<PIX>(p, mpair, vbuf, tid, sw);
+            else wg::sample_pass<PIX>(p, mpair, vbuf, tid);
             // the fused pixel path requests the next iteration's load HERE, straight into L (dead since the slide): requested in front
             // of the exchange like the rows' it is two more live registers through the sample pass -- two spills, and a spill reload
             // is a vector-memory load the compiler waits for with vmcnt(0), this load included (same device: 3.79 -> 3.68 ms)

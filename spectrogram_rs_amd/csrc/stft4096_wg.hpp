@@ -279,6 +279,46 @@ __device__ __forceinline__ void sample_pass_for(const Params &p, const float2 *P
 #endif
 }
 
+// The same pass with the table words requested EARLY (SGX_SAMPLE_EARLY, stft4096_real.hip): a thread's nine words are asked for in front of
+// the barrier and the column writes that precede the pass, so that their L1 / L2 latency falls on those instead of on the head of the pass
+// (stamped build: the pass was 22 % of config 3's iteration, most of it the wait for the words it had just requested).
+constexpr int kSampleSteps = (kMaxFusedSamples + 255) / 256;
+#ifndef SGX_SAMPLE_EARLY_N
+#define SGX_SAMPLE_EARLY_N 9   // words requested early (in front of the column writes: 17 spilled registers at the 128-register cap; behind each pair of them, as stft4096_real.hip does: none)
+#endif
+constexpr int kSampleEarly = SGX_SAMPLE_EARLY_N;
+struct SampleWords { PackedSample se[kSampleEarly]; };
+__device__ __forceinline__ PackedSample sample_word(const __amdgpu_buffer_rsrc_t &rt, const Params &p, uint32_t i)
+{
+    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rt, (int)((i < p.n_samples ? i : 0u) * 8u), 0, 0);
+    return PackedSample{(int32_t)v.x, __uint_as_float(v.y)};
+}
+__device__ __forceinline__ void sample_request(const Params &p, int tid, SampleWords &w)
+{
+    const __amdgpu_buffer_rsrc_t rt = pcm_rsrc(reinterpret_cast<const float *>(p.samples));
+    asm volatile("" : "+v"(tid));   // (opaque: see sample_pass_for)
+#pragma unroll
+    for (int k = 0; k < kSampleEarly; ++k) w.se[k] = sample_word(rt, p, tid + 256 * k);
+}
+template <int PIX>
+__device__ __forceinline__ void sample_pass_with(const Params &p, const float2 *P, float2 *vbuf, int tid, const SampleWords &w)
+{
+    const __amdgpu_buffer_rsrc_t rt = pcm_rsrc(reinterpret_cast<const float *>(p.samples));
+    asm volatile("" : "+v"(tid));
+    PackedSample se[kSampleSteps];
+#pragma unroll
+    for (int k = 0; k < kSampleSteps; ++k) se[k] = k < kSampleEarly ? w.se[k] : sample_word(rt, p, tid + 256 * k);   // the rest: now, all at once
+#pragma unroll
+    for (int k = 0; k < kSampleSteps; ++k) {
+        const uint32_t s = tid + 256 * k;
+        if (s < p.n_samples) {
+            if (PIX == kPixCosine || (PIX == kPixGeneric && p.interp == SGX_INTERP_COSINE)) vbuf[s] = interp_sample2<true>(P, se[k].i0, se[k].w);
+            else vbuf[s] = interp_sample2<false>(P, se[k].i0, se[k].w);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 template <int PIX>
 __device__ __forceinline__ void sample_pass(const Params &p, const float2 *P, float2 *vbuf, int tid)
 {
