@@ -57,11 +57,16 @@ ALGO_BYTES_STFT = H * 1 * 4 + M * 2 * 4  # 17 400 B / frame: each input sample o
 ALGO_BYTES_PIXEL = H * 1 * 4 + R * 4     # 5 120 B / frame
 W4, H4, C4 = 8192, 512, 8
 ALGO_BYTES_CFG4 = H4 * C4 * 4 + (C4 // 2) * (W4 - 1) * 8  # 278 496 B / hop position
-PROFILE_ROUND = "r05"
+PROFILE_ROUND = "r06"
 W_APP, H_APP = 2400, 93     # the application's own operating point: 48 kHz x 0.05 s (gpu_spectrogram.rs:323), hop (2/1024) s (simple_spectrogram.rs:102)
 ALGO_BYTES_STEREO = H * 2 * 4 + M * 2 * 4                     # 18 424 B / frame: an (l, r) stream, what the reference feeds
 ALGO_BYTES_APP = H_APP * 2 * 4 + (W_APP - 1) * 2 * 4          # 19 936 B / frame
 ALGO_BYTES_APP_PIXEL = H_APP * 2 * 4 + R * 4                  # 4 840 B / frame
+FP32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: peak FP32 vector rate (spec)
+NOMINAL_FLOP_4096 = 5 * 4096 * 12      # 245 760: the 5 P log2 P convention of SURVEY 8(d), one complex 4096-point transform
+NOMINAL_FLOP_16384 = 5 * 16384 * 14    # 1 146 880
+LINE_BUDGET = 4096           # bytes of the ONE stdout line (round 5's 21 KB line was not parsed by the driver)
+LEGS_FILE = "bench_legs.json"
 KERNEL_NAMES = {
     0: ("generic power-of-two (workgroup per frame, LDS radix-4)", "sgx::stft_generic_kernel"),
     2: ("stft4096 workgroup-per-transform (256 threads x 16 points, radix-16 x3, mono frame pairs), scalar codelets",
@@ -94,6 +99,9 @@ def parse(argv=None):
     ap.add_argument("--app-frames", type=int, default=262_144, help="N = 1: frames of the leg at the application's operating point, W 2400 / hop 93 stereo (0 = skip)")
     ap.add_argument("--config5-frames", type=int, default=100_000_000, help="N > 1: total frames of the config-5 leg (0 = skip)")
     ap.add_argument("--config5-chunk", type=int, default=65_536, help="columns per rank per gather round")
+    ap.add_argument("--config5-probe", type=int, default=0, help="config-5 leg: pieces (spread from the first to the last frame) of which 8 columns each are "
+                                                                 "kept and written to --config5-probe-file, for a host-side check of far stream offsets (0 = none)")
+    ap.add_argument("--config5-probe-file", default=None, help="where the probed columns go (.npz: frames [n] int64, rgba [n][R][4] uint8); default gpurun_out/ or the repo root")
     ap.add_argument("--leg-timeout", type=float, default=600.0, help="seconds after which a stalled collective leg is given up (exit 3)")
     ap.add_argument("--cpu-frames", type=int, default=262_144, help="frames of the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--generic", action="store_true", help="force the generic power-of-two kernel")
@@ -134,6 +142,12 @@ def launch_children(args, argv):
         print("bench.py: the ranks exited 0 without printing a JSON line", file=sys.stderr)
         rc = 4
     return rc
+
+
+def test_hook(name):
+    """BENCH_FAIL_RANK (a rank that dies: fault injection) and BENCH_GROUP_OF_ONE (one launched rank takes the multi-rank path) are
+    test hooks: they read as unset unless BENCH_TEST_HOOKS=1 is set beside them, so that a stray variable cannot alter a real run."""
+    return os.environ.get(name) if os.environ.get("BENCH_TEST_HOOKS") == "1" else None
 
 
 def host_info():
@@ -177,20 +191,154 @@ def csrc_sha16():
 
 
 def load_profile_json(name):
-    """A committed summary of this round's rocprofv3 --pmc passes (profiles/<round>_<name>.json), or None -- also None (with the
-    reason on stderr) when the summary was taken from other kernel sources than the ones in the tree."""
-    path = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_{name}.json")
-    try:
-        with open(path) as f:
-            d = json.load(f)
-        if d.get("csrc_sha16") != csrc_sha16():
+    """A committed summary of rocprofv3 --pmc passes (profiles/<round>_<name>.json: this round's, else the newest earlier round's), or
+    None -- also None (with the reason on stderr) when every summary was taken from other kernel sources than the ones in the tree."""
+    sha = csrc_sha16()
+    n = int(PROFILE_ROUND[1:])
+    for rnd in (f"r{k:02d}" for k in range(n, 0, -1)):
+        path = os.path.join(ROOT, "profiles", f"{rnd}_{name}.json")
+        try:
+            with open(path) as f:
+                d = json.load(f)
+        except Exception:  # noqa: BLE001 -- absent or unreadable: try the round before
+            continue
+        if d.get("csrc_sha16") != sha:
             print(f"bench.py: {os.path.relpath(path, ROOT)} was measured on other kernel sources "
-                  f"({d.get('csrc_sha16')} != {csrc_sha16()}): not quoted", file=sys.stderr)
+                  f"({d.get('csrc_sha16')} != {sha}): not quoted", file=sys.stderr)
             return None
         d["source"] = os.path.relpath(path, ROOT)
         return d
-    except Exception:
-        return None
+    return None
+
+
+def r6(x):
+    """a float at 6 significant digits (the stdout line is budgeted; the full figures are in bench_legs.json)"""
+    return float(f"{x:.6g}") if isinstance(x, float) else x
+
+
+def pick(d, *keys):
+    return {k: r6(d[k]) for k in keys if isinstance(d, dict) and d.get(k) is not None}
+
+
+CONTRACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                 "dtype", "data", "config", "roofline", "cpu_baseline")
+
+
+def compact_line(full, budget=LINE_BUDGET):
+    """The ONE stdout line: the contract keys, `config`, a `roofline` and a `cpu_baseline` cut down to their figures, and one-number
+    summaries of the side legs -- never more than `budget` bytes (the 21 KB line of that round was not parsed).
+    Everything else (per-launch statistics, placement passes, the prose) goes to stderr and to bench_legs.json (emit_line).
+    Optional keys are dropped from the end of DROP_ORDER until the line fits; the contract keys are never dropped."""
+    line = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                 "vs_baseline", "dtype", "data") if k in full}
+    cfg = full.get("config") or {}
+    line["config"] = pick(cfg, "workload", "window", "fft_length", "hop", "channels", "frames_per_gpu", "kernel", "sharding")
+    roof = full.get("roofline") or {}
+    rl = pick(roof, "bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "launch_ms", "bytes_per_frame", "frames_per_launch",
+              "frac_burst", "frac_sustained", "fp32_frac", "fp32_frac_nominal", "traffic_source", "sclk_mhz_after_run")
+    rl.setdefault("traffic", None)
+    if roof.get("first_allocation"):
+        rl["first_allocation"] = pick(roof["first_allocation"], "launch_ms", "frac", "is_value")
+    if roof.get("placement"):
+        rl["placement"] = pick(roof["placement"], "candidates", "chosen", "spread")
+    if roof.get("measured_device"):
+        rl["measured_device"] = pick(roof["measured_device"], "fill_GBps", "copy_GBps", "frac_of_fill", "frac_of_copy")
+    line["roofline"] = rl
+    cpu = full.get("cpu_baseline")
+    if isinstance(cpu, dict):
+        cb = pick(cpu, "value", "unit", "cores", "kind", "impl", "sample", "nproc", "cpu_model", "parity_on_sample")
+        if isinstance(cpu.get("port"), dict):
+            cb["port"] = pick(cpu["port"], "value", "impl")
+        if isinstance(cpu.get("library"), dict):
+            cb["library"] = pick(cpu["library"], "value", "impl", "matches_oracle")
+        if isinstance(cpu.get("single_thread"), dict):
+            cb["single_thread"] = pick(cpu["single_thread"], "value")
+        cb["fftw"] = cpu["fftw"] if isinstance(cpu.get("fftw"), dict) and "as_written" in cpu["fftw"] else "absent"
+        if isinstance(cb["fftw"], dict):
+            cb["fftw"] = pick(cb["fftw"], "as_written", "hoisted")
+        line["cpu_baseline"] = cb
+    for k in ("error", "checksum_first_4096_frames", "achieved_GBps_algorithmic"):
+        if k in full:
+            line[k] = r6(full[k])
+    c3 = full.get("config3")
+    if isinstance(c3, dict):
+        rf = c3.get("roofline") or {}
+        line["config3_frac"] = r6(rf.get("frac"))
+        line["config3_fp32_frac"] = r6(rf.get("fp32_frac"))
+        line["config3_fp32_frac_nominal"] = r6(rf.get("fp32_frac_nominal"))
+        line["config3_frames_per_s"] = r6(c3.get("frames_per_s"))
+        if isinstance(c3.get("cubic"), dict) and "frames_per_s" in c3["cubic"]:
+            line["config3_cubic_frames_per_s"] = r6(c3["cubic"]["frames_per_s"])
+            line["config3_cubic_fp32_frac"] = r6(c3["cubic"].get("fp32_frac"))
+        par = (c3.get("rgba_vs_oracle") or {}).get("cosine") or {}
+        line["config3_rgba"] = pick(par, "mismatch_rate", "max_lut_step", "stage_wise_bit_exact_on_128_frames")
+    c4 = full.get("config4")
+    if isinstance(c4, dict):
+        rf = c4.get("roofline") or {}
+        line["config4_frac"] = r6(rf.get("frac"))
+        line["config4_fp32_frac"] = r6(rf.get("fp32_frac"))
+        line["config4_fp32_frac_nominal"] = r6(rf.get("fp32_frac_nominal"))
+        line["config4_hop_positions_per_s"] = r6(c4.get("hop_positions_per_s"))
+        line["config4_traffic_over_algorithmic"] = r6(rf.get("traffic_over_algorithmic"))
+    st = full.get("stereo4096")
+    if isinstance(st, dict):
+        rf = st.get("roofline") or {}
+        line["stereo_frac"] = r6(rf.get("frac"))
+        line["stereo_fp32_frac"] = r6(rf.get("fp32_frac"))
+        line["stereo_fp32_frac_nominal"] = r6(rf.get("fp32_frac_nominal"))
+        line["stereo_frames_per_s"] = r6(st.get("frames_per_s"))
+    for key, short in (("mono_paired_frames", "mono_paired_frac"), ("mono_complex_frames", "mono_complex_frac")):
+        if isinstance(full.get(key), dict):
+            line[short] = r6((full[key].get("roofline") or {}).get("frac"))
+    ap = full.get("app_point")
+    if isinstance(ap, dict):
+        line["app_point"] = {k: r6(ap[k]["frames_per_s"]) for k in ("rows_f32", "pcm_to_rgba", "mono_rows_f32", "mono_pcm_to_rgba")
+                             if isinstance(ap.get(k), dict) and "frames_per_s" in ap[k]}
+    c5 = full.get("config5")
+    if isinstance(c5, dict):
+        d = pick(c5, "backend", "ranks_seen", "frames_total", "frames_per_gpu", "chunk_columns", "rounds", "frames_per_s",
+                 "algorithmic_GBps", "overlapped_s", "render_only_s", "gather_only_s", "overlap_ratio", "gathered_bytes",
+                 "GBps_into_root", "GBps_into_root_gather_only", "checksum_all_columns",
+                 "sharded_equals_single_gpu_on_first_chunk_of_every_rank", "probes_file", "probes")
+        if isinstance(c5.get("GBps_per_source_alone"), list):
+            d["GBps_per_source_alone"] = [r6(q.get("GBps")) for q in c5["GBps_per_source_alone"]]
+        line["config5"] = d
+    line["legs_file"] = LEGS_FILE
+    DROP_ORDER = ("app_point", "mono_complex_frac", "mono_paired_frac", "achieved_GBps_algorithmic", "config3_rgba",
+                  "config4_traffic_over_algorithmic", "config3_cubic_fp32_frac", "config3_cubic_frames_per_s", "stereo_frames_per_s",
+                  "config4_hop_positions_per_s", "config3_frames_per_s", "checksum_first_4096_frames", "legs_file")
+    size = lambda: len(json.dumps(line, separators=(", ", ": ")))
+    for k in DROP_ORDER:
+        if size() <= budget:
+            break
+        line.pop(k, None)
+    # still too long (a very long error text, many ranks): shorten what is free text, then the optional sub-objects
+    for obj, key, keep in ((line, "error", 300), (line.get("config", {}), "workload", 160), (line.get("cpu_baseline", {}), "sample", 120),
+                           (line.get("config", {}), "kernel", 80)):
+        if size() > budget and isinstance(obj.get(key), str) and len(obj[key]) > keep:
+            obj[key] = obj[key][:keep - 3] + "..."
+    for obj, key in ((line.get("roofline", {}), "measured_device"), (line.get("roofline", {}), "placement"),
+                     (line.get("config5", {}), "GBps_per_source_alone"), (line.get("cpu_baseline", {}), "library"),
+                     (line.get("cpu_baseline", {}), "single_thread"), (line.get("roofline", {}), "first_allocation")):
+        if size() > budget:
+            obj.pop(key, None)
+    assert size() <= budget, f"bench.py: the stdout line is {size()} bytes (> {budget})"
+    return line
+
+
+def emit_line(full, stream=None):
+    """rank 0: the full record as ONE line on stderr (prefix `bench_legs `) and in bench_legs.json next to bench.py (and in gpurun_out/
+    when that directory exists), then the compact line -- alone -- on stdout."""
+    txt = json.dumps(full)
+    print("bench_legs " + txt, file=sys.stderr, flush=True)
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, LEGS_FILE), "w") as f:
+                    f.write(txt + "\n")
+            except OSError as e:      # a read-only tree: the line on stderr is the copy
+                print(f"bench.py: {LEGS_FILE} not written in {d}: {e}", file=sys.stderr)
+    print(json.dumps(compact_line(full)), file=stream or sys.stdout, flush=True)
 
 
 def kernel_name(eng):
@@ -198,6 +346,18 @@ def kernel_name(eng):
     if eng.info.stft_kernel == 2 and eng.channels == 1 and eng.info.render_path & 8:
         return KERNEL_NAMES["real"]
     return KERNEL_NAMES.get(eng.info.stft_kernel, ("?", "?"))
+
+
+def fp32_fracs(leg, nominal_flop_per_unit, units_per_s):
+    """SURVEY 8(d) asks for the FP32-vector fraction beside the HBM fraction.  `fp32_frac_nominal`: the 5 P log2 P convention (one
+    complex transform of the reference's length per frame, whatever the kernel really does) x rate / 157.3 TFLOP/s; `fp32_frac`: the
+    f32 operations the kernel EXECUTES per unit -- SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F32 x 64 lanes (FMA twice), a rocprofv3 --pmc
+    pass of this round committed as profiles/<round>_fp32_flops.json (tools/pmc_flops.py) -- x rate / peak; None without that file."""
+    counted = ((load_profile_json("fp32_flops") or {}).get("flop_per_unit") or {}).get(leg)
+    peak = FP32_PEAK_TFLOPS * 1e12
+    return {"fp32_frac_nominal": nominal_flop_per_unit * units_per_s / peak,
+            "fp32_frac": (counted * units_per_s / peak) if counted else None,
+            "fp32_flop_per_unit_counted": counted, "fp32_flop_per_unit_nominal": nominal_flop_per_unit}
 
 
 def stats_ms(v):
@@ -284,7 +444,7 @@ def library_loop_rate(np, oracle, W, H, frames, cores, ref):
         dt = time.perf_counter() - t0
     peak = np.abs(ref[:, 0]).max(axis=(1, 2), keepdims=True)
     ok = bool((np.abs(first - ref[:, 0]) <= 2e-5 * np.maximum(np.abs(ref[:, 0]), 0.02 * peak)).all())
-    return {"value": frames / dt, "unit": "frames/s", "cores": cores, "frames": frames, "matches_oracle": ok,
+    return {"value": frames / dt, "unit": "frames/s", "cores": cores, "frames": frames, "matches_oracle": ok, "impl": "numpy + scipy.fft (pocketfft) complex64",
             "what": "the whole frame loop of fft.rs:47-99 in numpy + scipy.fft (pocketfft) complex64, every thread its own chunks of 256 frames"}
 
 
@@ -306,7 +466,7 @@ def main_rank(args):
             ranks_sum = float(t[0])
         else:
             ranks_sum = 0.0
-        if os.environ.get("BENCH_FAIL_RANK") == str(rank):
+        if test_hook("BENCH_FAIL_RANK") == str(rank):
             os._exit(7)
         if rank == 0:
             print(json.dumps({"metric": "launcher self-test", "n_gpus": world, "ranks_sum": ranks_sum,
@@ -323,7 +483,7 @@ def main_rank(args):
     torch.cuda.set_device(local_rank)
     # BENCH_GROUP_OF_ONE=1 (tests/test_gpu_config5.py, one-GPU box): a single launched rank takes the multi-rank path -- process group
     # over `backend` (RCCL: init, barrier, all-reduce, all-gather execute for real; it refuses two ranks on one device), config-5 leg
-    grouped = world > 1 or (os.environ.get("BENCH_GROUP_OF_ONE") == "1" and "RANK" in os.environ)
+    grouped = world > 1 or (test_hook("BENCH_GROUP_OF_ONE") == "1" and "RANK" in os.environ)
     if grouped:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
@@ -450,6 +610,7 @@ def main_rank(args):
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
+                **fp32_fracs("config2_stft", NOMINAL_FLOP_4096, F / (kernel_ms * 1e-3)),
                 "frac_burst": frac_of(burst_ms), "frac_sustained": frac_of(sustained_ms),
                 "traffic": ((traffic or {}).get("stft_bytes_per_frame") or 0) * F or None,
                 "traffic_source": (traffic or {}).get("source"),
@@ -477,7 +638,7 @@ def main_rank(args):
 
     def on_stall():
         if rank == 0:
-            print(json.dumps(build_line({"error": f"a collective leg did not finish within {args.leg_timeout} s"})), flush=True)
+            emit_line(build_line({"error": f"a collective leg did not finish within {args.leg_timeout} s"}))
         os._exit(3)   # a stalled exchange is a failed run: never status 0
 
     extra = {}
@@ -514,7 +675,7 @@ def main_rank(args):
     except Exception as e:  # noqa: BLE001 -- reported in the line; the headline stands, the status does not
         extra["error"] = f"{type(e).__name__}: {e}"
         if rank == 0:
-            print(json.dumps(build_line(extra)), flush=True)
+            emit_line(build_line(extra))
         os._exit(3)       # the other ranks may be waiting in the exchange: nothing collective from here on
     watchdog.cancel()
 
@@ -524,7 +685,7 @@ def main_rank(args):
             pcm = eng.white_noise(W + 63 * H)     # the parity check of the leg reads the first 64 frames
         extra["cpu_baseline"] = cpu_baseline_leg(args, eng, pcm)
     if rank == 0:
-        print(json.dumps(build_line(extra)), flush=True)
+        emit_line(build_line(extra))
     if grouped:
         dist.destroy_process_group()
     return 0
@@ -661,7 +822,8 @@ def config3_leg(args, torch, eng, pcm, F):
         eng3 = SpectrogramEngine(48000.0, window_samples=W, hop_samples=H, channels=1, device=eng.device.index, interp=0, gradient="viridis")
         m3 = measure_leg(torch, lambda: eng3.render_batch(pcm, max_frames=Fp, out=rgba), args.leg_sustain_s)
         cubic = dict({"frames_per_s": Fp / (m3["mean_ms"] * 1e-3),
-                      "what": "the same leg with the cubic interpolator, which is what the reference runs"}, **leg_times(m3))
+                      "what": "the same leg with the cubic interpolator, which is what the reference runs"}, **leg_times(m3),
+                     **fp32_fracs("config3_cubic", NOMINAL_FLOP_4096, Fp / (m3["mean_ms"] * 1e-3)))
         parity["cubic"] = rgba_vs_oracle(torch, eng3, pcm, rgba, Fp, interp=0)
         eng3.close()
     except Exception as e:  # noqa: BLE001 -- an extra, never fatal
@@ -684,6 +846,7 @@ def config3_leg(args, torch, eng, pcm, F):
         "rgba_vs_oracle": parity,
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            **fp32_fracs("config3_cosine", NOMINAL_FLOP_4096, Fp / (mean * 1e-3)),
             "bytes_per_frame": ALGO_BYTES_PIXEL, "frames_per_launch": Fp,
             "traffic": ((traffic or {}).get("pixel_bytes_per_frame") or 0) * Fp or None,
             "traffic_source": (traffic or {}).get("source"),
@@ -741,6 +904,7 @@ def stereo_leg(args, torch, device):
         "workload": f"4096-pt Hann STFT, hop 256, {Fs} frames of an (l, r) white-noise stream (2 channels interleaved), one frame per transform",
         "frames_per_s": Fs / (mean * 1e-3), **leg_times(m),
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     **fp32_fracs("stereo4096", NOMINAL_FLOP_4096, Fs / (mean * 1e-3)),
                      "bytes_per_frame": ALGO_BYTES_STEREO, "frames_per_launch": Fs,
                      "kernel": "sgx::wg::stft4096_wg_kernel<false, 0, true, 0>",   # (l, r) at hop 256: the sliding-window instantiation
                      "first_allocation": first_allocation_of(torch, first, m, lambda buf: eng.stft_batch(pcm, out=buf), Fs * ALGO_BYTES_STEREO, args),
@@ -884,6 +1048,8 @@ def config4_leg(args, torch, device):
         **leg_times(m), "kernel": name[0], "output_bytes": hops * (C4 // 2) * (W4 - 1) * 8,
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            **fp32_fracs("config4", (C4 // 2) * NOMINAL_FLOP_16384, hops / (mean * 1e-3)),
+            "traffic_over_algorithmic": ((traffic or {}).get("config4_bytes_per_hop") or 0) / ALGO_BYTES_CFG4 or None,
             "bytes_per_hop_position": ALGO_BYTES_CFG4, "hop_positions_per_launch": hops,
             "traffic": ((traffic or {}).get("config4_bytes_per_hop") or 0) * hops or None,
             "traffic_source": (traffic or {}).get("source"),
@@ -918,11 +1084,22 @@ def config5_leg(args, torch, dist, eng, rank, world, backend, barrier, max_over_
     def produce(c0, n, buf):
         render_range(my_first + c0, n, buf)
 
+    # --config5-probe: a few pieces of the run that counts, spread from the first frame of the stream to the last, leave 8 of their
+    # columns behind (first, last, six between) for a host-side check against the oracle at far stream offsets
+    n_probe = int(getattr(args, "config5_probe", 0) or 0)
+    starts = sorted(ranges[r][0] + c0 for r in range(world) for c0 in range(0, counts[r], chunk))
+    probe_at = {starts[(j * (len(starts) - 1)) // max(n_probe - 1, 1)] for j in range(n_probe)} if starts else set()
+    probed = []      # (global frame index, [R][4] uint8 on the host)
+
     def consume(g0, piece):
         eng.checksum_add(piece, acc, base_word=g0 * R)
         for r in range(world):
             if g0 == ranges[r][0]:        # the first piece of rank r: kept apart for the sub-range check below
                 eng.checksum_add(piece, first_piece[r], base_word=g0 * R)
+        if g0 in probe_at:
+            n = piece.shape[0]
+            for j in sorted({(q * (n - 1)) // 7 for q in range(8)}):
+                probed.append((g0 + j, piece[j].cpu().numpy().copy()))
 
     def run(produce_fn, consume_fn, send=True):
         torch.cuda.synchronize()
@@ -942,7 +1119,7 @@ def config5_leg(args, torch, dist, eng, rank, world, backend, barrier, max_over_
     warm = min(1024, chunk)        # (the sample buffer and the rings hold `chunk` frames: never more per round)
     stream_columns([min(warm, c) for c in counts], warm, produce, lambda g0, p: None, like=like, dst=0)
     acc.zero_()
-    if os.environ.get("BENCH_FAIL_RANK") == str(rank):            # fault injection (tests/test_gpu_config5.py): a rank that dies inside the leg
+    if test_hook("BENCH_FAIL_RANK") == str(rank):                 # fault injection (tests/test_gpu_config5.py): a rank that dies inside the leg
         os._exit(7)
     t_over, arrived = run(produce, consume)                       # the run that counts: render + gather, overlapped
     t_comp, _ = run(produce, None, send=False)                    # render only
@@ -991,6 +1168,13 @@ def config5_leg(args, torch, dist, eng, rank, world, backend, barrier, max_over_
             "checksum_all_columns": int(acc[0]) & (2**64 - 1),
             "sharded_equals_single_gpu_on_first_chunk_of_every_rank": bool(ok),
         }
+        if n_probe:
+            import numpy as np
+            path = getattr(args, "config5_probe_file", None) or os.path.join(
+                ROOT, "gpurun_out" if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else "", "config5_probes.npz")
+            np.savez(path, frames=np.array([t for t, _ in probed], np.int64),
+                     rgba=np.stack([c for _, c in probed]) if probed else np.zeros((0, R, 4), np.uint8))
+            out["probes"], out["probes_file"] = len(probed), os.path.relpath(path, ROOT)
     return out
 
 
@@ -1024,7 +1208,7 @@ def cpu_baseline_leg(args, eng, pcm):
     peak = np.abs(ref[:, 0]).max(axis=(1, 2), keepdims=True)
     ok = bool((np.abs(got - ref[:, 0]) <= 2e-5 * np.maximum(np.abs(ref[:, 0]), 0.02 * peak)).all())
     cpu = {
-        "value": Fc / cdt, "unit": "frames/s", "cores": cores, "kind": "port",
+        "value": Fc / cdt, "unit": "frames/s", "cores": cores, "kind": "port", "impl": "plain C (oracle/spectro_oracle.c)",
         "nproc": info["nproc"], "affinity": info["affinity"], "cgroup_cpu_quota": info["cgroup_cpu_quota"], "cpu_model": info["cpu_model"],
         "sample": f"first {Fc} frames of the same white-noise stream, float32 oracle (oracle/spectro_oracle.c), {cores} threads, "
                   f"{cdt * cores:.1f} thread-seconds",
@@ -1062,13 +1246,14 @@ def cpu_baseline_leg(args, eng, pcm):
         cpu["library_fft"] = {"error": f"{type(e).__name__}: {e}"}
     # ... and the WHOLE frame loop around it: the fairer CPU baseline.  `value` is the faster of the two complete loops (the oracle's
     # plain-C port, a checker with a textbook recursive FFT, and this one); both are reported
-    cpu["port"] = {"value": cpu["value"], "unit": "frames/s", "cores": cores, "sample": cpu["sample"], "parity_on_sample": ok}
+    cpu["port"] = {"value": cpu["value"], "unit": "frames/s", "cores": cores, "sample": cpu["sample"], "parity_on_sample": ok, "impl": cpu["impl"]}
     try:
         lib = library_loop_rate(np, oracle, W, H, min(Fc, 131072), cores, ref)
         cpu["library"] = lib
         if lib["matches_oracle"] and lib["value"] > cpu["value"]:
-            cpu.update(value=lib["value"], kind="library",
-                       sample=f"first {lib['frames']} frames of the same white-noise stream, {lib['what']}, {cores} threads")
+            # still a PORT of the reference's frame loop (kind): a stand-in for its FFTW path, which this image cannot build
+            cpu.update(value=lib["value"], kind="port", impl=lib["impl"],
+                       sample=f"first {lib['frames']} frames of the same white-noise stream, fft.rs:47-99 in numpy + pocketfft c64, {cores} threads")
     except Exception as e:  # noqa: BLE001
         cpu["library"] = {"error": f"{type(e).__name__}: {e}"}
     return cpu

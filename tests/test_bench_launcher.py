@@ -26,8 +26,13 @@ def test_bare_multi_gpu_invocation_spawns_the_ranks_and_relays_one_line():
 
 
 def test_a_failing_rank_fails_the_bare_invocation():
-    p = run_bench({"BENCH_FAIL_RANK": "1"}, "--gpus", "2")
+    p = run_bench({"BENCH_FAIL_RANK": "1", "BENCH_TEST_HOOKS": "1"}, "--gpus", "2")
     assert p.returncode != 0   # (rank 0 may still have printed its line: the status is what tells the driver)
+
+
+def test_a_stray_hook_variable_without_the_switch_changes_nothing():
+    p = run_bench({"BENCH_FAIL_RANK": "1"}, "--gpus", "2")          # no BENCH_TEST_HOOKS=1 beside it: read as unset
+    assert p.returncode == 0, p.stderr[-2000:]
 
 
 def test_single_gpu_invocation_stays_in_process():

@@ -102,3 +102,75 @@ def test_measure_leg_reports_burst_and_the_steady_part_of_the_sustained_window(m
     assert t["launch_ms"] == t["launch_ms_sustained"] and t["sustain_s"] > 0
     m0 = bench.measure_leg(fake_torch(FakeDevice()), lambda: None, sustain_s=0.0)
     assert m0["launch_ms_sustained"]["n"] == 5                                           # no sustain window: the burst is the figure
+
+
+# ---- the ONE stdout line (the 21 KB line of that round was not parsed by the driver) --------------------------------
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def full_record_of_round_5():
+    import json
+    with open(os.path.join(ROOT, "profiles", "r05_bench_n1.json")) as f:      # the real 21 041-byte line of round 5
+        return json.load(f)
+
+
+def test_the_stdout_line_fits_its_budget_and_keeps_every_contract_key():
+    import json
+    full = full_record_of_round_5()
+    assert len(json.dumps(full)) > 20_000
+    line = bench.compact_line(full)
+    txt = json.dumps(line)
+    assert len(txt) <= bench.LINE_BUDGET == 4096
+    for k in bench.CONTRACT_KEYS:
+        assert k in line, k
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"):
+        assert line[k] == full[k]                                              # the contract's scalars: verbatim, never rounded
+    assert line["config"]["workload"].startswith("configs[1]")
+    rf = line["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-6
+    assert "traffic" in rf and abs(rf["frac"] - full["roofline"]["frac"]) < 1e-6
+    cb = line["cpu_baseline"]
+    assert cb["value"] > 0 and cb["cores"] == 16 and cb["unit"] == "frames/s" and "sample" in cb and cb["kind"] in ("port", "library")
+    assert abs(line["config3_frac"] - full["config3"]["roofline"]["frac"]) < 1e-6
+    assert abs(line["config4_frac"] - full["config4"]["roofline"]["frac"]) < 1e-6
+    assert abs(line["stereo_frac"] - full["stereo4096"]["roofline"]["frac"]) < 1e-6
+    assert line["legs_file"] == bench.LEGS_FILE
+
+
+def test_an_oversized_record_loses_extras_never_contract_keys():
+    import json
+    full = full_record_of_round_5()
+    full["error"] = "RuntimeError: " + "x" * 5000                             # a long error text
+    full["config"]["workload"] += " " + "y" * 3000
+    full["config5"] = {"backend": "nccl", "ranks_seen": list(range(8)), "frames_total": 10**8, "frames_per_gpu": [12_500_000] * 8,
+                       "chunk_columns": 65536, "rounds": 191, "frames_per_s": 1.9e9, "gathered_bytes": 358_400_000_000,
+                       "checksum_all_columns": 2**63 + 12345, "sharded_equals_single_gpu_on_first_chunk_of_every_rank": True,
+                       "GBps_per_source_alone": [{"source": r, "bytes": 1, "GBps": 47.123456789} for r in range(1, 8)],
+                       "workload": "z" * 500}
+    line = bench.compact_line(full)
+    assert len(json.dumps(line)) <= 4096
+    for k in bench.CONTRACT_KEYS:
+        assert k in line, k
+    assert line["error"].startswith("RuntimeError") and line["config5"]["ranks_seen"] == list(range(8))
+    assert line["config5"]["checksum_all_columns"] == 2**63 + 12345           # integers are never rounded
+
+
+def test_emit_line_puts_the_full_record_on_stderr_and_in_the_legs_file(tmp_path, monkeypatch, capsys):
+    import json
+    full = full_record_of_round_5()
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    bench.emit_line(full)
+    out, err = capsys.readouterr()
+    lines = [ln for ln in out.splitlines() if ln.strip()]
+    assert len(lines) == 1 and len(lines[0]) <= 4096 and json.loads(lines[0])["metric"] == full["metric"]
+    legs = [ln for ln in err.splitlines() if ln.startswith("bench_legs ")]
+    assert len(legs) == 1 and json.loads(legs[0][len("bench_legs "):]) == full
+    assert json.load(open(tmp_path / bench.LEGS_FILE)) == full
+
+
+def test_fp32_fraction_is_counted_flops_times_rate_over_the_vector_peak(monkeypatch):
+    monkeypatch.setattr(bench, "load_profile_json", lambda name: {"flop_per_unit": {"stereo4096": 300_000.0}} if name == "fp32_flops" else None)
+    f = bench.fp32_fracs("stereo4096", bench.NOMINAL_FLOP_4096, 200e6)
+    assert abs(f["fp32_frac"] - 300_000.0 * 200e6 / 157.3e12) < 1e-12
+    assert abs(f["fp32_frac_nominal"] - 245_760 * 200e6 / 157.3e12) < 1e-12
+    assert bench.fp32_fracs("config4", 4 * bench.NOMINAL_FLOP_16384, 8.4e6)["fp32_frac"] is None      # no counter pass for that leg: said, not guessed
