@@ -36,7 +36,7 @@ def gold():
 # 1.7e-7 .. 2.8e-7 of the frame peak and sits in the top 10 dB, its pure relative error passes 1e-5 between 40 and
 # 50 dB below the peak, and the floor that would just hold is 0.007 .. 0.011.  (Round 1 used 0.05.)
 REL_TOL = 1e-5
-PEAK_FLOOR = 0.02
+PEAK_FLOOR = 0.012
 # Multiples of that bound a kernel is held to against the float64 truth: 1 x for every kernel on every BASELINE path and every other
 # kernel -- with ONE measured exception: the chirp-z convolution at its largest length, L = 16384 (windows with 3W - 1 > 8192 whose 2W
 # has a prime factor above 7), where two 16384-point float32 transforms and three chirp products stand behind every bin: the worst
