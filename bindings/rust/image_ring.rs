@@ -14,12 +14,14 @@ extern "C" {
     pub fn sgx_image_destroy(image: *mut SgxImage);
     pub fn sgx_image_write_columns(image: *mut SgxImage, d_rgba: *const u8, n_columns: usize, offset_out: *mut u32) -> c_int;
     pub fn sgx_image_offset(image: *const SgxImage) -> u32;
+    pub fn sgx_image_width(image: *const SgxImage) -> u32;
+    pub fn sgx_image_height(image: *const SgxImage) -> u32;
     pub fn sgx_live_tick_image(live: *mut SgxLive, image: *mut SgxImage, max_frames: usize, n_frames: *mut usize) -> c_int;
     pub fn sgx_image_read(image: *mut SgxImage, scrolled: c_int, d_out: *mut u8) -> c_int;
     pub fn sgx_image_pixels(image: *const SgxImage) -> *const u8;
 }
 
-pub struct ImageRing { raw: *mut SgxImage, pub width: u32 }
+pub struct ImageRing { raw: *mut SgxImage, pub width: u32, pub height: u32 }
 
 impl ImageRing {
     /// `Pixbuf::new(Colorspace::Rgb, true, 8, TEXTURE_WIDTH, TEXTURE_HEIGHT)` (:89-94); the height is the context's row count
@@ -27,7 +29,8 @@ impl ImageRing {
         let mut raw = std::ptr::null_mut();
         let rc = unsafe { sgx_image_create(ctx, width, &mut raw) };
         assert_eq!(rc, 0);
-        Self { raw, width }
+        // `buffer.width()` / `buffer.height()` (:150, :186-187): read back, so that a caller sizes `scrolled_into`'s buffer from the image
+        Self { raw, width: unsafe { sgx_image_width(raw) }, height: unsafe { sgx_image_height(raw) } }
     }
 
     /// the body of `for frequency_sample in self.fft.borrow_mut().process() { ... }` (:136-165) for one GUI tick:
@@ -45,6 +48,7 @@ impl ImageRing {
     /// device pointer to [height][width][4] bytes, rowstride 4 * width: what a GL / Vulkan interop texture (or one
     /// hipMemcpyDtoH into the Pixbuf's own pixels) takes; `scrolled_into` gives the picture of :181-209 in one piece instead
     pub fn pixels(&self) -> *const u8 { unsafe { sgx_image_pixels(self.raw) } }
+    /// `d_out`: a device buffer of `height * width * 4` bytes
     pub fn scrolled_into(&self, d_out: *mut u8) { assert_eq!(unsafe { sgx_image_read(self.raw, 1, d_out) }, 0); }
 }
 

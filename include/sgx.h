@@ -344,6 +344,10 @@ SGX_API void sgx_image_destroy(sgx_image *image);
  * laps itself and the later columns win, as written one by one.  The new offset is returned. */
 SGX_API int sgx_image_write_columns(sgx_image *image, const uint8_t *d_rgba, size_t n_columns, uint32_t *offset_out);
 SGX_API uint32_t sgx_image_offset(const sgx_image *image);
+/* the Pixbuf's get_width() / get_height() (:89-94): width as created, height = the context's rows -- what a caller sizes the
+ * buffer of sgx_image_read with (0 for a null image) */
+SGX_API uint32_t sgx_image_width(const sgx_image *image);
+SGX_API uint32_t sgx_image_height(const sgx_image *image);
 /* One GUI tick of SimpleSpectrogram::snapshot (:136-165: `for frequency_sample in fft.process()` -> put_pixel): every complete frame
  * of the live ring, at most max_frames, becomes a pixel column of the image, device to device. */
 SGX_API int sgx_live_tick_image(sgx_live *live, sgx_image *image, size_t max_frames, size_t *n_frames);

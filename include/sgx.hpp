@@ -217,10 +217,13 @@ private:
 // put_pixel loop with its offset update (:140-164) as tick(), the picture of the two sub-images (:181-209) as scrolled().
 class ImageRing {
 public:
-    ImageRing(FastFourierTransform &transform, std::uint32_t width, std::uint32_t rows) : transform_(transform), width_(width), rows_(rows)
+    // (the height is never the caller's to choose: it is the context's row count, read back from the image)
+    ImageRing(FastFourierTransform &transform, std::uint32_t width) : transform_(transform)
     {
         const int rc = sgx_image_create(transform.ctx(), width, &image_);
         if (rc != SGX_OK) throw Error(rc, sgx_last_error(transform.ctx()));
+        width_ = sgx_image_width(image_);
+        rows_ = sgx_image_height(image_);
     }
     ImageRing(const ImageRing &) = delete;
     ImageRing &operator=(const ImageRing &) = delete;
@@ -235,6 +238,8 @@ public:
         return got;
     }
     std::size_t offset() const { return sgx_image_offset(image_); }
+    std::uint32_t width() const { return width_; }
+    std::uint32_t height() const { return rows_; }
 
     // [rows][width][4] bytes on the host: the buffer as it lies, or the scrolled picture
     std::vector<std::uint8_t> pixels(bool scrolled = false)
@@ -255,7 +260,7 @@ public:
 private:
     FastFourierTransform &transform_;
     sgx_image *image_ = nullptr;
-    std::uint32_t width_, rows_;
+    std::uint32_t width_ = 0, rows_ = 0;
 };
 
 // audio_transform.rs:14-43; the three members are public and assignable, as in the reference

@@ -125,6 +125,8 @@ SIGNATURES = [
     ("sgx_image_destroy", None, [C.c_void_p]),
     ("sgx_image_write_columns", C.c_int, [C.c_void_p, _vp, _sz, C.POINTER(C.c_uint32)]),
     ("sgx_image_offset", C.c_uint32, [C.c_void_p]),
+    ("sgx_image_width", C.c_uint32, [C.c_void_p]),
+    ("sgx_image_height", C.c_uint32, [C.c_void_p]),
     ("sgx_live_tick_image", C.c_int, [C.c_void_p, C.c_void_p, _sz, C.POINTER(_sz)]),
     ("sgx_image_read", C.c_int, [C.c_void_p, C.c_int, _vp]),
     ("sgx_image_pixels", C.c_void_p, [C.c_void_p]),

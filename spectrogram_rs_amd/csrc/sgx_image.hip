@@ -143,6 +143,8 @@ int sgx_image_write_columns(sgx_image *im, const uint8_t *d_rgba, size_t n_colum
 }
 
 uint32_t sgx_image_offset(const sgx_image *im) { return im ? im->offset : 0; }
+uint32_t sgx_image_width(const sgx_image *im) { return im ? im->width : 0; }
+uint32_t sgx_image_height(const sgx_image *im) { return im ? im->height : 0; }
 
 int sgx_image_read(sgx_image *im, int scrolled, uint8_t *d_out)
 {

@@ -57,7 +57,7 @@ __device__ unsigned long long g_phase_cycles[20];
 #define SGX_ADDTID 1   // (0: the (l, r) sliding kernel with the b64 transposes of every other instantiation, for A/B)
 #endif
 // rows q and q + 1 of the real and the imaginary plane, this wave's 64 words of each: LDS address = M0 + offset + 4 * lane
-// (M0 is set inside the statement: the compiler neither knows about nor relies on its value)
+// (M0 is set inside the statement and declared clobbered: whatever the compiler keeps in M0 -- LDS-DMA bases, indexed moves -- it restores)
 __device__ __forceinline__ void addtid_rows(float2 a, float2 b, uint32_t m0_wave, int q)
 {
     asm volatile("s_mov_b32 m0, %4\n\t"
@@ -68,7 +68,7 @@ __device__ __forceinline__ void addtid_rows(float2 a, float2 b, uint32_t m0_wave
                  "ds_write_addtid_b32 %3 offset:%8"
                  :
                  : "v"(a.x), "v"(a.y), "v"(b.x), "v"(b.y), "s"(m0_wave), "i"(1088 * q), "i"(1088 * q + 17408), "i"(1088 * (q + 1)), "i"(1088 * (q + 1) + 17408)
-                 : "memory");
+                 : "memory", "m0");
 }
 // the 16 values of this thread's next transform: 16 consecutive words of its row in either plane
 __device__ __forceinline__ void read_planes(const float4 *rd4, float (&xr)[16], float (&xi)[16])
@@ -593,7 +593,8 @@ hipError_t wg4096_init(sgx_ctx *c, void **out)
     };
     for (size_t i = 0; i < rows.size(); ++i) {
         const auto &r = c->tab.rows[i];
-        if (r.count >= 256 || samples.size() >= 65536) fusable = false;   // (block_max_cnt holds a byte per block of 256 rows)
+        // (the row word holds 16 bits of count; only the SGX_ROW_BATCH row pass keeps a BYTE per block of 256 rows, block_max_cnt)
+        if (r.count >= (SGX_ROW_BATCH ? 256u : 65536u) || samples.size() >= 65536) fusable = false;
         rows[i] = ((uint32_t)samples.size() & 0xffffu) | ((r.count & 0xffffu) << 16);
         for (uint32_t j = 0; j < r.count; ++j) samples.push_back(packed(c->tab.samples[r.first + j]));
         if (r.count >= 4 && (r.count & 1u) == 0) samples.push_back(samples.back());   // the pad slot

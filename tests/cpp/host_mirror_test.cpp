@@ -56,7 +56,8 @@ int main(int argc, char **argv)
         {
             const uint32_t width = 16, rows = 1024;
             LiveRing live_a(fft, 1 << 16), live_b(fft, 1 << 16);
-            ImageRing image(fft, width, rows);
+            ImageRing image(fft, width);
+            if (image.width() != width || image.height() != rows) return 8;      // the height is the context's R, not an argument
             std::vector<uint8_t> want((size_t)rows * width * 4, 0), cols(64 * (size_t)rows * 4);
             size_t off = 0, total = 0;
             for (size_t i = 0; i < n; i += 480) {

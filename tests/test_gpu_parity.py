@@ -934,12 +934,17 @@ def test_fused_kernel_equals_two_kernel_path(torch_cuda, channels, frames, mode,
     dict(rows=2048, f_min=32.0, f_max=22030.0, min_db=-70.0, max_db=-10.0, interp=0, lut_index_mode=1),  # round-to-nearest LUT rule
     dict(rows=300, f_min=1.0, f_max=90000.0, min_db=-70.0, max_db=-10.0, interp=0),       # axis far outside the spectrum: index clamps at both ends
 ])
-def test_pixel_path_configuration_space(torch_cuda, gradients, cfg):
-    # fused kernel, two-kernel path and oracle agree for every axis / dB range / LUT rule (on the engine's own magnitudes)
+@pytest.mark.parametrize("channels", [1, 2])
+def test_pixel_path_configuration_space(torch_cuda, gradients, cfg, channels):
+    # fused kernel, two-kernel path and oracle agree for every axis / dB range / LUT rule (on the engine's own magnitudes); mono runs
+    # the real-input kernel's pixel passes, (l, r) the complex kernel's.  rows = 7: the top rows average > 256 samples each -- fused
+    # all the same (the row word holds 16 bits of count)
     torch = torch_cuda
-    pcm = to_dev(torch, oracle.white_noise(W + 20 * H, seed=101) * np.float32(0.2))
-    kw = dict(window_samples=W, hop_samples=H, channels=1, gradient="inferno", **cfg)
+    pcm = to_dev(torch, oracle.white_noise((W + 20 * H) * channels, seed=101) * np.float32(0.2))
+    kw = dict(window_samples=W, hop_samples=H, channels=channels, gradient="inferno", **cfg)
     fused, split = engine(**kw), engine(fused_render=False, **kw)
+    if cfg["rows"] == 7:
+        assert fused.row_sample_counts().max() >= 256 and fused.info.render_path & 1, "the fused kernel must serve rows of 256 samples and more"
     a = fused.render_batch(pcm).cpu().numpy()[:, 0]
     b = split.render_batch(pcm).cpu().numpy()[:, 0]
     mags = fused.stft_batch(pcm).cpu().numpy()[:, 0]
