@@ -105,6 +105,7 @@ typedef struct sgx_config {
 #define SGX_FLAG_LUT_WALK 64u      /* fused pixel kernel: walk the dB thresholds from the log2 seed even where the host has shown that one compare pair settles the LUT index (A/B, and the test of the fallback) */
 #define SGX_FLAG_RESIDUE_16K 128u  /* W = 8192: the second 16384-point kernel (four 4096-point residues of the OUTPUT, two passes of a 512-thread workgroup) instead of the time-decimated one (A/B) */
 #define SGX_FLAG_CHANNEL_PLANES 2048u /* W = 8192, more than two channels: split the call's sample range into per-pair (l, r) planes first and transform those (the default of rounds 3-5: a second kernel, a workspace grown on the call, HBM traffic 1.15 x algorithmic) instead of reading every pair where it lies in the interleaved stream (8-byte loads at a stride of `channels` floats: traffic 1.02 x).  Same bytes; 2 % faster on short launches, 1 % slower at BASELINE config 4's size (A/B, profiles/r05_k16.txt) */
+#define SGX_FLAG_K16_W 4096u /* W = 8192: the fourth 16384-point kernel (32 x 32 x 16 in one 512-thread workgroup, 32 points per thread: stft16384_w.hip) instead of the lane-quad one (A/B) */
 #define SGX_FLAG_MIXED_GENERIC 256u /* W = 2400: the composite-radix kernel (any 2-3-5-7-smooth length) instead of the tuned 4800-point one (A/B) */
 
 typedef struct sgx_info {

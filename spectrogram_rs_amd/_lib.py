@@ -29,6 +29,7 @@ FLAG_MIXED_GENERIC = 256
 FLAG_COMPLEX_MONO = 512
 FLAG_PAIRED_FRAMES = 1024
 FLAG_CHANNEL_PLANES = 2048
+FLAG_K16_W = 4096
 LIVE_MAGS, LIVE_MAGS_F16, LIVE_RGBA = 0, 1, 2
 LIVE_REFERENCE_SKIP = 1
 

@@ -233,6 +233,7 @@ hipError_t run_stft(const sgx_ctx *c, const float *d_pcm, uint32_t channels, uin
     // W = 8192: the four-residue kernel, (l, r) streams and mono frame pairs alike (independent mono frames: generic)
     if (c->stft_kernel == 5 && (channels != 1 || !(c->cfg.flags & SGX_FLAG_INDEPENDENT_FRAMES)))
         return sgx::launch_stft_q16384(c, c->d_q16k, d_pcm, channels, pairs, first, n, total, d_mags);
+    if (c->stft_kernel == 10) return sgx::launch_stft_w16384(c, c->d_w16k, d_pcm, channels, pairs, first, n, total, d_mags);
     if (c->stft_kernel == 8)   // (a mono stream whose frames are not paired: as an (s, s) plane through the two-channel kernel; the 8192-point
                                // plan of the mixed-radix kernel's real-input mode measured no faster: 31.4 against 32.6 M frames/s, round 4)
         return sgx::launch_stft_d16384(c, c->d_d16k, d_pcm, channels, pairs, first, n, total, d_mags);
@@ -393,6 +394,10 @@ int sgx_create(const sgx_config *cfg, sgx_ctx **out_ctx)
             if (e != hipSuccess) return bail(SGX_ERR_HIP, std::string("sgx_create: real-input kernel tables: ") + hipGetErrorString(e));
         }
         c->stft_kernel = 2;
+    } else if ((cfg->flags & SGX_FLAG_K16_W) && !(cfg->flags & SGX_FLAG_FORCE_GENERIC) && sgx::w16384_supported(c)) {
+        e = sgx::w16384_init(c, &c->d_w16k);
+        if (e != hipSuccess) return bail(SGX_ERR_HIP, std::string("sgx_create: 16384-point kernel tables: ") + hipGetErrorString(e));
+        c->stft_kernel = 10;
     } else if (!(cfg->flags & (SGX_FLAG_FORCE_GENERIC | SGX_FLAG_RESIDUE_16K)) && sgx::d16384_supported(c)) {
         e = sgx::d16384_init(c, &c->d_d16k);
         if (e != hipSuccess) return bail(SGX_ERR_HIP, std::string("sgx_create: 16384-point kernel tables: ") + hipGetErrorString(e));
@@ -426,6 +431,8 @@ void sgx_destroy(sgx_ctx *c)
     c->d_chz = nullptr;
     sgx::q16384_destroy(c->d_q16k);
     c->d_q16k = nullptr;
+    sgx::w16384_destroy(c->d_w16k);
+    c->d_w16k = nullptr;
     sgx::d16384_destroy(c->d_d16k);
     c->d_d16k = nullptr;
     void *ptrs[] = {c->d_window, c->d_twiddle, c->d_rows, c->d_samples, c->d_lut_thr, c->d_alpha_thr,

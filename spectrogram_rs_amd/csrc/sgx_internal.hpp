@@ -128,6 +128,7 @@ struct sgx_ctx {
     void *d_w4800 = nullptr;       // tables of the tuned 4800-point kernel (W = 2400: the application's window at 48 kHz)
     void *d_real = nullptr;        // tables of the real-input 4096-point kernel (independent mono frames at W 2048 / H 256)
     void *d_chz = nullptr;         // chirp-z through the mixed-radix kernel's stages (or null: the radix-4 ladder of stft_bluestein.hip)
+    void *d_w16k = nullptr;        // tables of the 16384-point kernel, 32 x 32 x 16 (stft16384_w.hip)
     void *d_q16k = nullptr;        // tables of the 16384-point kernel, four 4096-point residues of the output (SGX_FLAG_RESIDUE_16K)
     void *d_d16k = nullptr;        // tables of the 16384-point kernel, four time-decimated 4096-point transforms per lane quad (the default)
 
@@ -179,6 +180,12 @@ bool d16384_supported(const sgx_ctx *c);
 hipError_t d16384_init(sgx_ctx *c, void **out);
 void d16384_destroy(void *tables);
 hipError_t launch_stft_d16384(const sgx_ctx *c, void *tables, const float *d_pcm, uint32_t channels, uint32_t pairs,
+                              size_t first_frame, size_t n_frames, size_t total_frames, float *d_mags);
+// stft16384_w.hip: W = 8192 as 32 x 32 x 16 in one 512-thread workgroup, 32 points per thread
+bool w16384_supported(const sgx_ctx *c);
+hipError_t w16384_init(sgx_ctx *c, void **out);
+void w16384_destroy(void *tables);
+hipError_t launch_stft_w16384(const sgx_ctx *c, void *tables, const float *d_pcm, uint32_t channels, uint32_t pairs,
                               size_t first_frame, size_t n_frames, size_t total_frames, float *d_mags);
 bool q16384_supported(const sgx_ctx *c);
 hipError_t q16384_init(sgx_ctx *c, void **out);

@@ -16,7 +16,10 @@
 #include <cstdio>
 #include <new>
 
+#include "live_ring.hpp"
 #include "sgx_internal.hpp"
+
+static_assert(sizeof(sgx::RingPair) == sizeof(float2), "the ring's pairs are the device's float2");
 
 struct sgx_live {
     sgx_ctx *ctx = nullptr;
@@ -27,8 +30,7 @@ struct sgx_live {
     float2 *d_alt = nullptr;         // [capacity] compaction target (ping-pong)
     void *d_out = nullptr;           // results of one tick
     size_t out_bytes = 0;
-    std::atomic<unsigned long long> pushed{0}, skipped{0};
-    unsigned long long uploaded = 0;
+    sgx::LiveRingState ring;         // positions and the lock-free producer / consumer protocol (live_ring.hpp: host only, sanitizer-tested)
 };
 
 namespace {
@@ -83,6 +85,8 @@ int sgx_live_create(sgx_ctx *c, size_t capacity_pairs, uint32_t flags, sgx_live 
         sgx_live_destroy(l);
         return rc;
     }
+    l->ring.slots = reinterpret_cast<sgx::RingPair *>(l->h_ring);
+    l->ring.capacity = capacity_pairs;
     *out = l;
     return SGX_OK;
 }
@@ -106,27 +110,12 @@ long long sgx_live_push(sgx_live *l, const float *h_samples, size_t n_values, ui
     if (!l) return SGX_ERR_INVALID_ARG;
     if (channels != 1 && channels != 2) return SGX_ERR_UNSUPPORTED;  // "{}-channel input not supported!" (:73)
     if (n_values && !h_samples) return SGX_ERR_INVALID_ARG;
-    const unsigned long long head = l->pushed.load(std::memory_order_relaxed);
-    const unsigned long long tail = l->skipped.load(std::memory_order_acquire);
-    const size_t vacant = l->capacity - (size_t)(head - tail);
-    size_t n = channels == 1 ? n_values : n_values / 2;  // tuples() drops a trailing odd value (:71)
-    if (n > vacant) n = vacant;
-    size_t slot = (size_t)(head % l->capacity);
-    for (size_t i = 0; i < n; ++i) {
-        l->h_ring[slot] = channels == 1 ? make_float2(h_samples[i], h_samples[i])  // :67-69
-                                        : make_float2(h_samples[2 * i], h_samples[2 * i + 1]);
-        if (++slot == l->capacity) slot = 0;
-    }
-    l->pushed.store(head + n, std::memory_order_release);
-    return (long long)n;
+    return (long long)l->ring.push(h_samples, n_values, channels);
 }
 
 size_t sgx_live_occupied(const sgx_live *l)
 {
-    if (!l) return 0;
-    const unsigned long long tail = l->skipped.load(std::memory_order_acquire);
-    const unsigned long long head = l->pushed.load(std::memory_order_acquire);
-    return (size_t)(head - tail);
+    return l ? l->ring.occupied() : 0;
 }
 
 static int live_tick(sgx_live *l, int what, void *h_out, sgx_view *view, sgx_image *image, size_t max_frames, size_t *n_frames);
@@ -170,19 +159,14 @@ static int live_tick(sgx_live *l, int what, void *h_out, sgx_view *view, sgx_ima
     LIVE_HIP(l, hipSetDevice(c->device));
 
     // the samples that arrived since the last tick
-    const unsigned long long tail = l->skipped.load(std::memory_order_relaxed);
-    const unsigned long long head = l->pushed.load(std::memory_order_acquire);
-    if (head > l->uploaded) {
-        const size_t fresh = (size_t)(head - l->uploaded);
-        const size_t slot = (size_t)(l->uploaded % l->capacity);
-        const size_t first = fresh < l->capacity - slot ? fresh : l->capacity - slot;
-        float2 *dst = l->d_cur + (size_t)(l->uploaded - tail);
-        LIVE_HIP(l, hipMemcpyAsync(dst, l->h_ring + slot, first * sizeof(float2), hipMemcpyHostToDevice, c->stream));
-        if (fresh > first)
-            LIVE_HIP(l, hipMemcpyAsync(dst + first, l->h_ring, (fresh - first) * sizeof(float2), hipMemcpyHostToDevice, c->stream));
-        l->uploaded = head;
+    const sgx::LiveRingState::Upload up = l->ring.begin_tick();
+    if (up.first) {
+        float2 *dst = l->d_cur + up.dst;
+        LIVE_HIP(l, hipMemcpyAsync(dst, l->h_ring + up.slot, up.first * sizeof(float2), hipMemcpyHostToDevice, c->stream));
+        if (up.second)
+            LIVE_HIP(l, hipMemcpyAsync(dst + up.first, l->h_ring, up.second * sizeof(float2), hipMemcpyHostToDevice, c->stream));
     }
-    const size_t occupied = (size_t)(head - tail);
+    const size_t occupied = up.occupied;
 
     // the hop loop: every complete frame, one launch
     size_t frames = sgx_num_frames(c, occupied);
@@ -217,11 +201,8 @@ static int live_tick(sgx_live *l, int what, void *h_out, sgx_view *view, sgx_ima
         }
     }
 
-    // ring.skip(H) per yielded frame; the reference's loop also skips on the read that returns None
-    // (audio_transform.rs:37-41) unless the caller's max_frames ended this tick early
-    size_t skip = frames * (size_t)c->H;
-    if ((l->flags & SGX_LIVE_REFERENCE_SKIP) && !truncated) skip += c->H;
-    if (skip > occupied) skip = occupied;  // HeapRb::skip stops at the end of the ring
+    // ring.skip(H) per yielded frame, the reference's extra skip on the terminating read (live_ring.hpp)
+    const size_t skip = sgx::LiveRingState::skip_of(frames, c->H, (l->flags & SGX_LIVE_REFERENCE_SKIP) != 0, truncated, occupied);
     const size_t keep = occupied - skip;
     if (skip && keep) {
         LIVE_HIP(l, hipMemcpyAsync(l->d_alt, l->d_cur + skip, keep * sizeof(float2), hipMemcpyDeviceToDevice, c->stream));
@@ -231,7 +212,7 @@ static int live_tick(sgx_live *l, int what, void *h_out, sgx_view *view, sgx_ima
     }
     // the pinned slots just uploaded are reusable only once the copies above have run
     LIVE_HIP(l, hipStreamSynchronize(c->stream));
-    l->skipped.store(tail + skip, std::memory_order_release);
+    l->ring.end_tick(up, skip);
     if (n_frames) *n_frames = frames;
     return SGX_OK;
 }

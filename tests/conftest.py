@@ -36,7 +36,14 @@ def gold():
 # 1.7e-7 .. 2.8e-7 of the frame peak and sits in the top 10 dB, its pure relative error passes 1e-5 between 40 and
 # 50 dB below the peak, and the floor that would just hold is 0.007 .. 0.011.  (Round 1 used 0.05.)
 REL_TOL = 1e-5
+# Round 6: 0.012 for the kernels of BASELINE configs 1-3 and 5 (K1R, K1 at W 2048 / H 256, mono and (l, r); every test that does not
+# name another floor) -- measured need 0.007 .. 0.011.  The other kernels need more and say so where they are tested (measured on the
+# GPU suite at 0.012, worst ratio x 0.012): the 16384-point kernel at config 4's own size 0.0132; the 4096-point kernel on 4 and 8
+# interleaved channels 0.0129; W 5461 real-input mixed radix 0.0126; W 2400 against the float32 oracle (two float32 transforms, one
+# of them with 25-term prime-factor sums) 0.0143; chirp-z lengths of the fuzz suite 0.0153.
 PEAK_FLOOR = 0.012
+FLOOR_K16 = 0.014        # W 8192 (BASELINE config 4)
+FLOOR_WIDE = 0.02        # every other window / channel count (the floor of rounds 2-5 for all kernels)
 # Multiples of that bound a kernel is held to against the float64 truth: 1 x for every kernel on every BASELINE path and every other
 # kernel -- with ONE measured exception: the chirp-z convolution at its largest length, L = 16384 (windows with 3W - 1 > 8192 whose 2W
 # has a prime factor above 7), where two 16384-point float32 transforms and three chirp products stand behind every bin: the worst
@@ -49,12 +56,13 @@ def chirpz_bound(W):
     return KERNEL_BOUND["chirp-z, L = 16384"] if 3 * W - 1 > 8192 else KERNEL_BOUND["default"]
 
 
-def mags_error(x, ref):
+def mags_error(x, ref, floor=None):
     """worst ratio of |x - ref| to its allowance, per frame layout [..., M, 2]; <= 1 passes"""
+    floor = PEAK_FLOOR if floor is None else floor
     x = np.asarray(x, np.float64)
     ref = np.asarray(ref, np.float64)
     peak = np.abs(ref).max(axis=(-1, -2), keepdims=True)
-    allow = REL_TOL * np.maximum(np.abs(ref), PEAK_FLOOR * peak)
+    allow = REL_TOL * np.maximum(np.abs(ref), floor * peak)
     allow = np.maximum(allow, 1e-30)
     return float((np.abs(x - ref) / allow).max())
 

@@ -285,7 +285,7 @@ def main():
         src, ops, _ = gen_fft(name, N, radices)
         parts.append(src + "\n")
         total[name] = ops
-    for name, n, N in (("pretwiddle32_w64", 32, 64), ("pretwiddle8_w16", 8, 16)):
+    for name, n, N in (("pretwiddle32_w64", 32, 64), ("pretwiddle8_w16", 8, 16), ("pretwiddle16_w32", 16, 32)):
         src, ops = gen_pretwiddle(name, n, N)
         parts.append(src + "\n")
         total[name] = ops
