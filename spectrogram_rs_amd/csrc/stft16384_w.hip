@@ -175,13 +175,13 @@ __global__ void __launch_bounds__(512, 2) stft16384_w_kernel(Params p)
         return j;
     };
     const int second_off = MONO ? (int)(p.H * 4) : 0;   // mono: the pair's second frame starts H samples on
-    auto prefetch = [&](const JobIn &j) {
+    auto prefetch = [&](const JobIn &j, int a_lo = 0, int a_hi = 16) {
         const __amdgpu_buffer_rsrc_t rs = uniform_rsrc(j.base);
         const int sec = j.data_second ? second_off : 0;
         const int lane_bytes = DIRECT ? (int)(4u * p.stride_floats) * tid : 8 * tid;                  // one sample of the pair per lane
         const int row_bytes = DIRECT ? (int)(2048u * p.stride_floats) : 4096;                        // 512 samples on
 #pragma unroll
-        for (int a = 0; a < 16; ++a) {
+        for (int a = a_lo; a < a_hi; ++a) {
 #ifdef W_ABL_NOLOAD
             pl[a] = (float)(a + 1) * 1e-3f; pr[a] = (float)tid * 1e-3f;
             (void)rs; (void)sec; (void)lane_bytes; (void)row_bytes;
@@ -196,6 +196,22 @@ __global__ void __launch_bounds__(512, 2) stft16384_w_kernel(Params p)
             }
         }
     };
+    // W_SPREAD (default): one request behind each of the sixteen butterflies of pass 1's two FFT16, one row store behind every second
+    // butterfly of pass 2's FFT32 -- never two vector-memory instructions back to back.  Same device, per 400 000 transforms: all 16
+    // requests + all 16 stores at the top of the iteration 13.6 ms; requests at the top, stores in two groups around the FFT32 11.7;
+    // requests in two halves 11.2 (profiles/r06_k16.txt): with two waves per SIMD a burst stalls the issuing wave at the memory
+    // pipeline's queue, and nothing else is there to run.
+#ifndef W_SPREAD
+#define W_SPREAD 2   // 2: and every LDS write of pass 1 and pass 2 issued the moment its value is final (the codelets' done() call-backs), inside the arithmetic
+#endif
+    constexpr bool kSpread = W_SPREAD && !MONO;   // (the paired-frame mono instantiation keeps the grouped placement: spread, it spills 12 registers)
+#ifndef W_PREFETCH_AT
+#define W_PREFETCH_AT (W_SPREAD ? 3 : 0)   // grouped placement -- 0: top of the iteration; 1: behind barrier B1; 2: behind barrier B2; 3: two halves, at the top and between the FFT16; 4: behind the pre-twiddle
+#endif
+#ifndef W_FLUSH_AT
+#define W_FLUSH_AT (W_SPREAD ? 1 : 0)      // the pending row's four store groups -- 0: between the stages of pass 1; 1: two in front of the FFT32, two behind; 2: inside pass 3; 3 / 4: all in front of / behind the FFT32; 5: 1 + 2 + 1 around FFT32 and pass-2 writes
+#endif
+    constexpr int kPrefetchAt = MONO ? 0 : W_PREFETCH_AT, kFlushAt = MONO ? 0 : W_FLUSH_AT;   // (mono pairs: twice the loads and stores; grouped at the top, no spill)
     // The prefetched values are consumed (Hann, fft.rs:53-63) at the END of the iteration that requested them, behind its stores, in
     // straight-line code, and pinned there (stft16384_d.hip: consumed at the loop head the wait becomes vmcnt(0) -- every store acknowledged)
     float er[16], ei[16];
@@ -238,9 +254,10 @@ __global__ void __launch_bounds__(512, 2) stft16384_w_kernel(Params p)
     const int q1B = (32 - q1) & 31;
     const int q2B = tid == 0 ? 16 : (q1 ? 31 - hi5 : 32 - hi5);
     const int uA = q1 + 32 * hi5, uB = q1B + 32 * q2B;      // thread 0: 0 and 512; else uB = 1024 - uA
-    // lane offsets of the kept bins in their row (bin k at byte 8 (k - 1)); thread 0 stores through its own branch: out of range here
-    const int voffA = tid == 0 ? (int)0x7ffffffc : 8 * (uA - 1);
-    const int voffB = tid == 0 ? (int)0x7ffffffc : 8 * (uB - 1);
+    // lane offsets of the kept bins in their row (bin k at byte 8 (k - 1))
+    const int voffA = tid == 0 ? 8184 : 8 * (uA - 1);                // thread 0: its bin 1024 (j + 1) in the store of j (see the split)
+    const int voffA7 = tid == 0 ? (int)0x7ffffffc : 8 * (uA - 1);    // ... and nothing in the store of j = 7 (out of range: dropped)
+    const int voffB = 8 * (uB - 1);
 
     // The finished row of a transform waits in 32 registers and is stored by the NEXT iteration, four stores at a time between the
     // stages of its pass 1, BEHIND its sample requests: issued at the end of the transform, all eight waves' 128 store instructions
@@ -249,6 +266,9 @@ __global__ void __launch_bounds__(512, 2) stft16384_w_kernel(Params p)
     // (nothing pending yet; the missing frame of a mono pair) is a descriptor of zero records: its stores are dropped.
 #ifndef W_DEFER
 #define W_DEFER 1
+#endif
+#if W_SPREAD && !W_DEFER
+#error "W_SPREAD stores the pending row inside the next iteration's pass 2: it needs W_DEFER"
 #endif
     float pm[32];
 #pragma unroll
@@ -265,7 +285,7 @@ __global__ void __launch_bounds__(512, 2) stft16384_w_kernel(Params p)
     };
     auto flush_group = [&](int g) {   // bins 4 g .. 4 g + 3 of the pending row: i = 2 q3 + side
 #pragma unroll
-        for (int i = 4 * g; i < 4 * g + 4; ++i) store_bin(pm[2 * i], pm[2 * i + 1], pend0, pend1, (i & 1) ? voffB : voffA, 8192 * (i >> 1));
+        for (int i = 4 * g; i < 4 * g + 4; ++i) store_bin(pm[2 * i], pm[2 * i + 1], pend0, pend1, (i & 1) ? voffB : (i == 14 ? voffA7 : voffA), 8192 * (i >> 1));
         __builtin_amdgcn_sched_barrier(0);   // (the groups stay where they are put: between the stages of pass 1)
     };
 #if SGX_STAMPS
@@ -299,35 +319,51 @@ __global__ void __launch_bounds__(512, 2) stft16384_w_kernel(Params p)
         const JobIn nxt = job_in(more ? job + job_step : job, hop_c, pair_c);
         // the NEXT transform's samples, a whole iteration ahead of their use (`take`, behind this transform's row stores): in front of
         // this transform's stores (vmcnt retires in issue order) and with ~14 000 cycles to arrive
-#ifndef W_PREFETCH_AT
-#define W_PREFETCH_AT 0   // 0: top of the iteration; 1: behind barrier B1 (in front of the pass-2 reads); 2: behind barrier B2
-#endif
-#ifndef W_FLUSH_AT
-#define W_FLUSH_AT 0      // the pending row's four store groups -- 0: between the stages of pass 1; 1: inside pass 2; 2: inside pass 3
-#endif
-        if (W_PREFETCH_AT == 0 && more) prefetch(nxt);
+        if (!kSpread && kPrefetchAt == 0 && more) prefetch(nxt);
 
         // ---- pass 1: 32-point DFT over a, inputs a >= 16 are the zero padding: even q1 = FFT16(z), odd q1 = FFT16(z * w_32^a)
         float orr[16], oi[16];
 #pragma unroll
         for (int a = 0; a < 16; ++a) { orr[a] = er[a]; oi[a] = ei[a]; }
-        if (W_DEFER && W_FLUSH_AT == 0) flush_group(0);
+        float2 *w1 = buf + tid;
+        auto tw_of = [&](float2 v, int q) {       // v * w^{q c}, q = l + 4 h
+            const int l = q & 3, h = q >> 2;
+            if (l) v = cmulf(v, twl[l]);
+            if (h) v = cmulf(v, twh[h]);
+            return v;
+        };
+        if constexpr (kSpread) {
+        // (the last iteration requests its own samples again: in bounds, never used -- no branch inside the arithmetic)
         pretwiddle16_w32(orr, oi);
-        if (W_DEFER && W_FLUSH_AT == 0) flush_group(1);
+        fft16h(er, ei, [&](auto k) {
+            __builtin_amdgcn_sched_barrier(0);
+            prefetch(nxt, decltype(k)::value, decltype(k)::value + 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }, [&](auto m, float re, float im) {   // even rows q1 = 2 m, written while the second FFT16 is still to come
+            if constexpr (W_SPREAD >= 2) w1[(2 * decltype(m)::value) * kS] = tw_of(make_float2(re, im), 2 * decltype(m)::value);
+        });
+        fft16h(orr, oi, [&](auto k) {
+            __builtin_amdgcn_sched_barrier(0);
+            prefetch(nxt, 8 + decltype(k)::value, 9 + decltype(k)::value);
+            __builtin_amdgcn_sched_barrier(0);
+        }, [&](auto m, float re, float im) {
+            if constexpr (W_SPREAD >= 2) w1[(2 * decltype(m)::value + 1) * kS] = tw_of(make_float2(re, im), 2 * decltype(m)::value + 1);
+        });
+        } else {
+        if (kPrefetchAt == 3 && more) prefetch(nxt, 0, 8);
+        if (W_DEFER && kFlushAt == 0) flush_group(0);
+        pretwiddle16_w32(orr, oi);
+        if (kPrefetchAt == 4 && more) prefetch(nxt);
+        if (W_DEFER && kFlushAt == 0) flush_group(1);
         fft16(er, ei);
-        if (W_DEFER && W_FLUSH_AT == 0) flush_group(2);
+        if (kPrefetchAt == 3 && more) prefetch(nxt, 8, 16);
+        if (W_DEFER && kFlushAt == 0) flush_group(2);
         fft16(orr, oi);
-        if (W_DEFER && W_FLUSH_AT == 0) flush_group(3);
+        if (W_DEFER && kFlushAt == 0) flush_group(3);
+        }
         SGX_STAMP(0)    // job bookkeeping + prefetch requests + pass-1 arithmetic (two FFT16)
         SGX_STAMP(1)
-        {
-            float2 *w1 = buf + tid;
-            auto tw_of = [&](float2 v, int q) {       // v * w^{q c}, q = l + 4 h
-                const int l = q & 3, h = q >> 2;
-                if (l) v = cmulf(v, twl[l]);
-                if (h) v = cmulf(v, twh[h]);
-                return v;
-            };
+        if (!(kSpread && W_SPREAD >= 2)) {
 #pragma unroll
             for (int m = 0; m < 16; ++m) {
                 const int pos = FFT16_OUT[m];
@@ -346,7 +382,7 @@ __global__ void __launch_bounds__(512, 2) stft16384_w_kernel(Params p)
         }
         lds_barrier();  // B1: the image is complete
         SGX_STAMP(3)
-        if (W_PREFETCH_AT == 1 && more) prefetch(nxt);
+        if (!kSpread && kPrefetchAt == 1 && more) prefetch(nxt);
 
         // ---- pass 2: thread (q1, c0): FFT32 over c1 -> q2, twiddle w_512^{q2 c0}, back into its own 32 slots
         {
@@ -357,22 +393,44 @@ __global__ void __launch_bounds__(512, 2) stft16384_w_kernel(Params p)
                 const float2 v = lds_read_alone(r2, 16 * c1);
                 xr[c1] = v.x; xi[c1] = v.y;
             }
-            if (W_DEFER && W_FLUSH_AT == 1) { flush_group(0); flush_group(1); }
-            fft32(xr, xi);
-            if (W_DEFER && W_FLUSH_AT == 1) { flush_group(2); flush_group(3); }
-            SGX_STAMP(4)    // image reads + FFT32
             float2 *w2 = buf + q1 * kS + hi5;
+            if constexpr (kSpread) {
+            fft32h(xr, xi, [&](auto k) {
+                constexpr int kk = decltype(k)::value;
+                if constexpr ((kk & 1) == 0) {
+                    constexpr int i = kk >> 1;       // bin 2 q3 + side of the pending row
+                    __builtin_amdgcn_sched_barrier(0);
+                    store_bin(pm[2 * i], pm[2 * i + 1], pend0, pend1, (i & 1) ? voffB : (i == 14 ? voffA7 : voffA), 8192 * (i >> 1));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }, [&](auto q2, float re, float im) {   // back into the thread's own slot the moment bin q2 is final
+                constexpr int qq = decltype(q2)::value;
+                if constexpr (W_SPREAD >= 2) w2[16 * qq] = qq == 0 ? make_float2(re, im) : cmulf(make_float2(re, im), t2[qq]);
+            });
+            } else {
+            if (W_DEFER && (kFlushAt == 1 || kFlushAt == 3)) { flush_group(0); flush_group(1); }
+            if (W_DEFER && kFlushAt == 3) { flush_group(2); flush_group(3); }
+            if (W_DEFER && kFlushAt == 5) flush_group(0);
+            fft32(xr, xi);
+            if (W_DEFER && kFlushAt == 4) { flush_group(0); flush_group(1); }
+            if (W_DEFER && (kFlushAt == 1 || kFlushAt == 4)) { flush_group(2); flush_group(3); }
+            if (W_DEFER && kFlushAt == 5) { flush_group(1); flush_group(2); }
+            }
+            SGX_STAMP(4)    // image reads + FFT32
+            if (!(kSpread && W_SPREAD >= 2)) {
 #pragma unroll
             for (int q2 = 0; q2 < 32; ++q2) {
                 const int pos = FFT32_OUT[q2];
                 const float2 v = make_float2(xr[pos], xi[pos]);
                 w2[16 * q2] = q2 == 0 ? v : cmulf(v, t2[q2]);
             }
+            }
         }
+        if (!kSpread && W_DEFER && kFlushAt == 5) flush_group(3);
         SGX_STAMP(5)    // pass-2 twiddles + writes
         lds_barrier();  // B2: every thread's slots hold pass-2 results
         SGX_STAMP(6)
-        if (W_PREFETCH_AT == 2 && more) prefetch(nxt);
+        if (!kSpread && kPrefetchAt == 2 && more) prefetch(nxt);
 
         // ---- pass 3: two FFT16 over c0: columns u_A and u_B = 1024 - u_A
         float ar[16], ai[16], br[16], bi[16];
@@ -396,9 +454,9 @@ __global__ void __launch_bounds__(512, 2) stft16384_w_kernel(Params p)
 #pragma unroll
         for (int c0 = 0; c0 < 16; ++c0) asm volatile("" : "+v"(ar[c0]), "+v"(ai[c0]), "+v"(br[c0]), "+v"(bi[c0]));
         SGX_STAMP(7)    // pass-3 reads + barrier B0
-        if (W_DEFER && W_FLUSH_AT == 2) { flush_group(0); flush_group(1); }
+        if (!kSpread && W_DEFER && kFlushAt == 2) { flush_group(0); flush_group(1); }
         fft16(ar, ai);
-        if (W_DEFER && W_FLUSH_AT == 2) { flush_group(2); flush_group(3); }
+        if (!kSpread && W_DEFER && kFlushAt == 2) { flush_group(2); flush_group(3); }
         fft16(br, bi);
         SGX_STAMP(8)    // two FFT16
 
@@ -412,30 +470,20 @@ __global__ void __launch_bounds__(512, 2) stft16384_w_kernel(Params p)
             ml = __builtin_amdgcn_sqrtf(fmaf(sr_, sr_, si_ * si_));  // the scale 1 / W rides on the window
             mr = __builtin_amdgcn_sqrtf(fmaf(dr_, dr_, di_ * di_));
         };
+        // Thread 0 holds the two self-paired columns: u = 0 (k = 1024 q3 pairs with 1024 (16 - q3), register 16 - q3 of its OWN column; k = 0,
+        // DC, is not an output: fft.rs:81) and u = 512 (k = 512 + 1024 q3 pairs with 512 + 1024 (15 - q3), own column again).  Selects on
+        // the split's inputs instead of a branch of its own: a divergent branch (250 instructions, 15 stores, one lane) made wave 0 the
+        // last at every barrier.  Its u = 0 bins ride one store instruction early (bin q3 + 1 in the slot of q3, lane offset 8184 =
+        // 8192 - 8: a lane offset of -8 would be dropped, profiles/r05_bufrange.txt); instruction 7 drops its lane.
+        const bool z = tid == 0;
 #pragma unroll
-        for (int q3 = 0; q3 < 8; ++q3) {
-            const int pa = FFT16_OUT[q3], pb = FFT16_OUT[15 - q3];
-            split(ar[pa], ai[pa], br[pb], bi[pb], pm[4 * q3], pm[4 * q3 + 1]);       // k = u_A + 1024 q3, partner (1024 - u_A) + 1024 (15 - q3)
-            split(br[pa], bi[pa], ar[pb], ai[pb], pm[4 * q3 + 2], pm[4 * q3 + 3]);   // k = u_B + 1024 q3, partner u_A + 1024 (15 - q3)
+        for (int j = 0; j < 8; ++j) {
+            const int pa = FFT16_OUT[j], pa1 = FFT16_OUT[j < 7 ? j + 1 : j], pb = FFT16_OUT[15 - j];
+            split(z ? ar[pa1] : ar[pa], z ? ai[pa1] : ai[pa], z ? ar[pb] : br[pb], z ? ai[pb] : bi[pb], pm[4 * j], pm[4 * j + 1]);   // k = u_A + 1024 j, partner (1024 - u_A) + 1024 (15 - j)
+            split(br[pa], bi[pa], z ? br[pb] : ar[pb], z ? bi[pb] : ai[pb], pm[4 * j + 2], pm[4 * j + 3]);                           // k = u_B + 1024 j, partner u_A + 1024 (15 - j)
         }
         pend0 = r0;
         pend1 = r1;
-        if (tid == 0) {
-            // the self-paired columns: u = 0 (k = 1024 q3 pairs with 1024 (16 - q3); k = 0, DC, is not an output: fft.rs:81) and
-            // u = 512 (k = 512 + 1024 q3 pairs with 512 + 1024 (15 - q3)); stored at once (one wave, 15 stores)
-#pragma unroll
-            for (int q3 = 0; q3 < 8; ++q3) {
-                const int pa = FFT16_OUT[q3], pb = FFT16_OUT[15 - q3];
-                float ml, mr;
-                if (q3 > 0) {
-                    const int pz = FFT16_OUT[16 - q3];
-                    split(ar[pa], ai[pa], ar[pz], ai[pz], ml, mr);
-                    store_bin(ml, mr, r0, r1, 8192 * q3 - 8, 0);
-                }
-                split(br[pa], bi[pa], br[pb], bi[pb], ml, mr);
-                store_bin(ml, mr, r0, r1, 8 * 511 + 8192 * q3, 0);
-            }
-        }
         if (!W_DEFER) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) flush_group(g);

@@ -27,6 +27,8 @@
 #include <hip/hip_fp16.h>
 
 #include "mix_codelets.hpp"
+#include <type_traits>
+
 #include "sgx_internal.hpp"
 
 namespace sgx {

@@ -84,6 +84,9 @@ def dif(e, vals, N, radices, out_pos, base_k=0, k_stride=1, positions=None):
         positions = list(range(N))
     if N == 1:
         out_pos[base_k] = positions[0]
+        if getattr(e, "hooks", None) is not None:      # bin base_k is final here: hand it to the caller at once
+            re, im = vals[positions[0]]
+            e.lines.append("    done(std::integral_constant<int, %d>{}, %s, %s);" % (base_k, re, im))
         return
     R = radices[0]
     L = N // R
@@ -108,12 +111,17 @@ def dif(e, vals, N, radices, out_pos, base_k=0, k_stride=1, positions=None):
             raise ValueError(R)
         for q in range(R):
             vals[p[q]] = ys[q]
+        if getattr(e, "hooks", None) is not None:      # a call-back point behind every butterfly (gen_fft(..., hooked=True))
+            e.lines.append("    hook(std::integral_constant<int, %d>{});" % e.hooks)
+            e.hooks += 1
     for q in range(R):
         dif(e, vals, L, radices[1:], out_pos, base_k + k_stride * q, k_stride * R, positions[q * L:(q + 1) * L])
 
 
-def gen_fft(name, N, radices):
+def gen_fft(name, N, radices, hooked=False):
     e = Emitter()
+    if hooked:
+        e.hooks = 0
     vals = {p: ("r[%d]" % p, "i[%d]" % p) for p in range(N)}
     out_pos = {}
     dif(e, vals, N, radices, out_pos)
@@ -123,11 +131,18 @@ def gen_fft(name, N, radices):
         body.append("    r[%d] = %s; i[%d] = %s;" % (p, re, p, im))
     src = []
     src.append("// %d-point forward DFT, DIF radices %s: %d VALU operations" % (N, radices, e.ops))
-    src.append("template <typename T>\n__device__ __forceinline__ void %s(T (&r)[%d], T (&i)[%d])\n{" % (name, N, N))
+    if hooked:
+        src.append("// (the same with a call-back point behind each of its %d butterflies: hook(std::integral_constant<int, k>{}), k in order --\n"
+                   "// where the caller puts vector-memory instructions it wants spread thinly through the arithmetic; bins as %s_OUT)" % (e.hooks, name[:-1].upper()))
+        src.append("// and done(std::integral_constant<int, bin>{}, re, im) the moment a bin is final (the last stage's outputs, as they come)")
+        src.append("template <typename T, typename H, typename D>\n__device__ __forceinline__ void %s(T (&r)[%d], T (&i)[%d], H &&hook, D &&done)\n{" % (name, N, N))
+    else:
+        src.append("template <typename T>\n__device__ __forceinline__ void %s(T (&r)[%d], T (&i)[%d])\n{" % (name, N, N))
     src += body
     src.append("}")
-    src.append("// bin k of %s is left in element %s_OUT[k]" % (name, name.upper()))
-    src.append("__device__ constexpr int %s_OUT[%d] = {%s};" % (name.upper(), N, ", ".join(str(out_pos[k]) for k in range(N))))
+    if not hooked:
+        src.append("// bin k of %s is left in element %s_OUT[k]" % (name, name.upper()))
+        src.append("__device__ constexpr int %s_OUT[%d] = {%s};" % (name.upper(), N, ", ".join(str(out_pos[k]) for k in range(N))))
     return "\n".join(src), e.ops, out_pos
 
 
@@ -287,6 +302,10 @@ def main():
         total[name] = ops
     for name, n, N in (("pretwiddle32_w64", 32, 64), ("pretwiddle8_w16", 8, 16), ("pretwiddle16_w32", 16, 32)):
         src, ops = gen_pretwiddle(name, n, N)
+        parts.append(src + "\n")
+        total[name] = ops
+    for name, N, radices in (("fft16h", 16, [4, 4]), ("fft32h", 32, [4, 4, 2])):
+        src, ops, _ = gen_fft(name, N, radices, hooked=True)
         parts.append(src + "\n")
         total[name] = ops
     cparts = ["// GENERATED by tools/gen_fft_codelets.py -- do not edit.\n"
