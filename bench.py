@@ -73,10 +73,9 @@ KERNEL_NAMES = {
         "sgx::wg::stft4096_wg_kernel<true, 0, false, 0>"),
     "real": ("stft4096 real-input: every mono frame its own transform, a 2048-point complex transform of the real frame + one butterfly per bin "
              "(256 threads x 2 frames x 8 points, radix 8 x 16 x 16, sliding half-row window)", "sgx::wgr::stft4096_real_kernel<0, 0, true>"),
-    5: ("stft16384 as four 4096-point residues (512 threads = 256 lane pairs, DPP decimation)", "sgx::q16k::stft16384_q_kernel<false, true>"),
     6: ("mixed radix at the window's own length (compile-time plan)", "sgx::mix::stft_mixed_fixed_kernel"),
-    8: ("stft16384 as four time-decimated 4096-point transforms in the lanes of a quad (1024 threads per transform, DPP recombination)",
-        "sgx::d16k::stft16384_d_kernel<false, true>"),   # (more than two channels: the pairs read where they lie)
+    10: ("stft16384 as 32 x 32 x 16 in one 512-thread workgroup (32 points per thread, two LDS exchanges, three barriers)",
+         "sgx::w16k::stft16384_w_kernel<false, true>"),   # (more than two channels: the pairs read where they lie)
     9: ("stft4800 workgroup-per-transform (320 threads, 16 x 20 x 15, resident twiddles, mono frame pairs)", "sgx::w48::stft4800_wg_kernel<0, false>"),
 }
 
@@ -1032,18 +1031,8 @@ def config4_leg(args, torch, device):
     achieved = hops * ALGO_BYTES_CFG4 / (mean * 1e-3) / 1e9
     traffic = load_profile_json("hbm_traffic")
     name = KERNEL_NAMES.get(eng.info.stft_kernel, ("?", "?"))
-    # the same launch through per-pair (l, r) planes (SGX_FLAG_CHANNEL_PLANES: the default of rounds 3-5), beside it
-    eng_d = SpectrogramEngine(48000.0, window_samples=W4, hop_samples=H4, channels=C4, device=device, channel_planes=True)
-    same_bytes = eng_d.checksum(eng_d.stft_batch(pcm, max_frames=512)) == eng.checksum(eng.stft_batch(pcm, max_frames=512))
-    md = measure_leg(torch, lambda: eng_d.stft_batch(pcm, out=out), min(args.leg_sustain_s, 0.5))
-    planes = {"hop_positions_per_s": hops / (md["mean_ms"] * 1e-3), "frac": hops * ALGO_BYTES_CFG4 / (md["mean_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-              "same_bytes_as_default_on_512_hops": bool(same_bytes), "kernel": "de-interleave pass + sgx::d16k::stft16384_d_kernel<false, false>",
-              "what": "SGX_FLAG_CHANNEL_PLANES: the call's sample range split into four (l, r) planes first (HBM counters 1.146 x algorithmic, "
-                      "a 1.6 GB workspace at this size); the default reads the pairs where they lie: 1.02 x (profiles/r05_k16.txt section 6)"}
-    eng_d.close()
     return {
         "workload": f"configs[3]: 16384-pt Hann STFT, hop 512, 8 interleaved channels, {hops} hop positions ({4 * hops} transforms)",
-        "channel_planes": planes,
         "hop_positions_per_s": hops / (mean * 1e-3), "transforms_per_s": 4 * hops / (mean * 1e-3),
         **leg_times(m), "kernel": name[0], "output_bytes": hops * (C4 // 2) * (W4 - 1) * 8,
         "roofline": {
@@ -1056,7 +1045,7 @@ def config4_leg(args, torch, device):
             "kernel": name[1],
             "first_allocation": first_allocation_of(torch, first, m, lambda buf: eng.stft_batch(pcm, out=buf), hops * ALGO_BYTES_CFG4, args),
             "placement": placement,
-            "note": "launch = ONE kernel: the (l, r) pairs are read where they lie in the 8-channel stream (no de-interleave pass, no workspace); channel_planes = the same through planes",
+            "note": "launch = ONE kernel: the (l, r) pairs are read where they lie in the 8-channel stream (no de-interleave pass, no workspace)",
         },
     }
 

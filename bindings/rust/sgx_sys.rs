@@ -45,5 +45,4 @@ pub const HIP_MEMCPY_DEVICE_TO_HOST: c_int = 2;
 // SgxConfig::flags (include/sgx.h).  A mono device (audio_input_list_model.rs:67-69): `channels = 1` and no flag -- every frame is its
 // own transform, the reference's dataflow (as a real-input transform at W 2048, the application's 2400 / 2205 and every other window but W 8192 and the smallest).
 pub const SGX_FLAG_PAIRED_FRAMES: u32 = 1024;   // opt-in: two frames per transform (half the work; tolerance against the pair's peak)
-pub const SGX_FLAG_INDEPENDENT_FRAMES: u32 = 16; // never pair: the default since round 4
 pub const SGX_FLAG_COMPLEX_MONO: u32 = 512;     // A/B: the literal (s, s) transform per frame where a real-input kernel would run

@@ -98,14 +98,9 @@ typedef struct sgx_config {
  * PAIR's peak only (measured: up to 4.7 x the own-peak tolerance across a 60 dB step inside one hop, unbounded next to digital
  * silence; invisible on stationary signals.  DESIGN.md section 4). */
 #define SGX_FLAG_PAIRED_FRAMES 1024u /* mono: two frames per transform (the default of rounds 1-3) */
-#define SGX_FLAG_INDEPENDENT_FRAMES 16u /* mono: never pair.  The default since round 4; kept for callers that set it, and it wins over
-                                           SGX_FLAG_PAIRED_FRAMES where both are given */
 #define SGX_FLAG_COMPLEX_MONO 512u /* mono: the literal (s, s) 2W-point complex transform per frame -- fft.rs:47-57 -- wherever a
                                       real-input kernel would run (A/B; implies no pairing) */
 #define SGX_FLAG_LUT_WALK 64u      /* fused pixel kernel: walk the dB thresholds from the log2 seed even where the host has shown that one compare pair settles the LUT index (A/B, and the test of the fallback) */
-#define SGX_FLAG_RESIDUE_16K 128u  /* W = 8192: the second 16384-point kernel (four 4096-point residues of the OUTPUT, two passes of a 512-thread workgroup) instead of the time-decimated one (A/B) */
-#define SGX_FLAG_CHANNEL_PLANES 2048u /* W = 8192, more than two channels: split the call's sample range into per-pair (l, r) planes first and transform those (the default of rounds 3-5: a second kernel, a workspace grown on the call, HBM traffic 1.15 x algorithmic) instead of reading every pair where it lies in the interleaved stream (8-byte loads at a stride of `channels` floats: traffic 1.02 x).  Same bytes; 2 % faster on short launches, 1 % slower at BASELINE config 4's size (A/B, profiles/r05_k16.txt) */
-#define SGX_FLAG_K16_W 4096u /* W = 8192: the fourth 16384-point kernel (32 x 32 x 16 in one 512-thread workgroup, 32 points per thread: stft16384_w.hip) instead of the lane-quad one (A/B) */
 #define SGX_FLAG_MIXED_GENERIC 256u /* W = 2400: the composite-radix kernel (any 2-3-5-7-smooth length) instead of the tuned 4800-point one (A/B) */
 
 typedef struct sgx_info {
@@ -119,8 +114,8 @@ typedef struct sgx_info {
     uint32_t rows;            /* R */
     uint32_t sample_rate_u32; /* SampleRate(sample_rate as u32)      simple_spectrogram.rs:138 */
     uint32_t total_samples_per_column; /* sum over rows of magnitude_in's sample count */
-    uint32_t stft_kernel;     /* 0 = generic power-of-two, 2 = 4096-point workgroup-per-transform (default at W 2048), 4 = Bluestein chirp-z (any 2W), 5 = 16384-point as four 4096-point residues of the output (SGX_FLAG_RESIDUE_16K), 6 = mixed radix (2W = 2^a 3^b 5^c 7^d <= 20480, e.g. the application's 4800, 4410 and 19200), 8 = 16384-point as four time-decimated 4096-point transforms in the lanes of a quad, one 1024-thread workgroup per transform (default for W = 8192), 9 = 4800-point workgroup-per-transform, 16 x 20 x 15 (default for W = 2400, the application's window at 48 kHz; streams of more than two channels run 6) */
-                              /* (magnitudes: the tuned kernels -- 2, 6, 8, 9 and the chirp-z plans of 4 -- take |re + i im| through the hardware
+    uint32_t stft_kernel;     /* 0 = generic power-of-two, 2 = 4096-point workgroup-per-transform (default at W 2048), 4 = Bluestein chirp-z (any 2W), 6 = mixed radix (2W = 2^a 3^b 5^c 7^d <= 20480, e.g. the application's 4800, 4410 and 19200), 9 = 4800-point workgroup-per-transform, 16 x 20 x 15 (default for W = 2400, the application's window at 48 kHz; streams of more than two channels run 6), 10 = 16384-point as 32 x 32 x 16 in one 512-thread workgroup, 32 points per thread (W = 8192; the designs 5, 7 and 8 of rounds 1-5 are gone: profiles/r06_k16.txt) */
+                              /* (magnitudes: the tuned kernels -- 2, 6, 9, 10 and the chirp-z plans of 4 -- take |re + i im| through the hardware
                                  square root of fma(re, re, im * im): 1 ulp; the generic kernel (0) and the radix-4 Bluestein ladder use the
                                  correctly rounded sqrtf.  Rows of different kernels for the same input agree within the tolerance, not bit for bit) */
     uint32_t render_path;     /* sgx_render_batch as configured NOW (palette included): bit 0 = one fused PCM-to-pixel kernel (the

@@ -22,14 +22,10 @@ INTERP_CUBIC, INTERP_COSINE = 0, 1
 LUT_FLOOR_N, LUT_ROUND_NM1 = 0, 1
 FLAG_FORCE_GENERIC = 1
 FLAG_NO_FUSED_RENDER = 4
-FLAG_INDEPENDENT_FRAMES = 16
 FLAG_LUT_WALK = 64
-FLAG_RESIDUE_16K = 128
 FLAG_MIXED_GENERIC = 256
 FLAG_COMPLEX_MONO = 512
 FLAG_PAIRED_FRAMES = 1024
-FLAG_CHANNEL_PLANES = 2048
-FLAG_K16_W = 4096
 LIVE_MAGS, LIVE_MAGS_F16, LIVE_RGBA = 0, 1, 2
 LIVE_REFERENCE_SKIP = 1
 

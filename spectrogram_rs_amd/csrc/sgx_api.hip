@@ -230,13 +230,9 @@ int ensure_workspace(sgx_ctx *c, size_t frames)
 hipError_t run_stft(const sgx_ctx *c, const float *d_pcm, uint32_t channels, uint32_t pairs, size_t first, size_t n,
                     size_t total, float *d_mags)
 {
-    // W = 8192: the four-residue kernel, (l, r) streams and mono frame pairs alike (independent mono frames: generic)
-    if (c->stft_kernel == 5 && (channels != 1 || !(c->cfg.flags & SGX_FLAG_INDEPENDENT_FRAMES)))
-        return sgx::launch_stft_q16384(c, c->d_q16k, d_pcm, channels, pairs, first, n, total, d_mags);
+    // W = 8192 (a mono stream whose frames are not paired: as an (s, s) plane through the two-channel instantiation; the 8192-point plan of
+    // the mixed-radix kernel's real-input mode measured no faster, round 4)
     if (c->stft_kernel == 10) return sgx::launch_stft_w16384(c, c->d_w16k, d_pcm, channels, pairs, first, n, total, d_mags);
-    if (c->stft_kernel == 8)   // (a mono stream whose frames are not paired: as an (s, s) plane through the two-channel kernel; the 8192-point
-                               // plan of the mixed-radix kernel's real-input mode measured no faster: 31.4 against 32.6 M frames/s, round 4)
-        return sgx::launch_stft_d16384(c, c->d_d16k, d_pcm, channels, pairs, first, n, total, d_mags);
     // (a mono stream, every frame its own transform: real-input mode of the mixed-radix kernel, 2400 points instead of 4800 on (s, s))
     if (c->stft_kernel == 9 && channels <= 2 && !sgx::mixed_real_serves(c, c->d_mix, channels)) return sgx::launch_stft_w4800(c, c->d_w4800, d_pcm, channels, first, n, total, d_mags, false);
     if (c->stft_kernel == 6 || c->stft_kernel == 9) return sgx::launch_stft_mixed(c, c->d_mix, d_pcm, channels, pairs, first, n, total, d_mags);
@@ -292,10 +288,11 @@ int sgx_create(const sgx_config *cfg, sgx_ctx **out_ctx)
     sgx_ctx *c = new (std::nothrow) sgx_ctx();
     if (!c) return fail(nullptr, SGX_ERR_NOMEM, "sgx_create: out of host memory");
     c->cfg = *cfg;
-    // Mono streams (include/sgx.h): every frame its own transform unless SGX_FLAG_PAIRED_FRAMES asks for frame pairs -- the kernels
-    // test SGX_FLAG_INDEPENDENT_FRAMES, which is therefore set whenever pairing was not asked for (and wins where both are given)
-    if (!(c->cfg.flags & SGX_FLAG_PAIRED_FRAMES)) c->cfg.flags |= SGX_FLAG_INDEPENDENT_FRAMES;
-    if (c->cfg.flags & (SGX_FLAG_INDEPENDENT_FRAMES | SGX_FLAG_COMPLEX_MONO)) c->cfg.flags &= ~SGX_FLAG_PAIRED_FRAMES;
+    // Mono streams (include/sgx.h): every frame its own transform unless SGX_FLAG_PAIRED_FRAMES asks for frame pairs; the literal
+    // (s, s) transform of SGX_FLAG_COMPLEX_MONO implies no pairing.  (Bit 16, the SGX_FLAG_INDEPENDENT_FRAMES of rounds 1-5 -- "never
+    // pair", the default since round 4 -- is accepted and means nothing.)
+    c->cfg.flags &= ~16u;
+    if (c->cfg.flags & SGX_FLAG_COMPLEX_MONO) c->cfg.flags &= ~SGX_FLAG_PAIRED_FRAMES;
 
     // fft.rs:19 / audio_transform.rs:35: f32 product, truncating cast
     c->W = cfg->window_samples ? cfg->window_samples : f32_as_u32(cfg->period * cfg->sample_rate);
@@ -361,9 +358,10 @@ int sgx_create(const sgx_config *cfg, sgx_ctx **out_ctx)
     if (rc != SGX_OK) { std::string m = c->err; return bail(rc, m); }
 
     c->stft_kernel = 0;
-    if (cfg->flags & (2u | 8u | 32u))   // the flag bits of the A/B kernels of rounds 1-3 (wave-per-transform, packed arithmetic, first 16384-point design)
-        return bail(SGX_ERR_UNSUPPORTED, "sgx_create: flag bits 2, 8 and 32 selected superseded A/B kernels that were removed in round 5 "
-                                         "(their measurements: profiles/r01_*, r02_*, r03_k16_ablation.txt)");
+    if (cfg->flags & (2u | 8u | 32u | 128u | 2048u))   // the flag bits of superseded A/B kernels: wave-per-transform, packed arithmetic, the first three 16384-point designs
+        return bail(SGX_ERR_UNSUPPORTED, "sgx_create: flag bits 2, 8, 32 (removed in round 5), 128 and 2048 (SGX_FLAG_RESIDUE_16K, SGX_FLAG_CHANNEL_PLANES: removed in "
+                                         "round 6) selected superseded A/B kernels (their measurements: profiles/r01_*, r02_*, r03_k16_ablation.txt, r05_k16.txt, r06_k16.txt)");
+    if (c->C > 32768u) return bail(SGX_ERR_INVALID_ARG, "sgx_create: at most 32768 channels (the kernels address a sample row with 32-bit byte offsets)");
     // powers of two from W = 512 on that have no tuned kernel ride the composite-radix stages too (compile-time plans 4 x 16 x 16,
     // 8 x 16 x 16, 4 x 8 x 16 x 16): same-device A/B against the radix-4 ladder of the generic kernel, mono / stereo:
     // W 512 +29 % / +44 %, W 1024 +48 % / +90 %, W 4096 +83 % / +117 %; W 256: -14 %, W 128: -53 % (run-time geometry)
@@ -394,18 +392,10 @@ int sgx_create(const sgx_config *cfg, sgx_ctx **out_ctx)
             if (e != hipSuccess) return bail(SGX_ERR_HIP, std::string("sgx_create: real-input kernel tables: ") + hipGetErrorString(e));
         }
         c->stft_kernel = 2;
-    } else if ((cfg->flags & SGX_FLAG_K16_W) && !(cfg->flags & SGX_FLAG_FORCE_GENERIC) && sgx::w16384_supported(c)) {
+    } else if (!(cfg->flags & SGX_FLAG_FORCE_GENERIC) && sgx::w16384_supported(c)) {
         e = sgx::w16384_init(c, &c->d_w16k);
         if (e != hipSuccess) return bail(SGX_ERR_HIP, std::string("sgx_create: 16384-point kernel tables: ") + hipGetErrorString(e));
         c->stft_kernel = 10;
-    } else if (!(cfg->flags & (SGX_FLAG_FORCE_GENERIC | SGX_FLAG_RESIDUE_16K)) && sgx::d16384_supported(c)) {
-        e = sgx::d16384_init(c, &c->d_d16k);
-        if (e != hipSuccess) return bail(SGX_ERR_HIP, std::string("sgx_create: 16384-point kernel tables: ") + hipGetErrorString(e));
-        c->stft_kernel = 8;
-    } else if (!(cfg->flags & SGX_FLAG_FORCE_GENERIC) && sgx::q16384_supported(c)) {
-        e = sgx::q16384_init(c, &c->d_q16k);
-        if (e != hipSuccess) return bail(SGX_ERR_HIP, std::string("sgx_create: 16384-point kernel tables: ") + hipGetErrorString(e));
-        c->stft_kernel = 5;
     }
     *out_ctx = c;
     return SGX_OK;
@@ -429,12 +419,8 @@ void sgx_destroy(sgx_ctx *c)
     c->d_mix = nullptr;
     sgx::chirpz_destroy(c->d_chz);
     c->d_chz = nullptr;
-    sgx::q16384_destroy(c->d_q16k);
-    c->d_q16k = nullptr;
     sgx::w16384_destroy(c->d_w16k);
     c->d_w16k = nullptr;
-    sgx::d16384_destroy(c->d_d16k);
-    c->d_d16k = nullptr;
     void *ptrs[] = {c->d_window, c->d_twiddle, c->d_rows, c->d_samples, c->d_lut_thr, c->d_alpha_thr,
                     c->d_lut_rgba, c->d_pal_seed, c->d_t_thr, c->d_t_cell, c->d_band_rows, c->d_band_samples, c->d_levels, c->d_ws_mags, c->d_one_in, c->d_one_out, c->d_cksum};
     for (void *p : ptrs)
@@ -463,7 +449,7 @@ int sgx_query(const sgx_ctx *c, sgx_info *out)
     if (c->stft_kernel == 2 && !(c->cfg.flags & SGX_FLAG_NO_FUSED_RENDER) && sgx::wg4096_can_fuse_render(c, c->d_fast_wg))
         out->render_path = 1u | (sgx::wg4096_seed_is_within_one(c) ? 2u : 0u);
     if ((c->stft_kernel == 6 || c->stft_kernel == 9) && sgx::mixed_fixed_plan(c->d_mix)) out->render_path |= 4u;
-    if (c->stft_kernel == 2 && c->d_real && !(c->cfg.flags & SGX_FLAG_COMPLEX_MONO) && (c->cfg.flags & SGX_FLAG_INDEPENDENT_FRAMES)) out->render_path |= 8u;
+    if (c->stft_kernel == 2 && c->d_real && !(c->cfg.flags & SGX_FLAG_COMPLEX_MONO) && !(c->cfg.flags & SGX_FLAG_PAIRED_FRAMES)) out->render_path |= 8u;
     if ((c->stft_kernel == 6 || c->stft_kernel == 9) && sgx::mixed_real_serves(c, c->d_mix, c->C)) out->render_path |= 8u;
     if (c->stft_kernel == 4 && c->d_chz) out->render_path |= 4u;
     if (c->stft_kernel == 4 && sgx::chirpz_real_serves(c, c->d_chz, c->C)) out->render_path |= 8u;

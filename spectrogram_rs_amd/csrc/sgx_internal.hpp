@@ -105,7 +105,7 @@ struct sgx_ctx {
     uint32_t W = 0, P = 0, M = 0, H = 0, C = 0, pairs = 0, R = 0, sr_u32 = 0, logP = 0;
     int device = 0;
     hipStream_t stream = nullptr;
-    int stft_kernel = 0;  // 0 generic, 1 tuned 4096 wave-per-transform, 2 tuned 4096 workgroup-per-transform (scalar codelets), 3 the same with packed (re, im) arithmetic, 4 Bluestein (2W not a power of two), 5 tuned 16384, second design (four 4096-point residues), 6 mixed radix (2W = 2^a 3^b 5^c 7^d), 7 tuned 16384, first design (whole transform in LDS), 8 tuned 16384, third design (time-decimated lane quads), 9 tuned 4800 (W = 2400; more than two channels: 6)
+    int stft_kernel = 0;  // 0 generic, 1 tuned 4096 wave-per-transform, 2 tuned 4096 workgroup-per-transform (scalar codelets), 3 the same with packed (re, im) arithmetic, 4 Bluestein (2W not a power of two), 5 tuned 16384, second design (four 4096-point residues), 6 mixed radix (2W = 2^a 3^b 5^c 7^d), 7 tuned 16384, first design (whole transform in LDS), 8 tuned 16384, third design (time-decimated lane quads; removed in round 6), 9 tuned 4800 (W = 2400; more than two channels: 6), 10 tuned 16384, fourth design (32 x 32 x 16, 512 threads: stft16384_w.hip)
 
     sgx::Tables tab;
     sgx::Palette pal;
@@ -129,8 +129,6 @@ struct sgx_ctx {
     void *d_real = nullptr;        // tables of the real-input 4096-point kernel (independent mono frames at W 2048 / H 256)
     void *d_chz = nullptr;         // chirp-z through the mixed-radix kernel's stages (or null: the radix-4 ladder of stft_bluestein.hip)
     void *d_w16k = nullptr;        // tables of the 16384-point kernel, 32 x 32 x 16 (stft16384_w.hip)
-    void *d_q16k = nullptr;        // tables of the 16384-point kernel, four 4096-point residues of the output (SGX_FLAG_RESIDUE_16K)
-    void *d_d16k = nullptr;        // tables of the 16384-point kernel, four time-decimated 4096-point transforms per lane quad (the default)
 
     // workspaces (grown on demand, kept)
     float *d_ws_mags = nullptr;
@@ -170,27 +168,17 @@ hipError_t launch_stft_wg4096(const sgx_ctx *c, const void *tables, const float 
                               size_t first_frame, size_t n_frames, size_t total_frames, float *d_mags);
 bool wg4096_can_fuse_render(const sgx_ctx *c, const void *tables);
 hipError_t launch_deinterleave_pairs(const sgx_ctx *c, const float *d_pcm, float *d_planes, size_t plane_floats, size_t first_sample, size_t n_samples,
-                                     uint32_t channels, uint32_t pairs);   // stft16384_q.hip
+                                     uint32_t channels, uint32_t pairs);   // deinterleave.hip
 bool wg4096_seed_is_within_one(const sgx_ctx *c);
 void lut_seed_coefficients(const sgx_ctx *c, float &a, float &b);
 namespace wg { bool seed_within_one(const std::vector<float> &thr, double guess_a, double guess_b); }   // stft4096_wg.hip: is floor(log2(p + 1e-7) a + b) within one of the threshold count for every power?   // LUT level ~ floor(log2(power + 1e-7) a + b): the seed of the threshold count
 hipError_t launch_render_wg4096(const sgx_ctx *c, const void *tables, const float *d_pcm, uint32_t channels, uint32_t pairs,
                                 size_t first_frame, size_t n_frames, size_t total_frames, uint8_t *d_rgba);
-bool d16384_supported(const sgx_ctx *c);
-hipError_t d16384_init(sgx_ctx *c, void **out);
-void d16384_destroy(void *tables);
-hipError_t launch_stft_d16384(const sgx_ctx *c, void *tables, const float *d_pcm, uint32_t channels, uint32_t pairs,
-                              size_t first_frame, size_t n_frames, size_t total_frames, float *d_mags);
 // stft16384_w.hip: W = 8192 as 32 x 32 x 16 in one 512-thread workgroup, 32 points per thread
 bool w16384_supported(const sgx_ctx *c);
 hipError_t w16384_init(sgx_ctx *c, void **out);
 void w16384_destroy(void *tables);
 hipError_t launch_stft_w16384(const sgx_ctx *c, void *tables, const float *d_pcm, uint32_t channels, uint32_t pairs,
-                              size_t first_frame, size_t n_frames, size_t total_frames, float *d_mags);
-bool q16384_supported(const sgx_ctx *c);
-hipError_t q16384_init(sgx_ctx *c, void **out);
-void q16384_destroy(void *tables);
-hipError_t launch_stft_q16384(const sgx_ctx *c, void *tables, const float *d_pcm, uint32_t channels, uint32_t pairs,
                               size_t first_frame, size_t n_frames, size_t total_frames, float *d_mags);
 // W = 2400 (48 kHz x 0.05 s): persistent 320-thread workgroups, 16 x 20 x 15 (stft4800_wg.hip); rows and half rows of one or two channels -- more
 // channels and the fused PCM-to-pixel path go to the composite-radix kernel, whose tables such a context carries too

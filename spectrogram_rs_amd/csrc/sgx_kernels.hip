@@ -136,7 +136,7 @@ hipError_t launch_stft_generic(const sgx_ctx *c, const float *d_pcm, uint32_t ch
     }
     p.n_frames = n_frames;
     p.total_frames = total_frames;
-    if (channels == 1 && !(c->cfg.flags & SGX_FLAG_INDEPENDENT_FRAMES)) {
+    if (channels == 1 && (c->cfg.flags & SGX_FLAG_PAIRED_FRAMES)) {
         // one workgroup per frame PAIR (2q, 2q+1); an odd first frame / last frame shares its transform with a
         // neighbour outside the range, which is computed and not stored
         p.mono_pairs = 1;

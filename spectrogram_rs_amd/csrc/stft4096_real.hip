@@ -128,7 +128,7 @@ constexpr size_t kLdsBytesR = (size_t)(kBufComplexTR + 256) * sizeof(float2);
 constexpr size_t kLdsBytesRenderR = kLdsBytesR + 256 * sizeof(uint2);
 static_assert(4 * kLdsBytesRenderR <= 160 * 1024, "four workgroups per CU");
 // rows ra and rb (STRIDE words each) of both planes, this wave's 64 words: LDS address = M0 + offset + 4 * lane.  M0 is set inside the
-// statement (and declared clobbered, so the compiler never relies on an older value) and one wait state separates a scalar write of M0 from an
+// statement (it cannot be declared clobbered -- a reserved register to clang: stft4096_wg.hip -- so the ISA check also refuses every implicit reader of M0 beside these statements) and one wait state separates a scalar write of M0 from an
 // add-TID instruction (tools/isa_check_addtid.py looks at every build).
 template <int STRIDE>
 __device__ __forceinline__ void addtid_rows(float2 a, float2 b, uint32_t m0_wave, int ra, int rb)
@@ -141,7 +141,7 @@ __device__ __forceinline__ void addtid_rows(float2 a, float2 b, uint32_t m0_wave
                  "ds_write_addtid_b32 %3 offset:%8"
                  :
                  : "v"(a.x), "v"(a.y), "v"(b.x), "v"(b.y), "s"(m0_wave), "i"(4 * STRIDE * ra), "i"(4 * STRIDE * ra + 4 * kPlaneIm), "i"(4 * STRIDE * rb), "i"(4 * STRIDE * rb + 4 * kPlaneIm)
-                 : "memory", "m0");
+                 : "memory");
 }
 __device__ __forceinline__ void read_planes(const float4 *rd4, float (&xr)[16], float (&xi)[16])
 {

@@ -57,7 +57,10 @@ __device__ unsigned long long g_phase_cycles[20];
 #define SGX_ADDTID 1   // (0: the (l, r) sliding kernel with the b64 transposes of every other instantiation, for A/B)
 #endif
 // rows q and q + 1 of the real and the imaginary plane, this wave's 64 words of each: LDS address = M0 + offset + 4 * lane
-// (M0 is set inside the statement and declared clobbered: whatever the compiler keeps in M0 -- LDS-DMA bases, indexed moves -- it restores)
+// (M0 is set inside the statement.  It cannot be DECLARED clobbered: clang answers "inline asm clobber list contains reserved registers: m0 ...
+// may not be preserved" (ROCm 7.2) -- so that nothing of the compiler's may depend on M0 around these statements is checked on the ISA of
+// every build instead: tools/isa_check_addtid.py fails on any instruction that reads M0 by name OR implicitly (indexed moves, LDS-DMA,
+// GWS, s_sendmsg, interpolation) in a kernel that issues add-TID stores)
 __device__ __forceinline__ void addtid_rows(float2 a, float2 b, uint32_t m0_wave, int q)
 {
     asm volatile("s_mov_b32 m0, %4\n\t"
@@ -68,7 +71,7 @@ __device__ __forceinline__ void addtid_rows(float2 a, float2 b, uint32_t m0_wave
                  "ds_write_addtid_b32 %3 offset:%8"
                  :
                  : "v"(a.x), "v"(a.y), "v"(b.x), "v"(b.y), "s"(m0_wave), "i"(1088 * q), "i"(1088 * q + 17408), "i"(1088 * (q + 1)), "i"(1088 * (q + 1) + 17408)
-                 : "memory", "m0");
+                 : "memory");
 }
 // the 16 values of this thread's next transform: 16 consecutive words of its row in either plane
 __device__ __forceinline__ void read_planes(const float4 *rd4, float (&xr)[16], float (&xi)[16])
@@ -202,7 +205,7 @@ __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
                     }
                 }
             } else {
-                // one channel, every frame its own (s, s) transform (SGX_FLAG_INDEPENDENT_FRAMES; audio_input_list_model.rs:67-69).
+                // one channel, every frame its own (s, s) transform (the default; audio_input_list_model.rs:67-69).
                 // (More than two interleaved channels never come here: their pairs are split into planes first and each
                 // plane runs the C2 kernel -- launch_wg.)
 #pragma unroll
@@ -735,10 +738,10 @@ hipError_t launch_wg(const sgx_ctx *c, const void *tables, const float *d_pcm, u
         // (stft4096_real.hip); SGX_FLAG_PAIRED_FRAMES: two frames per transform; SGX_FLAG_COMPLEX_MONO: every frame as its own (s, s)
         // transform
         const uint32_t fl = c->cfg.flags;      // (sgx_create: INDEPENDENT is set unless PAIRED was asked for)
-        const bool own_transform = (fl & (SGX_FLAG_INDEPENDENT_FRAMES | SGX_FLAG_COMPLEX_MONO)) != 0;
+        const bool own_transform = !(fl & SGX_FLAG_PAIRED_FRAMES) || (fl & SGX_FLAG_COMPLEX_MONO) != 0;
         if (channels == 1 && own_transform && !(fl & SGX_FLAG_COMPLEX_MONO) && real4096_serves(c, d_pcm, channels))
             return launch_real4096(c, c->d_real, p, out_f16, RENDER);
-        const bool mono = channels == 1 && !(fl & (SGX_FLAG_INDEPENDENT_FRAMES | SGX_FLAG_COMPLEX_MONO));
+        const bool mono = channels == 1 && (fl & SGX_FLAG_PAIRED_FRAMES) && !(fl & SGX_FLAG_COMPLEX_MONO);
         p.pair_base = mono ? first_frame / 2 : 0;
         p.n_jobs = mono ? (first_frame + n_frames + 1) / 2 - first_frame / 2 : n_frames;
         // persistent workgroups, 4 per CU; each owns a contiguous run of transforms so that the

@@ -85,7 +85,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void *base)
 }
 
 // MODE: 0 an (l, r) stream, one frame per transform; 1 a mono stream, frames (2j, 2j+1) per transform; 2 a mono stream, every
-// frame its own (s, s) transform (SGX_FLAG_INDEPENDENT_FRAMES: the reference's dataflow)
+// frame its own (s, s) transform (the default: the reference's dataflow)
 #ifndef W48_ABL
 #define W48_ABL 0   // ablation builds (profiles/r03_app_point.txt): 1 no row stores, 2 no sample loads, 4 / 8 no butterfly in pass 2 / 3
 #endif
@@ -399,7 +399,7 @@ hipError_t launch_stft_w4800(const sgx_ctx *c, const void *tables, const float *
     p.H = c->H;
     p.pairs = 1;
     p.half_scale = 0.5f * (2.0f / (float)c->W);
-    const int mode = channels == 2 ? 0 : ((c->cfg.flags & SGX_FLAG_INDEPENDENT_FRAMES) ? 2 : 1);
+    const int mode = channels == 2 ? 0 : ((c->cfg.flags & SGX_FLAG_PAIRED_FRAMES) ? 1 : 2);
     p.pair_base = mode == 1 ? first_frame / 2 : 0;
     p.n_jobs = mode == 1 ? (first_frame + n_frames + 1) / 2 - first_frame / 2 : n_frames;
     // persistent workgroups, three per CU, each with a contiguous run of transforms: neighbouring frames share 96 % of their samples

@@ -242,7 +242,7 @@ hipError_t launch_stft_bluestein(const sgx_ctx *c, const void *tables, const flo
     p.first_frame = first_frame;
     p.n_frames = n_frames;
     p.total_frames = total_frames;
-    if (channels == 1 && !(c->cfg.flags & SGX_FLAG_INDEPENDENT_FRAMES)) {
+    if (channels == 1 && (c->cfg.flags & SGX_FLAG_PAIRED_FRAMES)) {
         p.mono_pairs = 1;
         p.mags = d_mags;
         const unsigned long long q0 = first_frame / 2, q1 = (first_frame + n_frames + 1) / 2;

@@ -870,7 +870,7 @@ void mixed_destroy(void *tables)
 bool mixed_real_serves(const sgx_ctx *c, const void *tables, uint32_t channels)
 {
     const auto *t = static_cast<const mix::MixTables *>(tables);
-    return t && t->half && channels == 1 && (c->cfg.flags & SGX_FLAG_INDEPENDENT_FRAMES) && !(c->cfg.flags & SGX_FLAG_COMPLEX_MONO);
+    return t && t->half && channels == 1 && !(c->cfg.flags & SGX_FLAG_PAIRED_FRAMES) && !(c->cfg.flags & SGX_FLAG_COMPLEX_MONO);
 }
 
 // real-input mode from PCM to pixels: a compile-time W-point plan, the palette conditions of the fused pixel stage, W / 2 bin pairs in
@@ -1030,7 +1030,7 @@ static hipError_t launch_mixed(const sgx_ctx *c, const void *tables, const float
         }
     };
     const size_t max_chunk = 1u << 30;
-    if (channels == 1 && !(c->cfg.flags & SGX_FLAG_INDEPENDENT_FRAMES)) {
+    if (channels == 1 && (c->cfg.flags & SGX_FLAG_PAIRED_FRAMES)) {
         p.mono_pairs = 1;
         p.mags = d_mags;
         const unsigned long long q0 = first_frame / 2, q1 = (first_frame + n_frames + 1) / 2;
@@ -1210,7 +1210,7 @@ hipError_t chirpz_init(sgx_ctx *c, void **out)
 bool chirpz_real_serves(const sgx_ctx *c, const void *tables, uint32_t channels)
 {
     const auto *t = static_cast<const mix::ChirpTables *>(tables);
-    return t && t->half && channels == 1 && (c->cfg.flags & SGX_FLAG_INDEPENDENT_FRAMES) && !(c->cfg.flags & SGX_FLAG_COMPLEX_MONO);
+    return t && t->half && channels == 1 && !(c->cfg.flags & SGX_FLAG_PAIRED_FRAMES) && !(c->cfg.flags & SGX_FLAG_COMPLEX_MONO);
 }
 
 void chirpz_destroy(void *tables)
@@ -1281,7 +1281,7 @@ hipError_t launch_stft_chirpz(const sgx_ctx *c, const void *tables, const float 
         }
     };
     const size_t max_chunk = 1u << 30;
-    if (channels == 1 && !(c->cfg.flags & SGX_FLAG_INDEPENDENT_FRAMES)) {
+    if (channels == 1 && (c->cfg.flags & SGX_FLAG_PAIRED_FRAMES)) {
         p.mono_pairs = 1;
         p.mags = d_mags;
         const unsigned long long q0 = first_frame / 2, q1 = (first_frame + n_frames + 1) / 2;

@@ -20,8 +20,8 @@ class SpectrogramEngine:
                  f_min: float = 32.0, f_max: float = 22030.0, min_db: float = -70.0, max_db: float = -10.0,
                  interp: int = _lib.INTERP_CUBIC, lut_index_mode: int = _lib.LUT_FLOOR_N,
                  device: Optional[int] = None, force_generic: bool = False, gradient: Optional[str] = None,
-                 fused_render: bool = True, independent_frames: bool = False, lut_walk: bool = False, residue_16k: bool = False,
-                 mixed_generic: bool = False, complex_mono: bool = False, paired_frames: bool = False, channel_planes: bool = False, k16_w: bool = False):
+                 fused_render: bool = True, lut_walk: bool = False,
+                 mixed_generic: bool = False, complex_mono: bool = False, paired_frames: bool = False):
         import torch
 
         self._lib = _lib.load()
@@ -41,10 +41,8 @@ class SpectrogramEngine:
         cfg.interp, cfg.lut_index_mode = interp, lut_index_mode
         cfg.device = -1 if device is None else int(device)
         cfg.flags = (_lib.FLAG_FORCE_GENERIC if force_generic else 0) | (0 if fused_render else _lib.FLAG_NO_FUSED_RENDER) \
-            | (_lib.FLAG_INDEPENDENT_FRAMES if independent_frames else 0) \
-            | (_lib.FLAG_LUT_WALK if lut_walk else 0) | (_lib.FLAG_RESIDUE_16K if residue_16k else 0) | (_lib.FLAG_MIXED_GENERIC if mixed_generic else 0) \
-            | (_lib.FLAG_COMPLEX_MONO if complex_mono else 0) | (_lib.FLAG_PAIRED_FRAMES if paired_frames else 0) \
-            | (_lib.FLAG_CHANNEL_PLANES if channel_planes else 0) | (_lib.FLAG_K16_W if k16_w else 0)
+            | (_lib.FLAG_LUT_WALK if lut_walk else 0) | (_lib.FLAG_MIXED_GENERIC if mixed_generic else 0) \
+            | (_lib.FLAG_COMPLEX_MONO if complex_mono else 0) | (_lib.FLAG_PAIRED_FRAMES if paired_frames else 0)
         if device is not None and torch.cuda.is_available():
             torch.cuda.set_device(int(device))
         rc = self._lib.sgx_create(C.byref(cfg), C.byref(self._ctx))

@@ -202,23 +202,19 @@ def test_app_point_4800_point_kernel(torch_cuda, mags_err, gradients, ch, paired
     eng.close()
 
 
-@pytest.mark.parametrize("ch,variant", [(8, "quad"), (2, "quad"), (1, "quad"), (1, "quad_paired"), (8, "residue"), (2, "residue"), (1, "residue"),
-                                        (1, "residue_paired"), (8, "generic"), (8, "quad_planes"), (6, "quad_planes"),
-                                        (8, "wide"), (6, "wide"), (2, "wide"), (1, "wide"), (1, "wide_paired")])
+@pytest.mark.parametrize("ch,variant", [(8, "tuned"), (6, "tuned"), (2, "tuned"), (1, "tuned"), (1, "tuned_paired"), (8, "generic")])
 def test_config4_16384_point_kernel(torch_cuda, mags_err, ch, variant):
-    # BASELINE config 4: W 8192 / P 16384, hop 512, interleaved channel pairs; the time-decimated lane-quad kernel (default), the
-    # four-residue kernel of round 2 (SGX_FLAG_RESIDUE_16K) and the generic kernel, each against the oracle
+    # BASELINE config 4: W 8192 / P 16384, hop 512, interleaved channel pairs; the tuned kernel (32 x 32 x 16 in one 512-thread workgroup,
+    # stft16384_w.hip: stft_kernel 10) and the generic kernel, each against the oracle
     torch = torch_cuda
     Wt, Ht = 8192, 512
-    # (a mono stream: by default every frame its own (s, s) transform -- the lane-quad kernel on a duplicated plane, the four-residue
-    # design through the generic kernel --, "_paired": two frames per transform, SGX_FLAG_PAIRED_FRAMES)
+    # (a mono stream: by default every frame its own (s, s) transform -- the tuned kernel on a duplicated plane --, "_paired": two frames
+    # per transform, SGX_FLAG_PAIRED_FRAMES)
     paired = variant.endswith("_paired")
-    planes = variant.endswith("_planes")      # SGX_FLAG_CHANNEL_PLANES: the sample range split into (l, r) planes first (default: pairs read where they lie)
     variant = variant.split("_")[0]
     force_generic = variant == "generic"
-    eng = engine(window_samples=Wt, hop_samples=Ht, channels=ch, force_generic=force_generic, residue_16k=(variant == "residue"), paired_frames=paired,
-                 channel_planes=planes, k16_w=(variant == "wide"))
-    assert eng.info.stft_kernel == {"quad": 8, "residue": 5, "generic": 0, "wide": 10}[variant]
+    eng = engine(window_samples=Wt, hop_samples=Ht, channels=ch, force_generic=force_generic, paired_frames=paired)
+    assert eng.info.stft_kernel == {"tuned": 10, "generic": 0}[variant]
     n = Wt + 21 * Ht + 9
     pcm = oracle.white_noise(n * ch, seed=40 + ch)
     dev = to_dev(torch, pcm)
@@ -226,8 +222,6 @@ def test_config4_16384_point_kernel(torch_cuda, mags_err, ch, variant):
     ref = oracle.stream_process(pcm, ch, Wt, Ht, threads=8)
     assert got.shape == ref.shape == (22, max(ch // 2, 1), Wt - 1, 2)
     assert mags_err(got, ref) <= 2.0
-    if planes:   # the same arithmetic on the same samples: the bytes of the default path
-        assert np.array_equal(engine(window_samples=Wt, hop_samples=Ht, channels=ch).stft_batch(dev).cpu().numpy(), got)
     lr = pcm.reshape(-1, ch)
     truth = oracle.np_truth_frame(np.stack([lr[5 * Ht:5 * Ht + Wt, 0], lr[5 * Ht:5 * Ht + Wt, min(1, ch - 1)]], 1), Wt)
     assert mags_err(got[5, 0], truth) <= 1.0
@@ -236,16 +230,16 @@ def test_config4_16384_point_kernel(torch_cuda, mags_err, ch, variant):
     for first, cnt in ((1, 4), (6, 3), (21, 1)):   # sub-ranges give the same bytes (mono pairs by global index)
         assert np.array_equal(eng.stft_batch(dev, first_frame=first, max_frames=cnt).cpu().numpy(), got[first:first + cnt])
     if ch == 8:
-        # a stream that is 8- but not 16-byte aligned takes the narrow de-interleave: same bytes
+        # a stream that is 8- but not 16-byte aligned: same bytes
         shifted = torch.empty(dev.numel() + 2, dtype=dev.dtype, device=dev.device)
         shifted[2:] = dev
         assert shifted[2:].data_ptr() % 16 == 8
         assert np.array_equal(eng.stft_batch(shifted[2:]).cpu().numpy(), got)
     if variant != "generic" and ch >= 6:
         # more jobs than persistent workgroups (142 hop positions x 4 pairs = 568 > 512): every workgroup runs several jobs with
-        # different data -- a stale read of what the previous job left (the four-residue kernel parks half of its magnitudes in a
-        # slot it reads back; both kernels re-use LDS images and prefetch registers across jobs) would show here
-        # 530 hop positions = 2 120 jobs: also past the size from which the lane-quad kernel hands every XCD its own eighth of the jobs
+        # different data -- a stale read of what the previous job left (the kernel re-uses its LDS image, its prefetch registers and the
+        # pending row across jobs) would show here
+        # 530 hop positions = 2 120 jobs: also past the size from which the kernel hands every XCD its own eighth of the jobs
         for hops in (142, 530):
             pcm2 = oracle.white_noise((Wt + (hops - 1) * Ht) * ch, seed=77 + hops)
             got2 = eng.stft_batch(to_dev(torch, pcm2)).cpu().numpy()
@@ -264,7 +258,7 @@ def test_generic_kernel_pairs_mono_frames_by_global_index(torch_cuda, mags_err, 
     # and the powers of two from W = 512 on that have no tuned kernel: 1024 = 4 x 16 x 16, 2048 = 8 x 16 x 16, 8192 = 4 x 8 x 16 x 16) and the
     # chirp-z kernel (2204 = 4 * 19 * 29): a mono stream rides two frames per transform there too
     # (frames 2q and 2q+1 in the real / imaginary part), any sub-range writes the bytes of the full run, and
-    # SGX_FLAG_INDEPENDENT_FRAMES restores the reference's (s, s) dataflow
+    # the default (no flag) is the reference's (s, s) dataflow
     torch = torch_cuda
     pcm = oracle.white_noise(Wt + 37 * Ht + 5, seed=Wt)
     dev = to_dev(torch, pcm)
@@ -280,7 +274,6 @@ def test_generic_kernel_pairs_mono_frames_by_global_index(torch_cuda, mags_err, 
     ind_eng = engine(window_samples=Wt, hop_samples=Ht, channels=1)            # the default: every frame its own (s, s) transform
     ind = ind_eng.stft_batch(dev).cpu().numpy()
     assert mags_err(ind, ref) <= tol and mags_err(ind, got.astype(np.float64)) <= tol
-    assert np.array_equal(engine(window_samples=Wt, hop_samples=Ht, channels=1, independent_frames=True).stft_batch(dev).cpu().numpy(), ind)
     for first, count in [(1, 36), (7, 1), (5, 6)]:
         assert np.array_equal(ind_eng.stft_batch(dev, first_frame=first, max_frames=count).cpu().numpy(), ind[first:first + count])
 
@@ -552,7 +545,7 @@ def test_full_size_config4_properties(torch_cuda, mags_err):
     Wt, Ht, ch, hops = 8192, 512, 8, 100_000
     Mt = Wt - 1
     eng = engine(window_samples=Wt, hop_samples=Ht, channels=ch)
-    assert eng.info.stft_kernel == 8, "the lane-quad 16384-point kernel must be the one that runs"
+    assert eng.info.stft_kernel == 10, "the tuned 16384-point kernel must be the one that runs"
     n = (hops - 1) * Ht + Wt
     pcm = eng.white_noise(n)
     assert pcm.numel() == n * ch
@@ -1038,7 +1031,7 @@ def test_frame_pairing_dynamic_range_and_independent_frames(torch_cuda, mags_err
     # A mono transform carries two frames; float32 rounding of the louder one is the noise floor of the
     # quieter one (as left / right share one transform in the reference).  Frames that share 7/8 of their
     # samples are never far apart in level -- except across an isolated transient.  By default (W 2048 / H 256: the real-input
-    # kernel) and with independent_frames=True every frame gets its own transform, exactly the reference's dataflow;
+    # kernel) every frame gets its own transform, exactly the reference's dataflow;
     # paired_frames=True is the two-frames-per-transform mode.
     torch = torch_cuda
     x = oracle.white_noise(W + 3 * H, seed=9) * np.float32(1e-3)
@@ -1046,7 +1039,7 @@ def test_frame_pairing_dynamic_range_and_independent_frames(torch_cuda, mags_err
     ref = np.stack([oracle.np_truth_frame(np.stack([x[t * H:t * H + W]] * 2, 1), W) for t in range(4)])
     paired = engine(window_samples=W, hop_samples=H, channels=1, paired_frames=True).stft_batch(to_dev(torch, x)).cpu().numpy()[:, 0]
     indep = engine(window_samples=W, hop_samples=H, channels=1).stft_batch(to_dev(torch, x)).cpu().numpy()[:, 0]   # the default at this window / hop
-    cplx = engine(window_samples=W, hop_samples=H, channels=1, independent_frames=True, complex_mono=True).stft_batch(to_dev(torch, x)).cpu().numpy()[:, 0]
+    cplx = engine(window_samples=W, hop_samples=H, channels=1, complex_mono=True).stft_batch(to_dev(torch, x)).cpu().numpy()[:, 0]
     assert mags_err(indep, ref) <= 1.0 and mags_err(cplx, ref) <= 1.0   # every frame within tolerance of the truth
     assert mags_err(paired[[0, 2, 3]], ref[[0, 2, 3]]) <= 1.0
     # frame 1 rides with the click: its error is bounded relative to the PAIR's peak, not its own
@@ -1070,7 +1063,6 @@ def test_real_input_kernel_for_independent_mono_frames(torch_cuda, mags_err, n_f
     cplx = engine(window_samples=W, hop_samples=H, channels=1, complex_mono=True)
     pair = engine(window_samples=W, hop_samples=H, channels=1, paired_frames=True)
     assert real.info.stft_kernel == 2 and real.info.render_path & 8 and not (cplx.info.render_path & 8) and not (pair.info.render_path & 8)
-    assert engine(window_samples=W, hop_samples=H, channels=1, independent_frames=True, paired_frames=True).info.render_path & 8   # "never pair" wins
     got = real.stft_batch(dev).cpu().numpy()
     assert got.shape == (n_frames, 1, M, 2)
     pick = sorted(set(list(range(min(n_frames, 24))) + [n_frames - 1, n_frames // 2] + list(range(0, n_frames, 97))))
@@ -1080,7 +1072,6 @@ def test_real_input_kernel_for_independent_mono_frames(torch_cuda, mags_err, n_f
     ref32 = oracle.stream_process(pcm, 1, W, H, threads=8)
     assert mags_err(got, ref32) <= 2.0
     assert mags_err(got, cplx.stft_batch(dev).cpu().numpy().astype(np.float64)) <= 2.0
-    assert np.array_equal(engine(window_samples=W, hop_samples=H, channels=1, independent_frames=True).stft_batch(dev).cpu().numpy(), got)
     assert _pair_error(pair.stft_batch(dev).cpu().numpy()[pick, 0], truth) <= 1.0 if pick == list(range(n_frames)) else True
     # frames are independent problems: any sub-range, from an odd first frame too, writes the bytes of the full run
     for first, cnt in ((0, 1), (1, 1), (1, 2), (2, 5), (n_frames - 1, 1), (n_frames // 2, n_frames)):
@@ -1096,7 +1087,7 @@ def test_real_input_kernel_for_independent_mono_frames(torch_cuda, mags_err, n_f
     shifted = torch.empty(dev.numel() + 1, dtype=dev.dtype, device=dev.device)
     shifted[1:] = dev
     assert shifted[1:].data_ptr() % 8 == 4
-    alt = engine(window_samples=W, hop_samples=H, channels=1, independent_frames=True).stft_batch(shifted[1:]).cpu().numpy()
+    alt = engine(window_samples=W, hop_samples=H, channels=1, complex_mono=False).stft_batch(shifted[1:]).cpu().numpy()
     assert mags_err(alt[pick, 0], truth) <= 1.0
     assert np.array_equal(real.stft_batch(shifted[1:]).cpu().numpy(), alt)
     # determinism

@@ -8,6 +8,9 @@ import re
 import sys
 
 bad = total = 0
+# instructions that read M0 without naming it: s_set_gpr_idx_* / v_movrel* (index), buffer_load ... lds and global_load_lds (LDS base),
+# ds_gws_* , s_sendmsg*, s_ttracedata, v_interp_* (parameter base), ds_*_addtid itself is the one expected user
+IMPLICIT_M0 = re.compile(r"^(s_set_gpr_idx|v_movrel|global_load_lds|ds_gws|s_sendmsg|s_ttracedata|v_interp|ds_ordered_count)")
 _addtid_files = {}
 
 
@@ -35,6 +38,13 @@ for path in sys.argv[1:]:
             # compiler's back, so compiler-generated users of M0 (s_movrel, LDS-DMA, readlane by M0 ...) must not exist beside them
             bad += 1
             print("%s:%d: %s -- another user of M0 beside the add-TID statements" % (path, n, t))
+        if uses_addtid(path) and IMPLICIT_M0.match(op):
+            # ... and the users whose assembly text never names m0: indexed register moves, LDS-DMA, GWS, messages
+            bad += 1
+            print("%s:%d: %s -- reads M0 implicitly, beside add-TID statements that set it behind the compiler's back" % (path, n, t))
+        if uses_addtid(path) and op.startswith("buffer_load") and re.search(r"\blds\b", t):
+            bad += 1
+            print("%s:%d: %s -- LDS-DMA takes its LDS base from M0" % (path, n, t))
         if "addtid" in op:
             total += 1
             if since_m0 is None or since_m0 < 1:

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """BASELINE config 4 (16384-point, hop 512, 8 interleaved channels), the two 16384-point kernels in ONE process, interleaved rounds
-(lane quads, stft16384_d.hip  vs  32 x 32 x 16, stft16384_w.hip): ms per launch per round, median and min; the same bytes within the
+(stft16384_w.hip): ms per launch per round, median and min; the same bytes within the
 tolerance (different decompositions round differently), each against the float64 truth on sampled rows.
 usage: tools/k16_ab.py [hop positions] [rounds] [channels]"""
 import os
@@ -16,10 +16,9 @@ HOPS = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
 ROUNDS = int(sys.argv[2]) if len(sys.argv) > 2 else 7
 CH = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 W, H = 8192, 512
-engs = {"quad (1024 thr x 16 pts)": SpectrogramEngine(48000.0, window_samples=W, hop_samples=H, channels=CH),
-        "wide (512 thr x 32 pts)": SpectrogramEngine(48000.0, window_samples=W, hop_samples=H, channels=CH, k16_w=True)}
-if os.environ.get("K16_ONLY"):      # K16_ONLY=wide / quad: one kernel (variant sweeps)
-    engs = {k: e for k, e in engs.items() if k.startswith(os.environ["K16_ONLY"])}
+# (round 6 compared the lane-quad kernel of rounds 3-5 with the 32 x 32 x 16 one here, in one process: profiles/r06_k16.txt; the former is gone --
+# what is left is the one kernel against another BUILD of it: K16_AB_LIB=spectrogram_rs_amd/ab/<variant>.so, tools/build_variant.sh)
+engs = {"wide (512 thr x 32 pts)": SpectrogramEngine(48000.0, window_samples=W, hop_samples=H, channels=CH)}
 print({k: e.info.stft_kernel for k, e in engs.items()})
 e0 = next(iter(engs.values()))
 pcm = e0.white_noise((HOPS - 1) * H + W)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Where a wave of K16 (csrc/stft16384_d.hip, BASELINE config 4) spends its cycles: diagnostic build -DSGX_STAMPS=1
-(SRC=stft16384_d.hip tools/build_variant.sh <name> -DSGX_STAMPS=1), s_memtime at every phase boundary, summed over all waves.
+"""Where a wave of K16 (csrc/stft16384_w.hip, BASELINE config 4) spends its cycles: diagnostic build -DSGX_STAMPS=1
+(SRC=stft16384_w.hip tools/build_variant.sh <name> -DSGX_STAMPS=1), s_memtime at every phase boundary, summed over all waves.
 usage: SGX_LIB=spectrogram_rs_amd/ab/<name>.so tools/k16_phases.py [hop positions]"""
 import ctypes as C
 import os
@@ -12,12 +12,11 @@ import torch
 from spectrogram_rs_amd import SpectrogramEngine, _lib
 
 HOPS = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
-PH = {0: "bookkeeping + pass-1 FFT8 x2", 1: "barrier A", 2: "flush: staged row read back + four 16-byte stores issued", 3: "image-1 writes, first half", 4: "barrier B",
-      5: "image-1 writes, second half", 6: "barrier C", 7: "image-1 reads + FFT16", 8: "pass-2 twiddles + writes (own row)", 9: "pass-3 reads + FFT16",
-      10: "prefetch requests + recombination (DPP)", 11: "barrier D", 12: "partner writes", 13: "barrier E", 14: "partner reads + split + staging writes",
-      15: "wait for next samples + Hann", 19: "loop control"}
+PH = {0: "bookkeeping + pass-1 arithmetic (pretwiddle, FFT16 x2)", 1: "barrier B0 (previous pass-3 reads done)", 2: "pass-1 twiddles + 32 image writes",
+      3: "barrier B1 (image complete)", 4: "32 image reads + FFT32", 5: "pass-2 twiddles (31 broadcast reads) + 32 writes in place", 6: "barrier B2",
+      7: "2 x 16 reads + FFT16 x2", 8: "prefetch requests (16 loads)", 9: "split + 16 row stores", 10: "wait for next samples + Hann", 19: "loop control"}
 lib = _lib.load()
-fn = lib.sgx_debug_phase_cycles16
+fn = lib.sgx_debug_phase_cycles16w
 fn.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
 buf = (C.c_ulonglong * 24)()
 eng = SpectrogramEngine(48000.0, window_samples=8192, hop_samples=512, channels=8)
@@ -37,7 +36,7 @@ ms = e0.elapsed_time(e1) / 5
 fn(buf, 1)
 iters = buf[20]
 total = sum(buf[i] for i in range(20))
-print(f"== config 4: {ms:.3f} ms per {HOPS} hop positions (stamped build, incl. the de-interleave pass); {iters} wave-iterations, {total / iters:.0f} cycles per wave-iteration")
+print(f"== config 4: {ms:.3f} ms per {HOPS} hop positions (stamped build); {iters} wave-iterations, {total / iters:.0f} cycles per wave-iteration")
 bar = 0
 for i, ph in sorted(PH.items()):
     print(f"  {buf[i] / iters:8.0f} cycles  {100.0 * buf[i] / total:5.1f} %   {ph}")

@@ -68,15 +68,11 @@ t2 = traffic("stft4096_real_kernel<0, 0, true>", F, 17400)
 t3 = traffic("stft4096_real_kernel<2, 2, true>", F, 5120)
 t2p = traffic("stft4096_wg_kernel<true, 0, false, 0>", F, 17400)     # the paired leg (SGX_FLAG_PAIRED_FRAMES), if the pass ran it
 hops = 20_000      # (tools/pmc_bench.sh runs the config-4 leg at 20 000 hop positions: a counter pass serialises every dispatch)
-t4a = traffic("stft16384_d_kernel<false, true>", hops, 278496)      # the default: the pairs read where they lie, ONE kernel
-t4p = traffic("stft16384_d_kernel<false, false>", hops, 278496)     # SGX_FLAG_CHANNEL_PLANES (the leg's side measurement): transform over planes
-t4b = traffic("deinterleave_pa", hops, 278496)   # ... and its de-interleave pass (deinterleave_pairs_kernel or deinterleave_paired_kernel<WIDE>)
+t4a = traffic("stft16384_w_kernel<false, true>", hops, 278496)      # the pairs read where they lie, ONE kernel
 out["config2_stft"] = t2
 out["config2_stft_paired_frames"] = t2p
 out["config3_fused_pixel"] = t3
 out["config4_transform"] = t4a
-out["config4_planes_transform"] = t4p
-out["config4_planes_deinterleave"] = t4b
 if t2:
     out["stft_bytes_per_frame"] = t2["bytes_per_unit"]
 if t3:
@@ -84,17 +80,14 @@ if t3:
 if t4a:
     out["config4_bytes_per_hop"] = t4a["bytes_per_unit"]
     out["config4_traffic_over_algorithmic"] = out["config4_bytes_per_hop"] / 278496
-if t4p and t4b:
-    out["config4_planes_traffic_over_algorithmic"] = (t4p["bytes_per_unit"] + t4b["bytes_per_unit"]) / 278496
 if t4a:
     fetch_kb = 2.0 * t4a["FETCH_SIZE_bytes_raw"] / hops / 1e3
     write_kb = t4a["WRITE_SIZE_bytes"] / hops / 1e3
     out["note_config4"] = (
         "config 4: FETCH_SIZE / WRITE_SIZE count requests between L2 and the fabric, Infinity-Cache hits included. Per hop position the "
-        f"transform kernel writes {write_kb:.0f} KB (262 KB of algorithmic output; nothing is parked since round 3's kernel, csrc/stft16384_d.hip) "
-        f"and fetches {fetch_kb:.0f} KB: the interleaved stream itself (the pairs are read where they lie since the end of round 5; "
-        "SGX_FLAG_CHANNEL_PLANES = the de-interleave pass + planes of rounds 3-5), every sample wanted by 16 overlapping hop positions and four "
-        "pairs, served mostly by L2 (16 KB algorithmic).")
+        f"transform kernel (csrc/stft16384_w.hip) writes {write_kb:.0f} KB (262 KB of algorithmic output: 8-byte row stores at an 8-byte row phase, a wave's 512-byte run "
+        f"shares its first and last line with its neighbours') and fetches {fetch_kb:.0f} KB: the interleaved stream itself (the pairs are read where they lie), "
+        "every sample wanted by 16 overlapping hop positions and four pairs, served mostly by L2 (16 KB algorithmic).")
 json.dump(out, open(os.path.join(root, "profiles", f"{rnd}_hbm_traffic.json"), "w"), indent=1)
 
 # ---- pipes of the fused pixel kernel -------------------------------------------------------------------------------

@@ -53,9 +53,9 @@ if __name__ == "__main__" and not any(f in sys.argv for f in ("--extra", "--live
     main()
 
 
-def config4(frames=20000, channels=8, residue=False):
+def config4(frames=20000, channels=8):
     """BASELINE config 4: 16384-point STFT, hop 512, 8 interleaved channels (4 pairs)"""
-    eng = SpectrogramEngine(48000.0, window_samples=8192, hop_samples=512, channels=channels, residue_16k=residue)
+    eng = SpectrogramEngine(48000.0, window_samples=8192, hop_samples=512, channels=channels)
     n = (frames - 1) * eng.H + eng.W
     pcm = eng.white_noise(n)
     out = torch.empty((frames, eng.pairs, eng.M, 2), dtype=torch.float32, device="cuda")
@@ -80,10 +80,6 @@ def app_default(frames=20000):
 
 if __name__ == "__main__" and "--config4" in sys.argv:
     for ch in ((2,) if "--stereo-only" in sys.argv else (8,) if "--ch8-only" in sys.argv else (8, 2, 1)):
-        if "--quad-vs-residue" in sys.argv:
-            a = config4(channels=ch, residue=True)
-            b = config4(channels=ch, residue=False)
-            print(f"  ch={ch}: max |residue - quad| = {(a - b).abs().max().item():.3e} (peak {a.abs().max().item():.3e})", flush=True)
             del a, b
             continue
         config4(channels=ch)

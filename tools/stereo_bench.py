@@ -26,7 +26,7 @@ def timeit(fn, reps=7):
 
 out = torch.empty((F, 1, 2047, 2), dtype=torch.float32, device="cuda")
 for name, kw, H in (("mono, default (real-input kernel)", dict(channels=1), 256), ("mono pairs, hop 256", dict(channels=1, paired_frames=True), 256), ("(l, r) stream", dict(channels=2), 256),
-                    ("independent mono frames", dict(channels=1, independent_frames=True), 256), ("mono pairs, hop 255", dict(channels=1), 255)):
+                    ("independent mono frames", dict(channels=1), 256), ("mono pairs, hop 255", dict(channels=1), 255)):
     eng = SpectrogramEngine(48000.0, window_samples=2048, hop_samples=H, gradient="viridis", **kw)
     pcm = eng.white_noise((F - 1) * H + 2048)
     ms = timeit(lambda: eng.stft_batch(pcm, out=out))
