@@ -234,7 +234,7 @@ def compact_line(full, budget=LINE_BUDGET):
     line["config"] = pick(cfg, "workload", "window", "fft_length", "hop", "channels", "frames_per_gpu", "kernel", "sharding")
     roof = full.get("roofline") or {}
     rl = pick(roof, "bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "launch_ms", "bytes_per_frame", "frames_per_launch",
-              "frac_burst", "frac_sustained", "fp32_frac", "fp32_frac_nominal", "traffic_source", "sclk_mhz_after_run")
+              "frac_burst", "frac_sustained", "fp32_frac", "fp32_frac_nominal", "valu_issue_frac", "traffic_source", "sclk_mhz_after_run")
     rl.setdefault("traffic", None)
     if roof.get("first_allocation"):
         rl["first_allocation"] = pick(roof["first_allocation"], "launch_ms", "frac", "is_value")
@@ -265,6 +265,7 @@ def compact_line(full, budget=LINE_BUDGET):
         line["config3_frac"] = r6(rf.get("frac"))
         line["config3_fp32_frac"] = r6(rf.get("fp32_frac"))
         line["config3_fp32_frac_nominal"] = r6(rf.get("fp32_frac_nominal"))
+        line["config3_valu_issue_frac"] = r6(rf.get("valu_issue_frac"))
         line["config3_frames_per_s"] = r6(c3.get("frames_per_s"))
         if isinstance(c3.get("cubic"), dict) and "frames_per_s" in c3["cubic"]:
             line["config3_cubic_frames_per_s"] = r6(c3["cubic"]["frames_per_s"])
@@ -277,6 +278,7 @@ def compact_line(full, budget=LINE_BUDGET):
         line["config4_frac"] = r6(rf.get("frac"))
         line["config4_fp32_frac"] = r6(rf.get("fp32_frac"))
         line["config4_fp32_frac_nominal"] = r6(rf.get("fp32_frac_nominal"))
+        line["config4_valu_issue_frac"] = r6(rf.get("valu_issue_frac"))
         line["config4_hop_positions_per_s"] = r6(c4.get("hop_positions_per_s"))
         line["config4_traffic_over_algorithmic"] = r6(rf.get("traffic_over_algorithmic"))
     st = full.get("stereo4096")
@@ -285,6 +287,7 @@ def compact_line(full, budget=LINE_BUDGET):
         line["stereo_frac"] = r6(rf.get("frac"))
         line["stereo_fp32_frac"] = r6(rf.get("fp32_frac"))
         line["stereo_fp32_frac_nominal"] = r6(rf.get("fp32_frac_nominal"))
+        line["stereo_valu_issue_frac"] = r6(rf.get("valu_issue_frac"))
         line["stereo_frames_per_s"] = r6(st.get("frames_per_s"))
     for key, short in (("mono_paired_frames", "mono_paired_frac"), ("mono_complex_frames", "mono_complex_frac")):
         if isinstance(full.get(key), dict):
@@ -352,11 +355,19 @@ def fp32_fracs(leg, nominal_flop_per_unit, units_per_s):
     complex transform of the reference's length per frame, whatever the kernel really does) x rate / 157.3 TFLOP/s; `fp32_frac`: the
     f32 operations the kernel EXECUTES per unit -- SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F32 x 64 lanes (FMA twice), a rocprofv3 --pmc
     pass of this round committed as profiles/<round>_fp32_flops.json (tools/pmc_flops.py) -- x rate / peak; None without that file."""
-    counted = ((load_profile_json("fp32_flops") or {}).get("flop_per_unit") or {}).get(leg)
+    prof = load_profile_json("fp32_flops") or {}
+    counted = (prof.get("flop_per_unit") or {}).get(leg)
     peak = FP32_PEAK_TFLOPS * 1e12
-    return {"fp32_frac_nominal": nominal_flop_per_unit * units_per_s / peak,
-            "fp32_frac": (counted * units_per_s / peak) if counted else None,
-            "fp32_flop_per_unit_counted": counted, "fp32_flop_per_unit_nominal": nominal_flop_per_unit}
+    out = {"fp32_frac_nominal": nominal_flop_per_unit * units_per_s / peak,
+           "fp32_frac": (counted * units_per_s / peak) if counted else None,
+           "fp32_flop_per_unit_counted": counted, "fp32_flop_per_unit_nominal": nominal_flop_per_unit}
+    # ... and the share of the vector pipes' ISSUE slots the kernel fills: every wave-instruction of the vector ALU (SQ_INSTS_VALU: adds,
+    # multiplies, moves, address arithmetic alike) holds its SIMD for 2 clocks; 1 024 SIMDs at the 2.4 GHz the peak is quoted at.  An
+    # FFT is adds and multiplies (1 flop per lane and slot) more than fused multiply-adds (2): fp32_frac can at best reach about half.
+    lg = (prof.get("legs") or {}).get(leg) or {}
+    if lg.get("valu_wave_instructions_all") and lg.get("units_per_launch"):
+        out["valu_issue_frac"] = lg["valu_wave_instructions_all"] / lg["units_per_launch"] * units_per_s * 2.0 / (1024 * 2.4e9)
+    return out
 
 
 def stats_ms(v):
