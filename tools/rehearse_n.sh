@@ -1,10 +1,10 @@
 #!/bin/bash
-# usage (one-GPU box, repo root): tools/rehearse_n.sh [N=6] [config-5 frames=1000003]  -- bench.py's N > 1 control flow with N fresh rank processes on
+# usage (one-GPU box, repo root): tools/rehearse_n.sh [N=5] [config-5 frames=1000003]  -- bench.py's N > 1 control flow with N fresh rank processes on
 # the ONE device (BENCH_BACKEND=gloo BENCH_SINGLE_DEVICE=1: pieces staged through the host; RCCL refuses two ranks on one device), uneven tails, >= 3
 # gather rounds per rank; the root's checksum over all gathered columns against ONE process rendering the same stream (tools/config5_single.py).
-# N is at most 6 here: a GPU box of this pool admits six processes on its card (N = 8 runs under gloo with a stub engine in tests/test_bench_config5.py).
-n=${1:-6}; total=${2:-1000003}
-[ "$n" -le 6 ] || { echo "at most 6 ranks on one card"; exit 2; }
+# N is at most 5 here: a GPU box of this pool admits six processes on its card and torch.distributed.run's agent is one of them (six ranks: the process guard ended the run) (N = 8 runs under gloo with a stub engine in tests/test_bench_config5.py).
+n=${1:-5}; total=${2:-1000003}
+[ "$n" -le 5 ] || { echo "at most 5 ranks on one card (the launcher's agent process counts as the sixth)"; exit 2; }
 mkdir -p gpurun_out
 BENCH_BACKEND=gloo BENCH_SINGLE_DEVICE=1 timeout -k 10 600 python bench.py --gpus $n --steps 2 --warmup 1 --frames 65536 --placements 1 --sustain-s 0 \
     --config5-frames $total --config5-chunk 32768 --leg-timeout 300 > gpurun_out/rehearsal_n$n.json 2> gpurun_out/rehearsal_n$n.err || { tail -5 gpurun_out/rehearsal_n$n.err; exit 1; }
