@@ -201,6 +201,9 @@ __global__ void __launch_bounds__(512, 2) stft16384_w_kernel(Params p)
     // requests + all 16 stores at the top of the iteration 13.6 ms; requests at the top, stores in two groups around the FFT32 11.7;
     // requests in two halves 11.2 (profiles/r06_k16.txt): with two waves per SIMD a burst stalls the issuing wave at the memory
     // pipeline's queue, and nothing else is there to run.
+#ifndef W_B0_AT
+#define W_B0_AT 1   // barrier B0 (the previous transform's pass-3 reads are complete) -- 1: at the top of the next iteration, where the skew of a whole stretch of arithmetic has been absorbed and the pass-3 reads overlap the two FFT16 (same device 10.7 - 10.9 -> 10.45 - 10.5 ms); 0: right behind the pass-3 reads; 2: behind the two FFT16
+#endif
 #ifndef W_SPREAD
 #define W_SPREAD 2   // 2: and every LDS write of pass 1 and pass 2 issued the moment its value is final (the codelets' done() call-backs), inside the arithmetic
 #endif
@@ -321,6 +324,7 @@ __global__ void __launch_bounds__(512, 2) stft16384_w_kernel(Params p)
         // this transform's stores (vmcnt retires in issue order) and with ~14 000 cycles to arrive
         if (!kSpread && kPrefetchAt == 0 && more) prefetch(nxt);
 
+        if (W_B0_AT == 1) lds_barrier();   // B0: every wave's pass-3 reads of the previous transform are complete -- the image may be written again
         // ---- pass 1: 32-point DFT over a, inputs a >= 16 are the zero padding: even q1 = FFT16(z), odd q1 = FFT16(z * w_32^a)
         float orr[16], oi[16];
 #pragma unroll
@@ -374,11 +378,14 @@ __global__ void __launch_bounds__(512, 2) stft16384_w_kernel(Params p)
         SGX_STAMP(2)    // pass-1 twiddles + image writes
         // the pass-2 twiddles of this thread's c0 (a broadcast read per half wave), requested in front of the barrier: read one by one
         // where they are used, each exposed its LDS latency (31 x lgkmcnt(0) per wave and transform, two waves per SIMD to hide it)
+#ifndef W_T2_STREAM
+#define W_T2_STREAM 1   // 1 (spread mode): the pass-2 twiddles of sub-block s of the FFT32 (bins q2 = s mod 4) requested one sub-block ahead of their use, eight at a time -- 16 resident at most instead of 31 (time +-0)
+#endif
         float2 t2[32];
-        {
-            lds_cfloat2 *tw = lds_ptr(tw2 + 32 * hi5);
+        lds_cfloat2 *tw2p = lds_ptr(tw2 + 32 * hi5);
+        if (!(kSpread && W_T2_STREAM)) {
 #pragma unroll
-            for (int q2 = 1; q2 < 32; ++q2) t2[q2] = lds_read_alone(tw, q2);
+            for (int q2 = 1; q2 < 32; ++q2) t2[q2] = lds_read_alone(tw2p, q2);
         }
         lds_barrier();  // B1: the image is complete
         SGX_STAMP(3)
@@ -397,6 +404,14 @@ __global__ void __launch_bounds__(512, 2) stft16384_w_kernel(Params p)
             if constexpr (kSpread) {
             fft32h(xr, xi, [&](auto k) {
                 constexpr int kk = decltype(k)::value;
+                if constexpr (W_T2_STREAM && (kk == 2 || kk == 8 || kk == 14 || kk == 20)) {   // the twiddles of sub-block (kk - 2) / 6: bins q2 = s + 4 j
+                    constexpr int sb = (kk - 2) / 6;
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (sb + 4 * j > 0) t2[sb + 4 * j] = lds_read_alone(tw2p, sb + 4 * j);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 if constexpr ((kk & 1) == 0) {
                     constexpr int i = kk >> 1;       // bin 2 q3 + side of the pending row
                     __builtin_amdgcn_sched_barrier(0);
@@ -448,16 +463,23 @@ __global__ void __launch_bounds__(512, 2) stft16384_w_kernel(Params p)
                 br[c0] = v.x; bi[c0] = v.y;
             }
         }
-        lds_barrier();  // B0: every wave's pass-3 reads are complete -- the next transform's pass-1 writes may begin whenever a wave gets there
-        // (pinned behind the barrier: the two FFT16 are register arithmetic, which the compiler otherwise moves in front of it -- the
-        // barrier then sits behind 220 more instructions of skew)
+        if (W_B0_AT == 0) {
+            lds_barrier();  // B0 here (A/B): pinned in front of the two FFT16, register arithmetic the compiler otherwise moves in front of the barrier
 #pragma unroll
-        for (int c0 = 0; c0 < 16; ++c0) asm volatile("" : "+v"(ar[c0]), "+v"(ai[c0]), "+v"(br[c0]), "+v"(bi[c0]));
-        SGX_STAMP(7)    // pass-3 reads + barrier B0
+            for (int c0 = 0; c0 < 16; ++c0) asm volatile("" : "+v"(ar[c0]), "+v"(ai[c0]), "+v"(br[c0]), "+v"(bi[c0]));
+        }
+        SGX_STAMP(7)    // pass-3 reads
         if (!kSpread && W_DEFER && kFlushAt == 2) { flush_group(0); flush_group(1); }
         fft16(ar, ai);
         if (!kSpread && W_DEFER && kFlushAt == 2) { flush_group(2); flush_group(3); }
         fft16(br, bi);
+        if (W_B0_AT == 2) {
+#pragma unroll
+            for (int c0 = 0; c0 < 16; ++c0) asm volatile("" : "+v"(ar[c0]), "+v"(ai[c0]), "+v"(br[c0]), "+v"(bi[c0]));
+            lds_barrier();
+#pragma unroll
+            for (int c0 = 0; c0 < 16; ++c0) asm volatile("" : "+v"(ar[c0]), "+v"(ai[c0]), "+v"(br[c0]), "+v"(bi[c0]));
+        }
         SGX_STAMP(8)    // two FFT16
 
         // ---- split + magnitude (fft.rs:81-98): bin k = u + 1024 q3 (q3 < 8) with its partner F[P - k] = register 15 - q3 of the other column
