@@ -196,25 +196,16 @@ __global__ void __launch_bounds__(512, 2) stft16384_w_kernel(Params p)
             }
         }
     };
-    // W_SPREAD (default): one request behind each of the sixteen butterflies of pass 1's two FFT16, one row store behind every second
-    // butterfly of pass 2's FFT32 -- never two vector-memory instructions back to back.  Same device, per 400 000 transforms: all 16
-    // requests + all 16 stores at the top of the iteration 13.6 ms; requests at the top, stores in two groups around the FFT32 11.7;
-    // requests in two halves 11.2 (profiles/r06_k16.txt): with two waves per SIMD a burst stalls the issuing wave at the memory
-    // pipeline's queue, and nothing else is there to run.
-#ifndef W_B0_AT
-#define W_B0_AT 1   // barrier B0 (the previous transform's pass-3 reads are complete) -- 1: at the top of the next iteration, where the skew of a whole stretch of arithmetic has been absorbed and the pass-3 reads overlap the two FFT16 (same device 10.7 - 10.9 -> 10.45 - 10.5 ms); 0: right behind the pass-3 reads; 2: behind the two FFT16
-#endif
-#ifndef W_SPREAD
-#define W_SPREAD 2   // 2: and every LDS write of pass 1 and pass 2 issued the moment its value is final (the codelets' done() call-backs), inside the arithmetic
-#endif
-    constexpr bool kSpread = W_SPREAD && !MONO;   // (the paired-frame mono instantiation keeps the grouped placement: spread, it spills 12 registers)
-#ifndef W_PREFETCH_AT
-#define W_PREFETCH_AT (W_SPREAD ? 3 : 0)   // grouped placement -- 0: top of the iteration; 1: behind barrier B1; 2: behind barrier B2; 3: two halves, at the top and between the FFT16; 4: behind the pre-twiddle
-#endif
-#ifndef W_FLUSH_AT
-#define W_FLUSH_AT (W_SPREAD ? 1 : 0)      // the pending row's four store groups -- 0: between the stages of pass 1; 1: two in front of the FFT32, two behind; 2: inside pass 3; 3 / 4: all in front of / behind the FFT32; 5: 1 + 2 + 1 around FFT32 and pass-2 writes
-#endif
-    constexpr int kPrefetchAt = MONO ? 0 : W_PREFETCH_AT, kFlushAt = MONO ? 0 : W_FLUSH_AT;   // (mono pairs: twice the loads and stores; grouped at the top, no spill)
+    // Where the vector-memory instructions sit decides this kernel (profiles/r06_k16.txt section 3: with two waves per SIMD a BURST of
+    // them stalls the issuing wave at the memory pipeline's queue and nothing else is there to run -- same device, per 400 000 transforms:
+    // all 16 requests and all 16 stores at the top of the iteration 13.6 ms; spread as below 10.4).  kSpread, every stream but mono frame
+    // pairs: the FFT codelets call back behind every butterfly (`hook`) and for every finished bin (`done`), and
+    //   * ONE sample request sits behind each of the 16 butterflies of pass 1's two FFT16,
+    //   * ONE store of the previous transform's row behind every second butterfly of pass 2's FFT32,
+    //   * every LDS write of pass 1 and pass 2 is issued the moment its value is final, inside the arithmetic,
+    //   * the pass-2 twiddles are requested eight at a time, one sub-block of the FFT32 ahead of their use.
+    // Mono frame pairs (MONO: twice the requests and stores, an opt-in mode) keep them in groups: spread, that instantiation spills.
+    constexpr bool kSpread = !MONO;
     // The prefetched values are consumed (Hann, fft.rs:53-63) at the END of the iteration that requested them, behind its stores, in
     // straight-line code, and pinned there (stft16384_d.hip: consumed at the loop head the wait becomes vmcnt(0) -- every store acknowledged)
     float er[16], ei[16];
@@ -262,17 +253,11 @@ __global__ void __launch_bounds__(512, 2) stft16384_w_kernel(Params p)
     const int voffA7 = tid == 0 ? (int)0x7ffffffc : 8 * (uA - 1);    // ... and nothing in the store of j = 7 (out of range: dropped)
     const int voffB = 8 * (uB - 1);
 
-    // The finished row of a transform waits in 32 registers and is stored by the NEXT iteration, four stores at a time between the
-    // stages of its pass 1, BEHIND its sample requests: issued at the end of the transform, all eight waves' 128 store instructions
+    // The finished row of a transform waits in 32 registers and is stored by the NEXT iteration (kSpread: through its pass 2; mono pairs:
+    // four stores at a time between the stages of its pass 1), BEHIND its sample requests: issued at the end of the transform, all eight waves' 128 store instructions
     // (64 KB through a store path of ~34 B / clock / CU) went out at once and the next requests queued behind them -- same device,
-    // loads and stores each alone +0.1 / +1.2 ms per 400 000 transforms, together +4.3 (W_DEFER 0: the A/B).  An absent row
+    // loads and stores each alone +0.1 / +1.2 ms per 400 000 transforms, together +4.3.  An absent row
     // (nothing pending yet; the missing frame of a mono pair) is a descriptor of zero records: its stores are dropped.
-#ifndef W_DEFER
-#define W_DEFER 1
-#endif
-#if W_SPREAD && !W_DEFER
-#error "W_SPREAD stores the pending row inside the next iteration's pass 2: it needs W_DEFER"
-#endif
     float pm[32];
 #pragma unroll
     for (int i = 0; i < 32; ++i) pm[i] = 0.0f;
@@ -289,7 +274,7 @@ __global__ void __launch_bounds__(512, 2) stft16384_w_kernel(Params p)
     auto flush_group = [&](int g) {   // bins 4 g .. 4 g + 3 of the pending row: i = 2 q3 + side
 #pragma unroll
         for (int i = 4 * g; i < 4 * g + 4; ++i) store_bin(pm[2 * i], pm[2 * i + 1], pend0, pend1, (i & 1) ? voffB : (i == 14 ? voffA7 : voffA), 8192 * (i >> 1));
-        __builtin_amdgcn_sched_barrier(0);   // (the groups stay where they are put: between the stages of pass 1)
+        __builtin_amdgcn_sched_barrier(0);   // (the groups stay where they are put)
     };
 #if SGX_STAMPS
     unsigned long long st_acc[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -322,9 +307,12 @@ __global__ void __launch_bounds__(512, 2) stft16384_w_kernel(Params p)
         const JobIn nxt = job_in(more ? job + job_step : job, hop_c, pair_c);
         // the NEXT transform's samples, a whole iteration ahead of their use (`take`, behind this transform's row stores): in front of
         // this transform's stores (vmcnt retires in issue order) and with ~14 000 cycles to arrive
-        if (!kSpread && kPrefetchAt == 0 && more) prefetch(nxt);
+        if (!kSpread && more) prefetch(nxt);
 
-        if (W_B0_AT == 1) lds_barrier();   // B0: every wave's pass-3 reads of the previous transform are complete -- the image may be written again
+        lds_barrier();  // B0: every wave's pass-3 reads of the previous transform are complete -- the image may be written again.  (Here, at
+                        // the top of the next iteration, the skew of a whole stretch of arithmetic has been absorbed and the pass-3 reads
+                        // overlapped the two FFT16: right behind those reads the same barrier cost 2 - 4 %.)
+        SGX_STAMP(1)
         // ---- pass 1: 32-point DFT over a, inputs a >= 16 are the zero padding: even q1 = FFT16(z), odd q1 = FFT16(z * w_32^a)
         float orr[16], oi[16];
 #pragma unroll
@@ -336,38 +324,30 @@ __global__ void __launch_bounds__(512, 2) stft16384_w_kernel(Params p)
             if (h) v = cmulf(v, twh[h]);
             return v;
         };
+        pretwiddle16_w32(orr, oi);
         if constexpr (kSpread) {
-        // (the last iteration requests its own samples again: in bounds, never used -- no branch inside the arithmetic)
-        pretwiddle16_w32(orr, oi);
-        fft16h(er, ei, [&](auto k) {
-            __builtin_amdgcn_sched_barrier(0);
-            prefetch(nxt, decltype(k)::value, decltype(k)::value + 1);
-            __builtin_amdgcn_sched_barrier(0);
-        }, [&](auto m, float re, float im) {   // even rows q1 = 2 m, written while the second FFT16 is still to come
-            if constexpr (W_SPREAD >= 2) w1[(2 * decltype(m)::value) * kS] = tw_of(make_float2(re, im), 2 * decltype(m)::value);
-        });
-        fft16h(orr, oi, [&](auto k) {
-            __builtin_amdgcn_sched_barrier(0);
-            prefetch(nxt, 8 + decltype(k)::value, 9 + decltype(k)::value);
-            __builtin_amdgcn_sched_barrier(0);
-        }, [&](auto m, float re, float im) {
-            if constexpr (W_SPREAD >= 2) w1[(2 * decltype(m)::value + 1) * kS] = tw_of(make_float2(re, im), 2 * decltype(m)::value + 1);
-        });
+            // (the last iteration requests its own samples again: in bounds, never used -- no branch inside the arithmetic)
+            fft16h(er, ei, [&](auto k) {
+                __builtin_amdgcn_sched_barrier(0);
+                prefetch(nxt, decltype(k)::value, decltype(k)::value + 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }, [&](auto m, float re, float im) {   // even rows q1 = 2 m, written while the second FFT16 is still to come
+                w1[(2 * decltype(m)::value) * kS] = tw_of(make_float2(re, im), 2 * decltype(m)::value);
+            });
+            fft16h(orr, oi, [&](auto k) {
+                __builtin_amdgcn_sched_barrier(0);
+                prefetch(nxt, 8 + decltype(k)::value, 9 + decltype(k)::value);
+                __builtin_amdgcn_sched_barrier(0);
+            }, [&](auto m, float re, float im) {
+                w1[(2 * decltype(m)::value + 1) * kS] = tw_of(make_float2(re, im), 2 * decltype(m)::value + 1);
+            });
         } else {
-        if (kPrefetchAt == 3 && more) prefetch(nxt, 0, 8);
-        if (W_DEFER && kFlushAt == 0) flush_group(0);
-        pretwiddle16_w32(orr, oi);
-        if (kPrefetchAt == 4 && more) prefetch(nxt);
-        if (W_DEFER && kFlushAt == 0) flush_group(1);
-        fft16(er, ei);
-        if (kPrefetchAt == 3 && more) prefetch(nxt, 8, 16);
-        if (W_DEFER && kFlushAt == 0) flush_group(2);
-        fft16(orr, oi);
-        if (W_DEFER && kFlushAt == 0) flush_group(3);
-        }
-        SGX_STAMP(0)    // job bookkeeping + prefetch requests + pass-1 arithmetic (two FFT16)
-        SGX_STAMP(1)
-        if (!(kSpread && W_SPREAD >= 2)) {
+            flush_group(0);
+            fft16(er, ei);
+            flush_group(1);
+            flush_group(2);
+            fft16(orr, oi);
+            flush_group(3);
 #pragma unroll
             for (int m = 0; m < 16; ++m) {
                 const int pos = FFT16_OUT[m];
@@ -375,21 +355,17 @@ __global__ void __launch_bounds__(512, 2) stft16384_w_kernel(Params p)
                 w1[(2 * m + 1) * kS] = tw_of(make_float2(orr[pos], oi[pos]), 2 * m + 1);
             }
         }
-        SGX_STAMP(2)    // pass-1 twiddles + image writes
-        // the pass-2 twiddles of this thread's c0 (a broadcast read per half wave), requested in front of the barrier: read one by one
-        // where they are used, each exposed its LDS latency (31 x lgkmcnt(0) per wave and transform, two waves per SIMD to hide it)
-#ifndef W_T2_STREAM
-#define W_T2_STREAM 1   // 1 (spread mode): the pass-2 twiddles of sub-block s of the FFT32 (bins q2 = s mod 4) requested one sub-block ahead of their use, eight at a time -- 16 resident at most instead of 31 (time +-0)
-#endif
+        SGX_STAMP(2)    // pass 1: arithmetic, sample requests, twiddles, image writes
+        // the pass-2 twiddles of this thread's c0 (a broadcast read per half wave): read one by one where they are used, each exposed its LDS
+        // latency (31 x lgkmcnt(0) per wave and transform).  kSpread: streamed from inside the FFT32, below; else all in front of the barrier
         float2 t2[32];
         lds_cfloat2 *tw2p = lds_ptr(tw2 + 32 * hi5);
-        if (!(kSpread && W_T2_STREAM)) {
+        if (!kSpread) {
 #pragma unroll
             for (int q2 = 1; q2 < 32; ++q2) t2[q2] = lds_read_alone(tw2p, q2);
         }
         lds_barrier();  // B1: the image is complete
         SGX_STAMP(3)
-        if (!kSpread && kPrefetchAt == 1 && more) prefetch(nxt);
 
         // ---- pass 2: thread (q1, c0): FFT32 over c1 -> q2, twiddle w_512^{q2 c0}, back into its own 32 slots
         {
@@ -402,50 +378,41 @@ __global__ void __launch_bounds__(512, 2) stft16384_w_kernel(Params p)
             }
             float2 *w2 = buf + q1 * kS + hi5;
             if constexpr (kSpread) {
-            fft32h(xr, xi, [&](auto k) {
-                constexpr int kk = decltype(k)::value;
-                if constexpr (W_T2_STREAM && (kk == 2 || kk == 8 || kk == 14 || kk == 20)) {   // the twiddles of sub-block (kk - 2) / 6: bins q2 = s + 4 j
-                    constexpr int sb = (kk - 2) / 6;
-                    __builtin_amdgcn_sched_barrier(0);
+                // call-back points of the FFT32 (4 x 4 x 2, depth first): 0 .. 7 its first stage, then per sub-block s (bins q2 = s mod 4)
+                // 8 + 6 s, 9 + 6 s (second stage) and 10 + 6 s .. 13 + 6 s (third stage: two bins final behind each)
+                fft32h(xr, xi, [&](auto k) {
+                    constexpr int kk = decltype(k)::value;
+                    if constexpr (kk == 2 || kk == 8 || kk == 14 || kk == 20) {   // the twiddles of sub-block (kk - 2) / 6, one sub-block ahead
+                        constexpr int sb = (kk - 2) / 6;
+                        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int j = 0; j < 8; ++j)
-                        if (sb + 4 * j > 0) t2[sb + 4 * j] = lds_read_alone(tw2p, sb + 4 * j);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                if constexpr ((kk & 1) == 0) {
-                    constexpr int i = kk >> 1;       // bin 2 q3 + side of the pending row
-                    __builtin_amdgcn_sched_barrier(0);
-                    store_bin(pm[2 * i], pm[2 * i + 1], pend0, pend1, (i & 1) ? voffB : (i == 14 ? voffA7 : voffA), 8192 * (i >> 1));
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }, [&](auto q2, float re, float im) {   // back into the thread's own slot the moment bin q2 is final
-                constexpr int qq = decltype(q2)::value;
-                if constexpr (W_SPREAD >= 2) w2[16 * qq] = qq == 0 ? make_float2(re, im) : cmulf(make_float2(re, im), t2[qq]);
-            });
+                        for (int j = 0; j < 8; ++j)
+                            if (sb + 4 * j > 0) t2[sb + 4 * j] = lds_read_alone(tw2p, sb + 4 * j);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if constexpr ((kk & 1) == 0) {
+                        constexpr int i = kk >> 1;       // bin 2 q3 + side of the pending row
+                        __builtin_amdgcn_sched_barrier(0);
+                        store_bin(pm[2 * i], pm[2 * i + 1], pend0, pend1, (i & 1) ? voffB : (i == 14 ? voffA7 : voffA), 8192 * (i >> 1));
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }, [&](auto q2, float re, float im) {   // back into the thread's own slot the moment bin q2 is final
+                    constexpr int qq = decltype(q2)::value;
+                    w2[16 * qq] = qq == 0 ? make_float2(re, im) : cmulf(make_float2(re, im), t2[qq]);
+                });
             } else {
-            if (W_DEFER && (kFlushAt == 1 || kFlushAt == 3)) { flush_group(0); flush_group(1); }
-            if (W_DEFER && kFlushAt == 3) { flush_group(2); flush_group(3); }
-            if (W_DEFER && kFlushAt == 5) flush_group(0);
-            fft32(xr, xi);
-            if (W_DEFER && kFlushAt == 4) { flush_group(0); flush_group(1); }
-            if (W_DEFER && (kFlushAt == 1 || kFlushAt == 4)) { flush_group(2); flush_group(3); }
-            if (W_DEFER && kFlushAt == 5) { flush_group(1); flush_group(2); }
-            }
-            SGX_STAMP(4)    // image reads + FFT32
-            if (!(kSpread && W_SPREAD >= 2)) {
+                fft32(xr, xi);
 #pragma unroll
-            for (int q2 = 0; q2 < 32; ++q2) {
-                const int pos = FFT32_OUT[q2];
-                const float2 v = make_float2(xr[pos], xi[pos]);
-                w2[16 * q2] = q2 == 0 ? v : cmulf(v, t2[q2]);
-            }
+                for (int q2 = 0; q2 < 32; ++q2) {
+                    const int pos = FFT32_OUT[q2];
+                    const float2 v = make_float2(xr[pos], xi[pos]);
+                    w2[16 * q2] = q2 == 0 ? v : cmulf(v, t2[q2]);
+                }
             }
         }
-        if (!kSpread && W_DEFER && kFlushAt == 5) flush_group(3);
-        SGX_STAMP(5)    // pass-2 twiddles + writes
+        SGX_STAMP(5)    // pass 2: image reads, FFT32, row stores, twiddles, writes in place
         lds_barrier();  // B2: every thread's slots hold pass-2 results
         SGX_STAMP(6)
-        if (!kSpread && kPrefetchAt == 2 && more) prefetch(nxt);
 
         // ---- pass 3: two FFT16 over c0: columns u_A and u_B = 1024 - u_A
         float ar[16], ai[16], br[16], bi[16];
@@ -463,23 +430,8 @@ __global__ void __launch_bounds__(512, 2) stft16384_w_kernel(Params p)
                 br[c0] = v.x; bi[c0] = v.y;
             }
         }
-        if (W_B0_AT == 0) {
-            lds_barrier();  // B0 here (A/B): pinned in front of the two FFT16, register arithmetic the compiler otherwise moves in front of the barrier
-#pragma unroll
-            for (int c0 = 0; c0 < 16; ++c0) asm volatile("" : "+v"(ar[c0]), "+v"(ai[c0]), "+v"(br[c0]), "+v"(bi[c0]));
-        }
-        SGX_STAMP(7)    // pass-3 reads
-        if (!kSpread && W_DEFER && kFlushAt == 2) { flush_group(0); flush_group(1); }
         fft16(ar, ai);
-        if (!kSpread && W_DEFER && kFlushAt == 2) { flush_group(2); flush_group(3); }
         fft16(br, bi);
-        if (W_B0_AT == 2) {
-#pragma unroll
-            for (int c0 = 0; c0 < 16; ++c0) asm volatile("" : "+v"(ar[c0]), "+v"(ai[c0]), "+v"(br[c0]), "+v"(bi[c0]));
-            lds_barrier();
-#pragma unroll
-            for (int c0 = 0; c0 < 16; ++c0) asm volatile("" : "+v"(ar[c0]), "+v"(ai[c0]), "+v"(br[c0]), "+v"(bi[c0]));
-        }
         SGX_STAMP(8)    // two FFT16
 
         // ---- split + magnitude (fft.rs:81-98): bin k = u + 1024 q3 (q3 < 8) with its partner F[P - k] = register 15 - q3 of the other column
@@ -506,18 +458,12 @@ __global__ void __launch_bounds__(512, 2) stft16384_w_kernel(Params p)
         }
         pend0 = r0;
         pend1 = r1;
-        if (!W_DEFER) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) flush_group(g);
-        }
-        SGX_STAMP(9)    // split + row stores
+        SGX_STAMP(9)    // split
         if (more) take(nxt.data_second);
         SGX_STAMP(10)   // wait for the next samples + Hann
     }
-    if (W_DEFER) {   // the last transform's row
 #pragma unroll
-        for (int g = 0; g < 4; ++g) flush_group(g);
-    }
+    for (int g = 0; g < 4; ++g) flush_group(g);   // the last transform's row
 #if SGX_STAMPS
     if ((tid & 63) == 0) {
 #pragma unroll

@@ -12,9 +12,9 @@ import torch
 from spectrogram_rs_amd import SpectrogramEngine, _lib
 
 HOPS = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
-PH = {0: "bookkeeping + pass-1 arithmetic (pretwiddle, FFT16 x2)", 1: "barrier B0 (previous pass-3 reads done)", 2: "pass-1 twiddles + 32 image writes",
-      3: "barrier B1 (image complete)", 4: "32 image reads + FFT32", 5: "pass-2 twiddles (31 broadcast reads) + 32 writes in place", 6: "barrier B2",
-      7: "2 x 16 reads + FFT16 x2", 8: "prefetch requests (16 loads)", 9: "split + 16 row stores", 10: "wait for next samples + Hann", 19: "loop control"}
+PH = {1: "job bookkeeping + barrier B0 (previous pass-3 reads done)", 2: "pass 1: pretwiddle, FFT16 x2, 16 sample requests, twiddles, 32 image writes",
+      3: "barrier B1 (image complete)", 5: "pass 2: 32 image reads, FFT32, 16 row stores, 31 twiddle reads, 32 writes in place", 6: "barrier B2",
+      8: "pass 3: 2 x 16 reads + FFT16 x2", 9: "split", 10: "wait for next samples + Hann", 19: "loop control"}
 lib = _lib.load()
 fn = lib.sgx_debug_phase_cycles16w
 fn.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
