@@ -105,7 +105,7 @@ struct sgx_ctx {
     uint32_t W = 0, P = 0, M = 0, H = 0, C = 0, pairs = 0, R = 0, sr_u32 = 0, logP = 0;
     int device = 0;
     hipStream_t stream = nullptr;
-    int stft_kernel = 0;  // 0 generic, 1 tuned 4096 wave-per-transform, 2 tuned 4096 workgroup-per-transform (scalar codelets), 3 the same with packed (re, im) arithmetic, 4 Bluestein (2W not a power of two), 5 tuned 16384, second design (four 4096-point residues), 6 mixed radix (2W = 2^a 3^b 5^c 7^d), 7 tuned 16384, first design (whole transform in LDS), 8 tuned 16384, third design (time-decimated lane quads; removed in round 6), 9 tuned 4800 (W = 2400; more than two channels: 6), 10 tuned 16384, fourth design (32 x 32 x 16, 512 threads: stft16384_w.hip)
+    int stft_kernel = 0;  // 0 generic, 1 tuned 4096 wave-per-transform, 2 tuned 4096 workgroup-per-transform (scalar codelets), 3 the same with packed (re, im) arithmetic, 4 Bluestein (2W not a power of two), 5 tuned 16384, second design (four 4096-point residues), 6 mixed radix (2W = 2^a 3^b 5^c 7^d), 7 tuned 16384, first design (whole transform in LDS), 8 tuned 16384, third design (four time-decimated 4096-point transforms per quad of lanes; removed in round 6), 9 tuned 4800 (W = 2400; more than two channels: 6), 10 tuned 16384, fourth design (32 x 32 x 16, 512 threads: stft16384_w.hip)
 
     sgx::Tables tab;
     sgx::Palette pal;

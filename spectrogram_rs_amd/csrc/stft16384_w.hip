@@ -4,7 +4,7 @@
 //
 // Replaces FastFourierTransform::process (fft.rs:43-99) + the hop loop (audio_transform.rs:34-42).
 //
-// Why.  The third design (stft16384_d.hip: 1024 threads x 16 points, four time-decimated 4096-point transforms in the lanes of a quad)
+// Why.  The third design (rounds 3-5, removed in round 6: 1024 threads x 16 points, four time-decimated 4096-point transforms in the lanes of a quad)
 // pays per transform five workgroup barriers, a two-stage DPP recombination, a partner exchange through LDS and a row staged in LDS and
 // read back: 48 LDS writes and 78 LDS reads per thread, 1024 threads.  Its vector pipe (8 550 cycles per CU and transform) and its LDS
 // pipe (9 340) take turns (15 000 - 16 000 measured: profiles/r05_k16.txt).  With 512 threads a thread may use 256 registers, enough
@@ -207,7 +207,8 @@ __global__ void __launch_bounds__(512, 2) stft16384_w_kernel(Params p)
     // Mono frame pairs (MONO: twice the requests and stores, an opt-in mode) keep them in groups: spread, that instantiation spills.
     constexpr bool kSpread = !MONO;
     // The prefetched values are consumed (Hann, fft.rs:53-63) at the END of the iteration that requested them, behind its stores, in
-    // straight-line code, and pinned there (stft16384_d.hip: consumed at the loop head the wait becomes vmcnt(0) -- every store acknowledged)
+    // straight-line code, and pinned there (consumed at the loop head, where the entry path is merged in, the compiler's wait becomes vmcnt(0):
+    // every store of the previous transform acknowledged by memory, once per transform -- 0.93 against 0.61 ms per 20 000 transforms on round 3's kernel)
     float er[16], ei[16];
     auto take = [&](bool data_second) {
 #pragma unroll
@@ -218,7 +219,10 @@ __global__ void __launch_bounds__(512, 2) stft16384_w_kernel(Params p)
 #pragma unroll
         for (int a = 0; a < 16; ++a) asm volatile("" : "+v"(er[a]), "+v"(ei[a]));
     };
-    // Job order: hop-major jobs, every XCD one contiguous eighth dealt round-robin to its workgroups (stft16384_d.hip)
+    // Job order.  Jobs are hop-major (the pairs of one hop position, then the next hop) and consecutive hop positions share 15/16 of their
+    // samples.  Workgroup i runs on XCD i % 8 (MI355X in SPX mode: kXcdHint), each XCD has its own L2: every XCD takes one contiguous eighth of
+    // the jobs and deals it round-robin to its workgroups, so that at any time the 32 CUs of an XCD work on ~8 neighbouring hop positions and a
+    // sample is fetched from the fabric once.  A LOCALITY hint only: on a part with another XCD count every job is still done exactly once.
     const unsigned long long nx = p.xcds, xcd = blockIdx.x % nx, local = blockIdx.x / nx;
     const unsigned long long job_step = gridDim.x / nx;
     const unsigned long long job_begin = xcd * p.jobs_per_xcd + local;

@@ -131,7 +131,7 @@ __global__ void __launch_bounds__(kT) __attribute__((amdgpu_waves_per_eu(4, 4)))
     // Software pipeline: the samples of transform j+1 are requested while transform j is in its last pass, BEFORE j's stores (vmcnt
     // retires in issue order: a load behind the stores waits for every one of them), and consumed (Hann, fft.rs:53-63) at the END of
     // iteration j, in straight-line code behind the stores: the compiler then waits with vmcnt(stores issued since) -- at the loop
-    // header it would merge the entry path and fall back to vmcnt(0) (stft16384_d.hip has the measurement).
+    // header it would merge the entry path and fall back to vmcnt(0) (measured on the 16384-point kernel of round 3: 0.93 ms per 20 000 transforms against 0.61 without the stores, profiles/r03_k16_ablation.txt).
     float pl[8], pr[8];
     struct JobIn { const float *base; bool data_second; };
     auto job_in = [&](unsigned long long job) {

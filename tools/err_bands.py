@@ -70,8 +70,8 @@ if __name__ == "__main__":
     run("K1 mono (frame pairs)", 2048, 256, 1, paired_frames=True)
     run("K1 mono ((s, s) transform per frame)", 2048, 256, 1, complex_mono=True)
     run("K1 stereo", 2048, 256, 2)
-    run("K16 stereo (lane quad, round 3)", 8192, 512, 2, frames=8)
-    run("K16 mono (lane quad)", 8192, 512, 1, frames=8)
+    run("K16 stereo (32 x 32 x 16, round 6)", 8192, 512, 2, frames=8)
+    run("K16 mono (duplicated plane)", 8192, 512, 1, frames=8)
     run("KM 4800", 2400, 93, 2)
     run("KB 2204 (chirp-z)", 1102, 100, 2)
     run("KB 3704 (chirp-z)", 1852, 100, 2)
