@@ -12,7 +12,11 @@
  *   - All `d_*` pointers are DEVICE pointers (hipMalloc'ed, or a torch tensor's data_ptr()).
  *     All `h_*` pointers are host pointers.  The caller owns every I/O buffer.
  *   - Work is enqueued on the context's stream (sgx_set_stream; default: the NULL stream) and is
- *     asynchronous; sgx_sync() waits for it.
+ *     asynchronous; sgx_sync() waits for it.  The batch calls (sgx_stft_batch*, sgx_render_*, sgx_magnitude_in,
+ *     sgx_image_write_columns / _read, sgx_view_write_rows / _draw, sgx_synth_white_noise, sgx_checksum_add) only enqueue;
+ *     the calls that hand host data back or free host slots (sgx_process_one, sgx_live_tick*, sgx_spectrum_levels,
+ *     sgx_checksum) and the calls that replace tables (sgx_set_gradient*, sgx_set_builtin_*) wait for the context's OWN
+ *     stream; no call waits for another context's stream (tests/test_gpu_streams.py).
  *   - Every function returns SGX_OK (0) or a negative sgx_status; the text of the last error is
  *     available from sgx_last_error().  The library never aborts the host process (the
  *     reference unwrap()s: fft.rs:24,77).
