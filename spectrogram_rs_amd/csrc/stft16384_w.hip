@@ -63,6 +63,7 @@ struct Params {
     unsigned long long first_frame, n_frames, total_frames, pair_base, n_jobs, jobs_per_xcd;
     uint32_t xcds;           // kXcdHint when the grid is a multiple of it, else 1 (plain round-robin)
     uint32_t H, pairs;
+    unsigned long long run_len;   // SLIDE: hop positions per workgroup (a contiguous run of ONE pair's transforms)
 };
 
 __device__ __forceinline__ void lds_barrier()
@@ -98,6 +99,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void *base,
     const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
     return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((unsigned long long)hi << 32) | lo), 0, (int)records, 0x00020000);
 }
+#ifndef W_SLIDE
+#define W_SLIDE 1     // A/B: 0 = every transform requests its 16 samples (the instantiation other hops run)
+#endif
 #ifndef W_OUT_AUX
 #define W_OUT_AUX 2   // nt: a write-once stream
 #endif
@@ -127,9 +131,14 @@ __global__ void __launch_bounds__(256) duplicate_mono_kernel(const float *pcm, f
 // MONO: SGX_FLAG_PAIRED_FRAMES -- frames 2j and 2j + 1 of a mono stream in the real and the imaginary part of one transform.
 // DIRECT: more than two interleaved channels, pair p = channels (2 p, 2 p + 1), read where they lie: 8-byte loads at a stride of C floats
 // (the four pairs of a hop position run on CUs of one XCD at the same time and share the lines in its L2; HBM traffic 1.02 x algorithmic).
-template <bool MONO, bool DIRECT = false>
+// SLIDE (H = 512, the thread stride of pass 1): a workgroup takes a contiguous run of hop positions of ONE pair.  Thread c holds samples
+// c + 512 a, a < 16, and the next hop position's sample a is this one's a + 1: the raw window stays in 32 registers, moves down one place
+// per transform, and ONE sample per thread is requested instead of sixteen (8-byte loads at a stride of 4 C bytes use a quarter of every
+// line they touch: without any request the kernel ran 9.6 against 10.4 ms per 400 000 transforms, profiles/r06_k16.txt).
+template <bool MONO, bool DIRECT = false, bool SLIDE = false>
 __global__ void __launch_bounds__(512, 2) stft16384_w_kernel(Params p)
 {
+    static_assert(!(MONO && SLIDE), "frame pairs of a mono stream do not slide");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float2 *buf = reinterpret_cast<float2 *>(smem_raw);
     float2 *tw2 = buf + kImg;
@@ -223,14 +232,18 @@ __global__ void __launch_bounds__(512, 2) stft16384_w_kernel(Params p)
     // samples.  Workgroup i runs on XCD i % 8 (MI355X in SPX mode: kXcdHint), each XCD has its own L2: every XCD takes one contiguous eighth of
     // the jobs and deals it round-robin to its workgroups, so that at any time the 32 CUs of an XCD work on ~8 neighbouring hop positions and a
     // sample is fetched from the fabric once.  A LOCALITY hint only: on a part with another XCD count every job is still done exactly once.
+    // SLIDE: workgroup number w (consecutive inside an XCD) takes pair w % pairs of run w / pairs -- the pairs of a run read the same
+    // lines at about the same time from the same L2; a job is a hop position of that run.
     const unsigned long long nx = p.xcds, xcd = blockIdx.x % nx, local = blockIdx.x / nx;
-    const unsigned long long job_step = gridDim.x / nx;
-    const unsigned long long job_begin = xcd * p.jobs_per_xcd + local;
-    const unsigned long long job_end = (xcd + 1) * p.jobs_per_xcd < p.n_jobs ? (xcd + 1) * p.jobs_per_xcd : p.n_jobs;
-    unsigned long long hop_c = MONO ? 0 : job_begin / p.pairs;                           // (hop, pair) of the current job
-    uint32_t pair_c = MONO ? 0 : (uint32_t)(job_begin - hop_c * p.pairs);
-    const unsigned long long step_hops = MONO ? 0 : job_step / p.pairs;                  // ... and of one step of the loop
-    const uint32_t step_pairs = MONO ? 0 : (uint32_t)(job_step - step_hops * p.pairs);
+    const unsigned long long wg = xcd * (gridDim.x / nx) + local;
+    const unsigned long long job_step = SLIDE ? 1 : gridDim.x / nx;
+    const unsigned long long job_begin = SLIDE ? (wg / p.pairs) * p.run_len : xcd * p.jobs_per_xcd + local;
+    const unsigned long long job_end = SLIDE ? (job_begin + p.run_len < p.n_frames ? job_begin + p.run_len : p.n_frames)
+                                             : ((xcd + 1) * p.jobs_per_xcd < p.n_jobs ? (xcd + 1) * p.jobs_per_xcd : p.n_jobs);
+    unsigned long long hop_c = MONO ? 0 : SLIDE ? job_begin : job_begin / p.pairs;       // (hop, pair) of the current job
+    uint32_t pair_c = MONO ? 0 : SLIDE ? (uint32_t)(wg % p.pairs) : (uint32_t)(job_begin - hop_c * p.pairs);
+    const unsigned long long step_hops = MONO ? 0 : SLIDE ? 1 : job_step / p.pairs;      // ... and of one step of the loop
+    const uint32_t step_pairs = (MONO || SLIDE) ? 0 : (uint32_t)(job_step - step_hops * p.pairs);
     if (job_begin < job_end) {
         const JobIn first = job_in(job_begin, hop_c, pair_c);
         prefetch(first);
@@ -331,14 +344,21 @@ __global__ void __launch_bounds__(512, 2) stft16384_w_kernel(Params p)
         pretwiddle16_w32(orr, oi);
         if constexpr (kSpread) {
             // (the last iteration requests its own samples again: in bounds, never used -- no branch inside the arithmetic)
+            if constexpr (SLIDE) {   // the window moves down one place: sample a of the next hop position is sample a + 1 of this one
+#pragma unroll
+                for (int a = 0; a < 15; ++a) { pl[a] = pl[a + 1]; pr[a] = pr[a + 1]; }
+            }
             fft16h(er, ei, [&](auto k) {
+                if constexpr (SLIDE && decltype(k)::value != 0) return;
                 __builtin_amdgcn_sched_barrier(0);
-                prefetch(nxt, decltype(k)::value, decltype(k)::value + 1);
+                if constexpr (SLIDE) prefetch(nxt, 15, 16);   // ... and its last one is the only request
+                else prefetch(nxt, decltype(k)::value, decltype(k)::value + 1);
                 __builtin_amdgcn_sched_barrier(0);
             }, [&](auto m, float re, float im) {   // even rows q1 = 2 m, written while the second FFT16 is still to come
                 w1[(2 * decltype(m)::value) * kS] = tw_of(make_float2(re, im), 2 * decltype(m)::value);
             });
             fft16h(orr, oi, [&](auto k) {
+                if constexpr (SLIDE) return;
                 __builtin_amdgcn_sched_barrier(0);
                 prefetch(nxt, 8 + decltype(k)::value, 9 + decltype(k)::value);
                 __builtin_amdgcn_sched_barrier(0);
@@ -542,6 +562,10 @@ hipError_t w16384_init(sgx_ctx *c, void **out)
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(stft16384_w_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
     if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(stft16384_w_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(stft16384_w_kernel<false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(stft16384_w_kernel<false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
     if (e != hipSuccess) {
         w16384_destroy(t);
         return e;
@@ -617,8 +641,20 @@ hipError_t launch_stft_w16384(const sgx_ctx *c, void *tables, const float *d_pcm
     p.xcds = (blocks % kXcdHint == 0 && p.n_jobs >= kXcdHint * blocks) ? kXcdHint : 1u;   // (short launches: plain round-robin keeps every workgroup busy)
     const unsigned long long group = mono ? 1 : pairs;                   // a hop position's pairs stay together
     p.jobs_per_xcd = ((p.n_jobs + p.xcds - 1) / p.xcds + group - 1) / group * group;
+    // H = 512 (config 4's hop): the sliding window -- runs of hop positions, one pair per workgroup
+    const bool slide = !mono && c->H == 512 && pairs <= (unsigned long long)c->n_cu && W_SLIDE;
+    if (slide) {
+        unsigned long long runs = (unsigned long long)c->n_cu / pairs;
+        if (runs > n_frames) runs = n_frames;
+        p.run_len = (n_frames + runs - 1) / runs;
+        runs = (n_frames + p.run_len - 1) / p.run_len;
+        blocks = runs * pairs;
+        p.xcds = blocks % kXcdHint == 0 ? kXcdHint : 1u;
+    }
     const dim3 grid((unsigned)blocks), block(512);
     if (mono) hipLaunchKernelGGL((stft16384_w_kernel<true>), grid, block, kLdsBytes, c->stream, p);
+    else if (slide && direct) hipLaunchKernelGGL((stft16384_w_kernel<false, true, true>), grid, block, kLdsBytes, c->stream, p);
+    else if (slide) hipLaunchKernelGGL((stft16384_w_kernel<false, false, true>), grid, block, kLdsBytes, c->stream, p);
     else if (direct) hipLaunchKernelGGL((stft16384_w_kernel<false, true>), grid, block, kLdsBytes, c->stream, p);
     else hipLaunchKernelGGL((stft16384_w_kernel<false>), grid, block, kLdsBytes, c->stream, p);
     return hipGetLastError();

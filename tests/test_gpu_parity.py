@@ -242,9 +242,33 @@ def test_config4_16384_point_kernel(torch_cuda, mags_err, ch, variant):
         # 530 hop positions = 2 120 jobs: also past the size from which the kernel hands every XCD its own eighth of the jobs
         for hops in (142, 530):
             pcm2 = oracle.white_noise((Wt + (hops - 1) * Ht) * ch, seed=77 + hops)
-            got2 = eng.stft_batch(to_dev(torch, pcm2)).cpu().numpy()
+            dev2 = to_dev(torch, pcm2)
+            got2 = eng.stft_batch(dev2).cpu().numpy()
             ref2 = oracle.stream_process(pcm2, ch, Wt, Ht, threads=8)
             assert got2.shape == ref2.shape == (hops, ch // 2, Wt - 1, 2) and mags_err(got2, ref2) <= 2.0
+        # a sub-range cuts the stream into other runs of hop positions (the sliding window starts somewhere else): the same bytes
+        assert np.array_equal(eng.stft_batch(dev2, first_frame=7, max_frames=300).cpu().numpy(), got2[7:307])
+    if variant == "tuned" and not paired and ch <= 2:
+        # hop 512 = the thread stride of the kernel's first pass: a workgroup takes a RUN of hop positions of one pair and keeps the
+        # window in registers (one new sample per thread and transform).  1 100 hop positions on 256 workgroups: runs of 5
+        hops = 1100
+        pcm2 = oracle.white_noise((Wt + (hops - 1) * Ht) * ch, seed=91 + ch)
+        dev2 = to_dev(torch, pcm2)
+        got2 = eng.stft_batch(dev2).cpu().numpy()
+        ref2 = oracle.stream_process(pcm2, ch, Wt, Ht, threads=8)
+        assert got2.shape == ref2.shape == (hops, 1, Wt - 1, 2) and mags_err(got2, ref2) <= 2.0
+        assert np.array_equal(eng.stft_batch(dev2, first_frame=3, max_frames=777).cpu().numpy(), got2[3:780])
+    if variant == "tuned" and not paired:
+        # any other hop: every transform requests its own 16 samples per thread (the instantiation without the sliding window)
+        for hop in (256, 1024, 500):
+            other = engine(window_samples=Wt, hop_samples=hop, channels=ch)
+            assert other.info.stft_kernel == 10
+            hops = 37
+            pcm3 = oracle.white_noise((Wt + (hops - 1) * hop) * ch, seed=5 + hop)
+            got3 = other.stft_batch(to_dev(torch, pcm3)).cpu().numpy()
+            ref3 = oracle.stream_process(pcm3, ch, Wt, hop, threads=8)
+            assert got3.shape == ref3.shape and mags_err(got3, ref3) <= 2.0
+            other.close()
     # the pixel path rides on it through the two-kernel route
     eng.set_builtin_gradient("viridis")
     rg = eng.render_batch(dev).cpu().numpy()
