@@ -99,9 +99,6 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void *base,
     const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
     return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((unsigned long long)hi << 32) | lo), 0, (int)records, 0x00020000);
 }
-#ifndef W_SLIDE
-#define W_SLIDE 1     // A/B: 0 = every transform requests its 16 samples (the instantiation other hops run)
-#endif
 #ifndef W_OUT_AUX
 #define W_OUT_AUX 2   // nt: a write-once stream
 #endif
@@ -642,7 +639,7 @@ hipError_t launch_stft_w16384(const sgx_ctx *c, void *tables, const float *d_pcm
     const unsigned long long group = mono ? 1 : pairs;                   // a hop position's pairs stay together
     p.jobs_per_xcd = ((p.n_jobs + p.xcds - 1) / p.xcds + group - 1) / group * group;
     // H = 512 (config 4's hop): the sliding window -- runs of hop positions, one pair per workgroup
-    const bool slide = !mono && c->H == 512 && pairs <= (unsigned long long)c->n_cu && W_SLIDE;
+    const bool slide = !mono && c->H == 512 && pairs <= (unsigned long long)c->n_cu;
     if (slide) {
         unsigned long long runs = (unsigned long long)c->n_cu / pairs;
         if (runs > n_frames) runs = n_frames;
