@@ -68,7 +68,20 @@ struct Params {
 
 __device__ __forceinline__ void lds_barrier()
 {
+#ifdef W_ABL_NOBAR
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+}
+// (ablation builds: W_ABL_NOLDSW keeps an image write's value live without the write)
+__device__ __forceinline__ void lds_put(float2 *dst, float2 v)
+{
+#ifdef W_ABL_NOLDSW
+    asm volatile("" ::"v"(v.x), "v"(v.y));
+#else
+    *dst = v;
+#endif
 }
 __device__ __forceinline__ float2 cmulf(float2 a, float2 b)
 {
@@ -84,6 +97,11 @@ __device__ __forceinline__ lds_cfloat2 *lds_ptr(const float2 *p) { return (lds_c
 __device__ __forceinline__ float2 lds_read_alone(lds_cfloat2 *&base, int idx)
 {
     if (W_NO_READ2) asm("" : "+v"(base));
+#ifdef W_ABL_NOLDSR
+    float a_ = (float)idx, b_ = 1.0f;
+    asm volatile("" : "+v"(a_), "+v"(b_) : "v"(base));
+    return make_float2(a_, b_);
+#endif
     const f2v v = base[idx];
     return make_float2(v.x, v.y);
 }
@@ -352,7 +370,7 @@ __global__ void __launch_bounds__(512, 2) stft16384_w_kernel(Params p)
                 else prefetch(nxt, decltype(k)::value, decltype(k)::value + 1);
                 __builtin_amdgcn_sched_barrier(0);
             }, [&](auto m, float re, float im) {   // even rows q1 = 2 m, written while the second FFT16 is still to come
-                w1[(2 * decltype(m)::value) * kS] = tw_of(make_float2(re, im), 2 * decltype(m)::value);
+                lds_put(&w1[(2 * decltype(m)::value) * kS], tw_of(make_float2(re, im), 2 * decltype(m)::value));
             });
             fft16h(orr, oi, [&](auto k) {
                 if constexpr (SLIDE) return;
@@ -360,7 +378,7 @@ __global__ void __launch_bounds__(512, 2) stft16384_w_kernel(Params p)
                 prefetch(nxt, 8 + decltype(k)::value, 9 + decltype(k)::value);
                 __builtin_amdgcn_sched_barrier(0);
             }, [&](auto m, float re, float im) {
-                w1[(2 * decltype(m)::value + 1) * kS] = tw_of(make_float2(re, im), 2 * decltype(m)::value + 1);
+                lds_put(&w1[(2 * decltype(m)::value + 1) * kS], tw_of(make_float2(re, im), 2 * decltype(m)::value + 1));
             });
         } else {
             flush_group(0);
@@ -419,7 +437,7 @@ __global__ void __launch_bounds__(512, 2) stft16384_w_kernel(Params p)
                     }
                 }, [&](auto q2, float re, float im) {   // back into the thread's own slot the moment bin q2 is final
                     constexpr int qq = decltype(q2)::value;
-                    w2[16 * qq] = qq == 0 ? make_float2(re, im) : cmulf(make_float2(re, im), t2[qq]);
+                    lds_put(&w2[16 * qq], qq == 0 ? make_float2(re, im) : cmulf(make_float2(re, im), t2[qq]));
                 });
             } else {
                 fft32(xr, xi);
