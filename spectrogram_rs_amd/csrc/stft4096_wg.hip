@@ -53,6 +53,9 @@ __device__ unsigned long long g_phase_cycles[20];
 #endif
 
 // PIX: kPixNone = rows (float or half pairs); else the fused pixel path with that pixel code (stft4096_wg.hpp)
+#ifndef SGX_ABL_LDS
+#define SGX_ABL_LDS 0
+#endif
 #ifndef SGX_ADDTID
 #define SGX_ADDTID 1   // (0: the (l, r) sliding kernel with the b64 transposes of every other instantiation, for A/B)
 #endif
@@ -63,6 +66,10 @@ __device__ unsigned long long g_phase_cycles[20];
 // GWS, s_sendmsg, interpolation) in a kernel that issues add-TID stores)
 __device__ __forceinline__ void addtid_rows(float2 a, float2 b, uint32_t m0_wave, int q)
 {
+#if SGX_ABL_LDS & 1   // timing only (diagnostic builds): the values live, no LDS write
+    asm volatile("" ::"v"(a.x), "v"(a.y), "v"(b.x), "v"(b.y));
+    return;
+#endif
     asm volatile("s_mov_b32 m0, %4\n\t"
                  "s_nop 0\n\t"            // one wait state between a scalar write of M0 and an add-TID LDS instruction (the compiler does not see into the statement)
                  "ds_write_addtid_b32 %0 offset:%5\n\t"
@@ -78,7 +85,12 @@ __device__ __forceinline__ void read_planes(const float4 *rd4, float (&xr)[16], 
 {
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
+#if SGX_ABL_LDS & 2   // timing only: no LDS read
+        float4 r = {1.0f, 2.0f, 3.0f, (float)c}, i = {4.0f, 3.0f, 2.0f, 1.0f};
+        asm volatile("" : "+v"(r.x), "+v"(r.y), "+v"(r.z), "+v"(r.w), "+v"(i.x), "+v"(i.y), "+v"(i.z), "+v"(i.w) : "v"(rd4));
+#else
         const float4 r = rd4[c], i = rd4[c + 1088];
+#endif
         xr[4 * c] = r.x; xr[4 * c + 1] = r.y; xr[4 * c + 2] = r.z; xr[4 * c + 3] = r.w;
         xi[4 * c] = i.x; xi[4 * c + 1] = i.y; xi[4 * c + 2] = i.z; xi[4 * c + 3] = i.w;
     }
@@ -292,13 +304,6 @@ __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
             sa[7] = ld0;
             sa[(MONO && PAIRING == kPairAdjacentRow) ? 8 : 7] = ld1;
         }
-        if (kSlide2 && pending) {
-            // (ld0 / ld1 were waited for behind the previous transform's stores, at the end of its iteration)
-#pragma unroll
-            for (int a = 0; a < 7; ++a) { sa[a] = sa[a + 1]; sb[a] = sb[a + 1]; }
-            sa[7] = ld0;
-            sb[7] = ld1;
-        }
         // ---- Hann (fft.rs:53-63) on the prefetched samples
         float er[8], ei[8];
         // local (output) frame indices; for mono f0 may be -1 (the pair's first frame precedes the range)
@@ -405,7 +410,11 @@ __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int pos = FFT16_OUT[8 + j];
+#if SGX_ABL_LDS & 1
+            asm volatile("" ::"v"(xr[pos]), "v"(xi[pos]));
+#else
             buf[j * 256 + col] = make_float2(xr[pos], xi[pos]);
+#endif
         }
         SGX_STAMP(10)   // partner writes
         lds_barrier();
@@ -420,7 +429,14 @@ __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
         float2 pb[8] = {};
         if (kInterleave) {
 #pragma unroll
-            for (int q3 = 0; q3 < 8; ++q3) pb[q3] = buf[(7 - q3) * 256 + pcol];
+            for (int q3 = 0; q3 < 8; ++q3) {
+#if SGX_ABL_LDS & 2
+                pb[q3] = make_float2((float)q3, 1.0f);
+                asm volatile("" : "+v"(pb[q3].x), "+v"(pb[q3].y) : "v"(pcol));
+#else
+                pb[q3] = buf[(7 - q3) * 256 + pcol];
+#endif
+            }
         }
 #if SGX_ABL_STORES == 1   // timing only: every row lands in the first 64 rows
         const long long f0_il = f0 & 63;
@@ -510,6 +526,15 @@ __global__ void __launch_bounds__(256, 4) stft4096_wg_kernel(Params p)
         }
         SGX_STAMP(13)   // row stores issued (fused pixel path: the pixel passes)
         if (!RENDER && !(MONO && PAIRING == kPairAdjacentRow && kSlideWindow)) next_samples_are_here();   // rows: behind the stores, vmcnt(stores issued since)
+        if (kSlide2) {
+            // the (l, r) window moves down one row HERE, in every iteration (behind the last transform nothing was requested and nothing reads
+            // the window again): at the loop head, under `pending`, the compiler copied the window out at the back edge and in again on
+            // either side of the branch -- 30 moves per transform for 14
+#pragma unroll
+            for (int a = 0; a < 7; ++a) { sa[a] = sa[a + 1]; sb[a] = sb[a + 1]; }
+            sa[7] = ld0;
+            sb[7] = ld1;
+        }
     }
 #if SGX_STAMPS
     if ((tid & 63) == 0) {

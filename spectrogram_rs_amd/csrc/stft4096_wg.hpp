@@ -107,6 +107,11 @@ __device__ __forceinline__ float2 lds_read_alone(lds_cfloat2 *&base, int idx)
 #if SGX_NO_READ2
     asm("" : "+v"(base));
 #endif
+#if defined(SGX_ABL_LDS) && (SGX_ABL_LDS & 2)   // timing only (diagnostic builds): no LDS read
+    float a_ = (float)idx, b_ = 1.0f;
+    asm volatile("" : "+v"(a_), "+v"(b_) : "v"(base));
+    return make_float2(a_, b_);
+#endif
     const lds_f2v v = base[idx];
     return make_float2(v.x, v.y);
 }
