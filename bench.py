@@ -74,8 +74,8 @@ KERNEL_NAMES = {
     "real": ("stft4096 real-input: every mono frame its own transform, a 2048-point complex transform of the real frame + one butterfly per bin "
              "(256 threads x 2 frames x 8 points, radix 8 x 16 x 16, sliding half-row window)", "sgx::wgr::stft4096_real_kernel<0, 0, true>"),
     6: ("mixed radix at the window's own length (compile-time plan)", "sgx::mix::stft_mixed_fixed_kernel"),
-    10: ("stft16384 as 32 x 32 x 16 in one 512-thread workgroup (32 points per thread, two LDS exchanges, three barriers)",
-         "sgx::w16k::stft16384_w_kernel<false, true>"),   # (more than two channels: the pairs read where they lie)
+    10: ("stft16384 as 32 x 32 x 16 in one 512-thread workgroup (32 points per thread, two LDS exchanges, three barriers; hop 512: the window slides in registers)",
+         "sgx::w16k::stft16384_w_kernel<false, true, true>"),   # (more than two channels: the pairs read where they lie; hop 512: runs of hop positions per workgroup)
     9: ("stft4800 workgroup-per-transform (320 threads, 16 x 20 x 15, resident twiddles, mono frame pairs)", "sgx::w48::stft4800_wg_kernel<0, false>"),
 }
 

@@ -68,7 +68,7 @@ t2 = traffic("stft4096_real_kernel<0, 0, true>", F, 17400)
 t3 = traffic("stft4096_real_kernel<2, 2, true>", F, 5120)
 t2p = traffic("stft4096_wg_kernel<true, 0, false, 0>", F, 17400)     # the paired leg (SGX_FLAG_PAIRED_FRAMES), if the pass ran it
 hops = 20_000      # (tools/pmc_bench.sh runs the config-4 leg at 20 000 hop positions: a counter pass serialises every dispatch)
-t4a = traffic("stft16384_w_kernel<false, true>", hops, 278496)      # the pairs read where they lie, ONE kernel
+t4a = traffic("stft16384_w_kernel<false, true, true>", hops, 278496)      # the pairs read where they lie, the window sliding in registers (hop 512), ONE kernel
 out["config2_stft"] = t2
 out["config2_stft_paired_frames"] = t2p
 out["config3_fused_pixel"] = t3
@@ -86,8 +86,9 @@ if t4a:
     out["note_config4"] = (
         "config 4: FETCH_SIZE / WRITE_SIZE count requests between L2 and the fabric, Infinity-Cache hits included. Per hop position the "
         f"transform kernel (csrc/stft16384_w.hip) writes {write_kb:.0f} KB (262 KB of algorithmic output: 8-byte row stores at an 8-byte row phase, a wave's 512-byte run "
-        f"shares its first and last line with its neighbours') and fetches {fetch_kb:.0f} KB: the interleaved stream itself (the pairs are read where they lie), "
-        "every sample wanted by 16 overlapping hop positions and four pairs, served mostly by L2 (16 KB algorithmic).")
+        f"shares its first and last line with its neighbours') and fetches {fetch_kb:.0f} KB: the interleaved stream itself (the pairs are read where they lie; "
+        "at hop 512 the window slides in registers, a thread requests ONE new sample per transform: every line is wanted by the four pairs of a run of hop positions, "
+        "which work on CUs of one XCD at about the same time; 16 KB algorithmic).")
 json.dump(out, open(os.path.join(root, "profiles", f"{rnd}_hbm_traffic.json"), "w"), indent=1)
 
 # ---- pipes of the fused pixel kernel -------------------------------------------------------------------------------
