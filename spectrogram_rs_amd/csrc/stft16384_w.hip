@@ -308,6 +308,54 @@ __global__ void __launch_bounds__(512, 2) stft16384_w_kernel(Params p)
         for (int i = 4 * g; i < 4 * g + 4; ++i) store_bin(pm[2 * i], pm[2 * i + 1], pend0, pend1, (i & 1) ? voffB : (i == 14 ? voffA7 : voffA), 8192 * (i >> 1));
         __builtin_amdgcn_sched_barrier(0);   // (the groups stay where they are put)
     };
+    // ---- pass 3 in two halves: its 32 reads (p3_read) and its arithmetic (p3_finish: two FFT16 over c0 for the columns u_A and u_B = 1024 - u_A,
+    // then the split).  kDefer3 (every stream but mono frame pairs): the arithmetic of transform t - 1 runs in iteration t, BEHIND the requests
+    // for pass 2's 32 words -- right behind barrier B1 all eight waves ask for their words at once, the LDS delivers them over ~1 000 clocks and
+    // nothing else was there to issue; pass 3's words (64 registers) wait through pass 1 instead of the finished row (32).
+    constexpr bool kDefer3 = kSpread;
+    float ar[16], ai[16], br[16], bi[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) ar[i] = ai[i] = br[i] = bi[i] = 0.0f;
+    __amdgpu_buffer_rsrc_t row0 = uniform_rsrc(p.mags, 0u), row1 = uniform_rsrc(p.mags, 0u);   // the rows of the transform whose pass-3 words are in ar .. bi
+    auto p3_read = [&]() {
+        lds_cfloat2 *rA = lds_ptr(buf + q1 * kS + 16 * hi5);
+        lds_cfloat2 *rB = lds_ptr(buf + q1B * kS + 16 * q2B);
+#pragma unroll
+        for (int c0 = 0; c0 < 16; ++c0) {
+            const float2 v = lds_read_alone(rA, c0);
+            ar[c0] = v.x; ai[c0] = v.y;
+        }
+#pragma unroll
+        for (int c0 = 0; c0 < 16; ++c0) {
+            const float2 v = lds_read_alone(rB, c0);
+            br[c0] = v.x; bi[c0] = v.y;
+        }
+    };
+    auto p3_finish = [&]() {
+        fft16(ar, ai);
+        fft16(br, bi);
+        // ---- split + magnitude (fft.rs:81-98): bin k = u + 1024 q3 (q3 < 8) with its partner F[P - k] = register 15 - q3 of the other column
+        auto split = [&](float xr_, float xi_, float yr_, float yi_, float &ml, float &mr) {
+            const float sr_ = xr_ + yr_, si_ = xi_ - yi_;   // a + conj(b) = 2 L^
+            const float dr_ = xr_ - yr_, di_ = xi_ + yi_;   // a - conj(b) = 2i R^
+            ml = __builtin_amdgcn_sqrtf(fmaf(sr_, sr_, si_ * si_));  // the scale 1 / W rides on the window
+            mr = __builtin_amdgcn_sqrtf(fmaf(dr_, dr_, di_ * di_));
+        };
+        // Thread 0 holds the two self-paired columns: u = 0 (k = 1024 q3 pairs with 1024 (16 - q3), register 16 - q3 of its OWN column; k = 0,
+        // DC, is not an output: fft.rs:81) and u = 512 (k = 512 + 1024 q3 pairs with 512 + 1024 (15 - q3), own column again).  Selects on
+        // the split's inputs instead of a branch of its own: a divergent branch (250 instructions, 15 stores, one lane) made wave 0 the
+        // last at every barrier.  Its u = 0 bins ride one store instruction early (bin q3 + 1 in the slot of q3, lane offset 8184 =
+        // 8192 - 8: a lane offset of -8 would be dropped, profiles/r05_bufrange.txt); instruction 7 drops its lane.
+        const bool z = tid == 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int pa = FFT16_OUT[j], pa1 = FFT16_OUT[j < 7 ? j + 1 : j], pb = FFT16_OUT[15 - j];
+            split(z ? ar[pa1] : ar[pa], z ? ai[pa1] : ai[pa], z ? ar[pb] : br[pb], z ? ai[pb] : bi[pb], pm[4 * j], pm[4 * j + 1]);   // k = u_A + 1024 j, partner (1024 - u_A) + 1024 (15 - j)
+            split(br[pa], bi[pa], z ? br[pb] : ar[pb], z ? bi[pb] : ai[pb], pm[4 * j + 2], pm[4 * j + 3]);                           // k = u_B + 1024 j, partner u_A + 1024 (15 - j)
+        }
+        pend0 = row0;
+        pend1 = row1;
+    };
 #if SGX_STAMPS
     unsigned long long st_acc[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long st_last = __builtin_readcyclecounter(), st_iters = 0;
@@ -341,9 +389,9 @@ __global__ void __launch_bounds__(512, 2) stft16384_w_kernel(Params p)
         // this transform's stores (vmcnt retires in issue order) and with ~14 000 cycles to arrive
         if (!kSpread && more) prefetch(nxt);
 
-        lds_barrier();  // B0: every wave's pass-3 reads of the previous transform are complete -- the image may be written again.  (Here, at
-                        // the top of the next iteration, the skew of a whole stretch of arithmetic has been absorbed and the pass-3 reads
-                        // overlapped the two FFT16: right behind those reads the same barrier cost 2 - 4 %.)
+        lds_barrier();  // B0: every wave's pass-3 reads of the previous transform are complete -- the image may be written again.  (At the
+                        // top of the iteration; kDefer3: the reads were the last thing of the previous one.  Moved into pass 1, in front of
+                        // its first image write, so that the pre-twiddle and the first FFT16 stage run while the words arrive: +-0.)
         SGX_STAMP(1)
         // ---- pass 1: 32-point DFT over a, inputs a >= 16 are the zero padding: even q1 = FFT16(z), odd q1 = FFT16(z * w_32^a)
         float orr[16], oi[16];
@@ -404,6 +452,13 @@ __global__ void __launch_bounds__(512, 2) stft16384_w_kernel(Params p)
             for (int q2 = 1; q2 < 32; ++q2) t2[q2] = lds_read_alone(tw2p, q2);
         }
         lds_barrier();  // B1: the image is complete
+        if constexpr (kDefer3) {
+            // (the previous transform's pass-3 words ARE there -- B0 and B1 waited with lgkmcnt(0) -- but the compiler does not read the
+            // statement: told here, it puts its own wait in front of pass 2's requests, where it costs nothing; left alone it waited at the
+            // first use, behind them, with lgkmcnt(14): for 18 of the 32 words just requested)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) asm volatile("" ::"v"(ar[i]), "v"(ai[i]), "v"(br[i]), "v"(bi[i]));
+        }
         SGX_STAMP(3)
 
         // ---- pass 2: thread (q1, c0): FFT32 over c1 -> q2, twiddle w_512^{q2 c0}, back into its own 32 slots
@@ -416,6 +471,11 @@ __global__ void __launch_bounds__(512, 2) stft16384_w_kernel(Params p)
                 xr[c1] = v.x; xi[c1] = v.y;
             }
             float2 *w2 = buf + q1 * kS + hi5;
+            if constexpr (kDefer3) {
+                __builtin_amdgcn_sched_barrier(0);
+                p3_finish();   // the previous transform's (the first iteration: zeros, and a row descriptor of zero records)
+                __builtin_amdgcn_sched_barrier(0);
+            }
             if constexpr (kSpread) {
                 // call-back points of the FFT32 (4 x 4 x 2, depth first): 0 .. 7 its first stage, then per sub-block s (bins q2 = s mod 4)
                 // 8 + 6 s, 9 + 6 s (second stage) and 10 + 6 s .. 13 + 6 s (third stage: two bins final behind each)
@@ -453,53 +513,18 @@ __global__ void __launch_bounds__(512, 2) stft16384_w_kernel(Params p)
         lds_barrier();  // B2: every thread's slots hold pass-2 results
         SGX_STAMP(6)
 
-        // ---- pass 3: two FFT16 over c0: columns u_A and u_B = 1024 - u_A
-        float ar[16], ai[16], br[16], bi[16];
-        {
-            lds_cfloat2 *rA = lds_ptr(buf + q1 * kS + 16 * hi5);
-            lds_cfloat2 *rB = lds_ptr(buf + q1B * kS + 16 * q2B);
-#pragma unroll
-            for (int c0 = 0; c0 < 16; ++c0) {
-                const float2 v = lds_read_alone(rA, c0);
-                ar[c0] = v.x; ai[c0] = v.y;
-            }
-#pragma unroll
-            for (int c0 = 0; c0 < 16; ++c0) {
-                const float2 v = lds_read_alone(rB, c0);
-                br[c0] = v.x; bi[c0] = v.y;
-            }
-        }
-        fft16(ar, ai);
-        fft16(br, bi);
-        SGX_STAMP(8)    // two FFT16
-
-        // ---- split + magnitude (fft.rs:81-98): bin k = u + 1024 q3 (q3 < 8) with its partner F[P - k] = register 15 - q3 of the other column
-        const __amdgpu_buffer_rsrc_t r0 = uniform_rsrc(p.mags + (((size_t)(have_first ? f0 : 0) * p.pairs + pair) * (size_t)kM) * 2,
-                                                       (MONO && !have_first) ? 0u : 0x7fffffffu);
-        const __amdgpu_buffer_rsrc_t r1 = uniform_rsrc(p.mags + (((size_t)f1 * p.pairs + pair) * (size_t)kM) * 2, (MONO && !have_second) ? 0u : 0x7fffffffu);
-        auto split = [&](float xr_, float xi_, float yr_, float yi_, float &ml, float &mr) {
-            const float sr_ = xr_ + yr_, si_ = xi_ - yi_;   // a + conj(b) = 2 L^
-            const float dr_ = xr_ - yr_, di_ = xi_ + yi_;   // a - conj(b) = 2i R^
-            ml = __builtin_amdgcn_sqrtf(fmaf(sr_, sr_, si_ * si_));  // the scale 1 / W rides on the window
-            mr = __builtin_amdgcn_sqrtf(fmaf(dr_, dr_, di_ * di_));
-        };
-        // Thread 0 holds the two self-paired columns: u = 0 (k = 1024 q3 pairs with 1024 (16 - q3), register 16 - q3 of its OWN column; k = 0,
-        // DC, is not an output: fft.rs:81) and u = 512 (k = 512 + 1024 q3 pairs with 512 + 1024 (15 - q3), own column again).  Selects on
-        // the split's inputs instead of a branch of its own: a divergent branch (250 instructions, 15 stores, one lane) made wave 0 the
-        // last at every barrier.  Its u = 0 bins ride one store instruction early (bin q3 + 1 in the slot of q3, lane offset 8184 =
-        // 8192 - 8: a lane offset of -8 would be dropped, profiles/r05_bufrange.txt); instruction 7 drops its lane.
-        const bool z = tid == 0;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int pa = FFT16_OUT[j], pa1 = FFT16_OUT[j < 7 ? j + 1 : j], pb = FFT16_OUT[15 - j];
-            split(z ? ar[pa1] : ar[pa], z ? ai[pa1] : ai[pa], z ? ar[pb] : br[pb], z ? ai[pb] : bi[pb], pm[4 * j], pm[4 * j + 1]);   // k = u_A + 1024 j, partner (1024 - u_A) + 1024 (15 - j)
-            split(br[pa], bi[pa], z ? br[pb] : ar[pb], z ? bi[pb] : ai[pb], pm[4 * j + 2], pm[4 * j + 3]);                           // k = u_B + 1024 j, partner u_A + 1024 (15 - j)
-        }
-        pend0 = r0;
-        pend1 = r1;
+        // ---- pass 3 (the lambdas in front of the loop): this transform's words; kDefer3: their arithmetic in the next iteration
+        row0 = uniform_rsrc(p.mags + (((size_t)(have_first ? f0 : 0) * p.pairs + pair) * (size_t)kM) * 2, (MONO && !have_first) ? 0u : 0x7fffffffu);
+        row1 = uniform_rsrc(p.mags + (((size_t)f1 * p.pairs + pair) * (size_t)kM) * 2, (MONO && !have_second) ? 0u : 0x7fffffffu);
+        p3_read();
+        if constexpr (!kDefer3) p3_finish();
+        SGX_STAMP(8)    // pass 3
         SGX_STAMP(9)    // split
         if (more) take(nxt.data_second);
         SGX_STAMP(10)   // wait for the next samples + Hann
+    }
+    if constexpr (kDefer3) {
+        if (job_begin < job_end) p3_finish();       // the last transform's pass 3
     }
 #pragma unroll
     for (int g = 0; g < 4; ++g) flush_group(g);   // the last transform's row
