@@ -166,100 +166,6 @@ def gen_pretwiddle(name, n, N):
     return "\n".join(src), e.ops
 
 
-class CEmitter:
-    """complex (re, im)-pair codelets: every complex add is one v_pk_add_f32, every twiddle two packed ops"""
-
-    def __init__(self):
-        self.lines = []
-        self.n = 0
-        self.ops = 0
-
-    def emit(self, expr):
-        self.n += 1
-        v = "c%d" % self.n
-        self.lines.append("    const f2v %s = %s;" % (v, expr))
-        self.ops += 1
-        return v
-
-
-def ctwiddle(e, z, idx, N):
-    idx %= N
-    if idx == 0:
-        return z
-    if 4 * idx == N:
-        return e.emit("cx_mul_mi(%s)" % z)      # rare (only outside butterflies); a swap + sign
-    if 2 * idx == N:
-        return e.emit("(-%s)" % z)
-    if 4 * idx == 3 * N:
-        return e.emit("cx_mul_pi(%s)" % z)
-    ang = -2.0 * math.pi * idx / N
-    e.ops += 1  # two packed ops
-    return e.emit("cx_mul_k(%s, %s, %s)" % (z, lit(math.cos(ang)), lit(math.sin(ang))))
-
-
-def cdif(e, vals, N, radices, out_pos, base_k=0, k_stride=1, positions=None):
-    if positions is None:
-        positions = list(range(N))
-    if N == 1:
-        out_pos[base_k] = positions[0]
-        return
-    R = radices[0]
-    L = N // R
-    for j in range(L):
-        p = [positions[j + L * q] for q in range(R)]
-        x = [vals[q] for q in p]
-        if R == 2:
-            ys = [e.emit("%s + %s" % (x[0], x[1])), ctwiddle(e, e.emit("%s - %s" % (x[0], x[1])), j, N)]
-        elif R == 4:
-            s02 = e.emit("%s + %s" % (x[0], x[2]))
-            d02 = e.emit("%s - %s" % (x[0], x[2]))
-            s13 = e.emit("%s + %s" % (x[1], x[3]))
-            d13 = e.emit("%s - %s" % (x[1], x[3]))
-            y0 = e.emit("%s + %s" % (s02, s13))
-            y2 = e.emit("%s - %s" % (s02, s13))
-            y1 = e.emit("cx_add_mi(%s, %s)" % (d02, d13))   # d02 - i d13, one packed add with op_sel/neg
-            y3 = e.emit("cx_add_pi(%s, %s)" % (d02, d13))   # d02 + i d13
-            ys = [y0, ctwiddle(e, y1, j, N), ctwiddle(e, y2, 2 * j, N), ctwiddle(e, y3, 3 * j, N)]
-        else:
-            raise ValueError(R)
-        for q in range(R):
-            vals[p[q]] = ys[q]
-    for q in range(R):
-        cdif(e, vals, L, radices[1:], out_pos, base_k + k_stride * q, k_stride * R, positions[q * L:(q + 1) * L])
-
-
-def gen_cfft(name, N, radices):
-    e = CEmitter()
-    vals = {p: "x[%d]" % p for p in range(N)}
-    out_pos = {}
-    cdif(e, vals, N, radices, out_pos)
-    body = list(e.lines)
-    for p in range(N):
-        body.append("    x[%d] = %s;" % (p, vals[p]))
-    src = ["// %d-point forward DFT on (re, im) pairs, DIF radices %s: %d packed VALU operations" % (N, radices, e.ops),
-           "__device__ __forceinline__ void %s(f2v (&x)[%d])\n{" % (name, N)]
-    src += body
-    src.append("}")
-    return "\n".join(src), e.ops
-
-
-def gen_cpretwiddle(name, n, N):
-    e = CEmitter()
-    body = []
-    outs = []
-    for a in range(n):
-        outs.append(ctwiddle(e, "x[%d]" % a, a, N))
-    body = list(e.lines)
-    for a, z in enumerate(outs):
-        if z != "x[%d]" % a:
-            body.append("    x[%d] = %s;" % (a, z))
-    src = ["// element a *= w_%d^a, a < %d, on (re, im) pairs: %d packed VALU operations" % (N, n, e.ops),
-           "__device__ __forceinline__ void %s(f2v (&x)[%d])\n{" % (name, n)]
-    src += body
-    src.append("}")
-    return "\n".join(src), e.ops
-
-
 def reference_check():
     """numerically execute the generated algorithm in float64 to validate structure + permutation"""
     rng = np.random.default_rng(0)
@@ -308,20 +214,6 @@ def main():
         src, ops, _ = gen_fft(name, N, radices, hooked=True)
         parts.append(src + "\n")
         total[name] = ops
-    cparts = ["// GENERATED by tools/gen_fft_codelets.py -- do not edit.\n"
-              "// In-register forward-DFT codelets on (re, im) pairs: f2v is a 2-wide float vector held in an\n"
-              "// aligned VGPR pair, so a complex add is ONE v_pk_add_f32 and a twiddle multiply two packed ops.\n"
-              "// The including file defines cx_add_mi / cx_add_pi (a -+ i b in one packed add with op_sel/neg),\n"
-              "// cx_mul_k (multiply by a literal twiddle), cx_mul_mi / cx_mul_pi.\n"]
-    for name, N, radices in (("fft8c", 8, [4, 2]), ("fft16c", 16, [4, 4])):
-        src, ops = gen_cfft(name, N, radices)
-        cparts.append(src + "\n")
-        total[name] = ops
-    src, ops = gen_cpretwiddle("pretwiddle8c_w16", 8, 16)
-    cparts.append(src + "\n")
-    total["pretwiddle8c_w16"] = ops
-    with open(os.path.join(ROOT, "spectrogram_rs_amd", "csrc", "fft_codelets_cx.inc"), "w") as f:
-        f.write("\n".join(cparts))
     path = os.path.join(ROOT, "spectrogram_rs_amd", "csrc", "fft_codelets.inc")
     with open(path, "w") as f:
         f.write("\n".join(parts))
