@@ -258,6 +258,17 @@ def test_config4_16384_point_kernel(torch_cuda, mags_err, ch, variant):
         ref2 = oracle.stream_process(pcm2, ch, Wt, Ht, threads=8)
         assert got2.shape == ref2.shape == (hops, 1, Wt - 1, 2) and mags_err(got2, ref2) <= 2.0
         assert np.array_equal(eng.stft_batch(dev2, first_frame=3, max_frames=777).cpu().numpy(), got2[3:780])
+    if variant == "tuned" and not paired and ch in (8, 2):
+        # the sliding window against the instantiation that requests every sample: hop position t at hop 512 IS hop position 2 t at hop 256 --
+        # the same arithmetic in the same order, so the same bytes (3 001 hop positions: runs of 47 / 12 transforms per workgroup)
+        hops = 3001
+        dev4 = to_dev(torch, oracle.white_noise((Wt + (hops - 1) * Ht) * ch, seed=123 + ch))
+        slid = eng.stft_batch(dev4)
+        half = engine(window_samples=Wt, hop_samples=Ht // 2, channels=ch)
+        every = half.stft_batch(dev4)
+        assert every.shape[0] == 2 * hops - 1 and torch.equal(slid, every[::2])
+        half.close()
+        del slid, every, dev4
     if variant == "tuned" and not paired:
         # any other hop: every transform requests its own 16 samples per thread (the instantiation without the sliding window)
         for hop in (256, 1024, 500):
