@@ -30,6 +30,9 @@ __global__ void run(unsigned long long *cycles, float *sink, int trips)
                 if (OP == 1) asm volatile("v_add_f32 %0, %1, %0" : "+v"(acc[i].x) : "v"(x.x));
                 if (OP == 2) asm volatile("v_pk_add_f32 %0, %1, %0" : "+v"(acc[i]) : "v"(x));
                 if (OP == 3) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(x), "v"(y));
+                if (OP == 4) asm volatile("v_mul_f32 %0, 0x3f3504f3, %0" : "+v"(acc[i].x));                  // a 32-bit literal: an 8-byte instruction
+                if (OP == 5) asm volatile("v_fmac_f32 %0, 0x3f3504f3, %1" : "+v"(acc[i].x) : "v"(x.x));
+                if (OP == 6) asm volatile("v_sqrt_f32 %0, %0" : "+v"(acc[i].x));
             }
     }
     asm volatile("s_nop 0" ::: "memory");
@@ -39,6 +42,60 @@ __global__ void run(unsigned long long *cycles, float *sink, int trips)
     for (int i = 0; i < NACC; ++i) s += acc[i].x + acc[i].y;
     if (s == 12345.678f) sink[0] = s;
     if ((threadIdx.x & 63) == 0) cycles[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = t1 - t0;
+}
+
+// Register-file banks (register number mod 4).  16 independent destinations v16 .. v31 per group, the same source registers in every instruction.
+#define BANK_CASE(NAME, INSTR)                                                                                                                      \
+    __global__ void NAME(unsigned long long *cycles, float *sink, int trips)                                                                        \
+    {                                                                                                                                               \
+        asm volatile("v_mov_b32 v40, 1.0\n\tv_mov_b32 v41, 1.0\n\tv_mov_b32 v42, 1.0\n\tv_mov_b32 v43, 1.0\n\tv_mov_b32 v44, 1.0\n\tv_mov_b32 v48, 1.0" ::         \
+                         : "v40", "v41", "v42", "v43", "v44", "v48");                                                                               \
+        __syncthreads();                                                                                                                            \
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();                                                                                 \
+        for (int it = 0; it < trips; ++it) {                                                                                                        \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r)                                                                                          \
+                asm volatile(INSTR(16) INSTR(17) INSTR(18) INSTR(19) INSTR(20) INSTR(21) INSTR(22) INSTR(23) INSTR(24) INSTR(25) INSTR(26) INSTR(27) \
+                                 INSTR(28) INSTR(29) INSTR(30) INSTR(31) ::                                                                          \
+                                 : "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31");  \
+        }                                                                                                                                           \
+        asm volatile("s_nop 0" ::: "memory");                                                                                                       \
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime();                                                                                 \
+        if (t1 == 1) sink[0] = 1.0f;                                                                                                                \
+        if ((threadIdx.x & 63) == 0) cycles[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = t1 - t0;                                           \
+    }
+#define I_FMA_3BANKS(d) "v_fma_f32 v" #d ", v40, v41, v42\n\t"
+#define I_FMA_1BANK(d) "v_fma_f32 v" #d ", v40, v44, v48\n\t"
+#define I_FMA_2OF3(d) "v_fma_f32 v" #d ", v40, v44, v41\n\t"
+#define I_ADD_2BANKS(d) "v_add_f32 v" #d ", v40, v41\n\t"
+#define I_ADD_1BANK(d) "v_add_f32 v" #d ", v40, v44\n\t"
+#define I_ADD_SAMEREG(d) "v_add_f32 v" #d ", v40, v40\n\t"
+#define I_FMAC_2BANKS(d) "v_fmac_f32 v" #d ", v41, v42\n\t"
+#define I_FMAC_1BANK(d) "v_fmac_f32 v" #d ", v40, v44\n\t"
+#define I_MULK_1(d) "v_mul_f32 v" #d ", 0x3f3504f3, v40\n\t"
+BANK_CASE(k_fma_3banks, I_FMA_3BANKS)
+BANK_CASE(k_fma_1bank, I_FMA_1BANK)
+BANK_CASE(k_fma_2of3, I_FMA_2OF3)
+BANK_CASE(k_add_2banks, I_ADD_2BANKS)
+BANK_CASE(k_add_1bank, I_ADD_1BANK)
+BANK_CASE(k_add_samereg, I_ADD_SAMEREG)
+BANK_CASE(k_fmac_2banks, I_FMAC_2BANKS)
+BANK_CASE(k_fmac_1bank, I_FMAC_1BANK)
+BANK_CASE(k_mulk, I_MULK_1)
+
+void banks(const char *what, void (*kern)(unsigned long long *, float *, int), int n_cu, unsigned long long *d_cyc, float *d_sink)
+{
+    const int trips = 2000;
+    for (int wps : {1, 2, 4}) {
+        const int threads = 256 * wps;
+        hipLaunchKernelGGL(kern, dim3(n_cu), dim3(threads), 0, 0, d_cyc, d_sink, trips);
+        CK(hipDeviceSynchronize());
+        std::vector<unsigned long long> h(n_cu * (threads / 64));
+        CK(hipMemcpy(h.data(), d_cyc, h.size() * 8, hipMemcpyDeviceToHost));
+        double sum = 0;
+        for (auto v : h) sum += (double)v;
+        const double clk = sum / h.size() / ((double)trips * 256);
+        printf("%-72s waves/SIMD %d: %.2f clocks per instruction and wave = one per %.2f clocks per SIMD\n", what, wps, clk, clk / wps);
+    }
 }
 
 template <int OP, int NACC>
@@ -81,5 +138,17 @@ int main()
     one<2, 16>("v_pk_add_f32", n, d_cyc, d_sink, tick_per_clk);
     one<2, 2>("v_pk_add_f32", n, d_cyc, d_sink, tick_per_clk);
     one<3, 16>("v_pk_fma_f32", n, d_cyc, d_sink, tick_per_clk);
+    one<4, 16>("v_mul literal", n, d_cyc, d_sink, tick_per_clk);
+    one<5, 16>("v_fmac literal", n, d_cyc, d_sink, tick_per_clk);
+    one<6, 16>("v_sqrt_f32", n, d_cyc, d_sink, tick_per_clk);
+    banks("v_fma_f32 d, v40, v41, v42   (three banks)", k_fma_3banks, n, d_cyc, d_sink);
+    banks("v_fma_f32 d, v40, v44, v41   (two sources of one bank)", k_fma_2of3, n, d_cyc, d_sink);
+    banks("v_fma_f32 d, v40, v44, v48   (three sources of one bank)", k_fma_1bank, n, d_cyc, d_sink);
+    banks("v_add_f32 d, v40, v41        (two banks)", k_add_2banks, n, d_cyc, d_sink);
+    banks("v_add_f32 d, v40, v44        (one bank)", k_add_1bank, n, d_cyc, d_sink);
+    banks("v_add_f32 d, v40, v40        (the same register twice)", k_add_samereg, n, d_cyc, d_sink);
+    banks("v_fmac_f32 d, v41, v42       (d = v16 .. v31: every bank in turn)", k_fmac_2banks, n, d_cyc, d_sink);
+    banks("v_fmac_f32 d, v40, v44       (sources of one bank)", k_fmac_1bank, n, d_cyc, d_sink);
+    banks("v_mul_f32 d, literal, v40", k_mulk, n, d_cyc, d_sink);
     return 0;
 }
