@@ -98,6 +98,53 @@ void banks(const char *what, void (*kern)(unsigned long long *, float *, int), i
     }
 }
 
+// the same run with a LONG straight-line loop body (BODY instructions per trip: 8-byte v_fma_f32 or 4-byte v_add_f32 encodings): does a wave's
+// instruction fetch keep up when eight waves of a CU walk through tens of kilobytes of code per trip?
+template <int OP, int BODY>
+__global__ void run_long(unsigned long long *cycles, float *sink, int trips)
+{
+    f2 acc[16];
+    f2 x = {1.0001f + threadIdx.x * 1e-7f, 0.9999f}, y = {1e-3f, 2e-3f};
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = f2{(float)i, (float)(i + 1)};
+    __syncthreads();
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < trips; ++it) {
+#pragma unroll
+        for (int r = 0; r < BODY / 16; ++r)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                if (OP == 0) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(acc[i].x) : "v"(x.x), "v"(y.x));
+                if (OP == 1) asm volatile("v_add_f32 %0, %1, %0" : "+v"(acc[i].x) : "v"(x.x));
+            }
+    }
+    asm volatile("s_nop 0" ::: "memory");
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float s = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += acc[i].x + acc[i].y;
+    if (s == 12345.678f) sink[0] = s;
+    if ((threadIdx.x & 63) == 0) cycles[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = t1 - t0;
+}
+
+template <int OP, int BODY>
+void long_body(const char *name, int n_cu, unsigned long long *d_cyc, float *d_sink)
+{
+    const int trips = 512 * 1024 / BODY;
+    for (int wps : {1, 2, 4}) {
+        const int threads = 256 * wps;
+        hipLaunchKernelGGL((run_long<OP, BODY>), dim3(n_cu), dim3(threads), 0, 0, d_cyc, d_sink, trips);
+        CK(hipDeviceSynchronize());
+        std::vector<unsigned long long> h(n_cu * (threads / 64));
+        CK(hipMemcpy(h.data(), d_cyc, h.size() * 8, hipMemcpyDeviceToHost));
+        double sum = 0;
+        for (auto v : h) sum += (double)v;
+        const double clk = sum / h.size() / ((double)trips * BODY);
+        printf("%-12s loop body %5d instructions (%3d KB)  waves/SIMD %d: %.2f clocks per instruction and wave = one per %.2f clocks per SIMD\n", name, BODY,
+               BODY * (OP == 0 ? 8 : 4) / 1024, wps, clk, clk / wps);
+    }
+}
+
 template <int OP, int NACC>
 void one(const char *name, int n_cu, unsigned long long *d_cyc, float *d_sink, double tick_per_clk)
 {
@@ -141,6 +188,12 @@ int main()
     one<4, 16>("v_mul literal", n, d_cyc, d_sink, tick_per_clk);
     one<5, 16>("v_fmac literal", n, d_cyc, d_sink, tick_per_clk);
     one<6, 16>("v_sqrt_f32", n, d_cyc, d_sink, tick_per_clk);
+    long_body<0, 256>("v_fma_f32", n, d_cyc, d_sink);
+    long_body<0, 2048>("v_fma_f32", n, d_cyc, d_sink);
+    long_body<0, 4096>("v_fma_f32", n, d_cyc, d_sink);
+    long_body<0, 16384>("v_fma_f32", n, d_cyc, d_sink);
+    long_body<1, 4096>("v_add_f32", n, d_cyc, d_sink);
+    long_body<1, 16384>("v_add_f32", n, d_cyc, d_sink);
     banks("v_fma_f32 d, v40, v41, v42   (three banks)", k_fma_3banks, n, d_cyc, d_sink);
     banks("v_fma_f32 d, v40, v44, v41   (two sources of one bank)", k_fma_2of3, n, d_cyc, d_sink);
     banks("v_fma_f32 d, v40, v44, v48   (three sources of one bank)", k_fma_1bank, n, d_cyc, d_sink);
