@@ -86,7 +86,7 @@ def parse(argv=None):
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=1_000_000, help="frames per GPU per step (config 2: 1e6)")
-    ap.add_argument("--placements", type=int, default=4, help="candidate allocations of the output buffer, timed hot and interleaved; another than the first is kept "
+    ap.add_argument("--placements", type=int, default=6, help="candidate allocations of the output buffer, timed hot and interleaved; another than the first is kept "
                                                               "only if it is faster by > 2 %% in BOTH passes (1 = take the first, no study)")
     ap.add_argument("--leg-sustain-s", type=float, default=1.0, help="seconds of back-to-back launches behind the burst of every side leg")
     ap.add_argument("--paired-frames", type=int, default=1_000_000, help="N = 1: frames of the two-frames-per-transform leg (0 = skip)")
